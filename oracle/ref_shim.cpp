@@ -1,0 +1,156 @@
+// TEST INFRASTRUCTURE ONLY -- never linked or imported by the product path.
+//
+// Thin C-ABI harness around the *unmodified* reference library.  It is compiled
+// together with /root/reference/ConvectionKernels_SingleFile.cpp (sources stay
+// where they are; see oracle/Makefile) into oracle/_ref/libcvtt_ref.so, which is
+// git-ignored.  Tests use it to pin the C restatement in oracle/cvtt_oracle.c and
+// bench.py may time it as the "reference" CPU baseline.
+//
+// Entry points take flat arrays of blocks; group g = blocks [8g, 8g+8), exactly
+// what one call of cvtt::Kernels::Encode* consumes (ConvectionKernels.h:241).
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <xmmintrin.h>
+
+#include "ConvectionKernels.h"
+
+namespace
+{
+    void *shimAlloc(void *, size_t size)
+    {
+        void *p = NULL;
+        if (posix_memalign(&p, 64, size) != 0)
+            return NULL;
+        // canonical oracle: scratch starts zeroed (hazard H2)
+        memset(p, 0, size);
+        return p;
+    }
+
+    void shimFree(void *, void *ptr, size_t)
+    {
+        free(ptr);
+    }
+
+    cvtt::Options makeOptions(uint32_t flags, const float *weights4, float threshold, int refineBC7, int refineBC6H, int refineS3TC, int seedPoints)
+    {
+        cvtt::Options o;
+        o.flags = flags;
+        o.threshold = threshold;
+        o.redWeight = weights4[0];
+        o.greenWeight = weights4[1];
+        o.blueWeight = weights4[2];
+        o.alphaWeight = weights4[3];
+        o.refineRoundsBC7 = refineBC7;
+        o.refineRoundsBC6H = refineBC6H;
+        o.refineRoundsS3TC = refineS3TC;
+        o.seedPoints = seedPoints;
+        return o;
+    }
+}
+
+extern "C"
+{
+    // sizeof checks used by the boundary tests
+    size_t ref_sizeof_options() { return sizeof(cvtt::Options); }
+    size_t ref_sizeof_bc7_plan() { return sizeof(cvtt::BC7EncodingPlan); }
+    size_t ref_sizeof_bc7_finetune() { return sizeof(cvtt::BC7FineTuningParams); }
+
+    // Default-constructed PODs, as raw bytes.
+    void ref_default_options(void *out) { cvtt::Options o; memcpy(out, &o, sizeof(o)); }
+    void ref_default_bc7_plan(void *out) { cvtt::BC7EncodingPlan p; memset(out, 0, sizeof(p)); memcpy(out, &p, sizeof(p)); }
+    void ref_bc7_plan_from_quality(void *out, int quality)
+    {
+        cvtt::BC7EncodingPlan p;
+        cvtt::Kernels::ConfigureBC7EncodingPlanFromQuality(p, quality);
+        memcpy(out, &p, sizeof(p));
+    }
+    void ref_bc7_plan_from_finetune(void *out, const void *params)
+    {
+        cvtt::BC7EncodingPlan p;
+        cvtt::BC7FineTuningParams ft;
+        memcpy(&ft, params, sizeof(ft));
+        cvtt::Kernels::ConfigureBC7EncodingPlanFromFineTuningParams(p, ft);
+        memcpy(out, &p, sizeof(p));
+    }
+
+    // rcpps of 0..16 on this host (index 0 unused) -- SURVEY App. A.
+    void ref_probe_rcp(float *out17)
+    {
+        for (int i = 0; i <= 16; i++)
+        {
+            float v = (float)(i == 0 ? 1 : i);
+            __m128 r = _mm_rcp_ps(_mm_set1_ps(v));
+            out17[i] = _mm_cvtss_f32(r);
+        }
+    }
+
+    void ref_encode_bc7(uint8_t *out, const uint8_t *blocks, size_t numBlocks, const void *optionsBytes, const void *planBytes)
+    {
+        cvtt::Options o;
+        memcpy(&o, optionsBytes, sizeof(o));
+        cvtt::BC7EncodingPlan plan;
+        memcpy(&plan, planBytes, sizeof(plan));
+        const cvtt::PixelBlockU8 *in = reinterpret_cast<const cvtt::PixelBlockU8 *>(blocks);
+        for (size_t b = 0; b + cvtt::NumParallelBlocks <= numBlocks; b += cvtt::NumParallelBlocks)
+            cvtt::Kernels::EncodeBC7(out + b * 16, in + b, o, plan);
+    }
+
+    void ref_encode_bc1(uint8_t *out, const uint8_t *blocks, size_t numBlocks, const void *optionsBytes)
+    {
+        cvtt::Options o;
+        memcpy(&o, optionsBytes, sizeof(o));
+        const cvtt::PixelBlockU8 *in = reinterpret_cast<const cvtt::PixelBlockU8 *>(blocks);
+        for (size_t b = 0; b + cvtt::NumParallelBlocks <= numBlocks; b += cvtt::NumParallelBlocks)
+            cvtt::Kernels::EncodeBC1(out + b * 8, in + b, o);
+    }
+
+    void ref_encode_bc6h(uint8_t *out, const uint8_t *blocks, size_t numBlocks, const void *optionsBytes, int isSigned)
+    {
+        cvtt::Options o;
+        memcpy(&o, optionsBytes, sizeof(o));
+        const cvtt::PixelBlockF16 *in = reinterpret_cast<const cvtt::PixelBlockF16 *>(blocks);
+        for (size_t b = 0; b + cvtt::NumParallelBlocks <= numBlocks; b += cvtt::NumParallelBlocks)
+        {
+            if (isSigned)
+                cvtt::Kernels::EncodeBC6HS(out + b * 16, in + b, o);
+            else
+                cvtt::Kernels::EncodeBC6HU(out + b * 16, in + b, o);
+        }
+    }
+
+    // mode: 0 = ETC2 RGB (8 B/block), 1 = ETC2 RGBA (16 B/block), 2 = EAC alpha only (8 B/block)
+    int ref_encode_etc2(uint8_t *out, const uint8_t *blocks, size_t numBlocks, const void *optionsBytes, int mode)
+    {
+        cvtt::Options o;
+        memcpy(&o, optionsBytes, sizeof(o));
+        const cvtt::PixelBlockU8 *in = reinterpret_cast<const cvtt::PixelBlockU8 *>(blocks);
+        cvtt::ETC2CompressionData *data = NULL;
+        if (mode != 2)
+        {
+            data = cvtt::Kernels::AllocETC2Data(shimAlloc, NULL, o);
+            if (!data)
+                return -1;
+        }
+        for (size_t b = 0; b + cvtt::NumParallelBlocks <= numBlocks; b += cvtt::NumParallelBlocks)
+        {
+            if (mode == 0)
+                cvtt::Kernels::EncodeETC2(out + b * 8, in + b, o, data);
+            else if (mode == 1)
+                cvtt::Kernels::EncodeETC2RGBA(out + b * 16, in + b, o, data);
+            else
+                cvtt::Kernels::EncodeETC2Alpha(out + b * 8, in + b, o);
+        }
+        if (data)
+            cvtt::Kernels::ReleaseETC2Data(data, shimFree);
+        return 0;
+    }
+
+    void ref_decode_bc7(uint8_t *outBlocks, const uint8_t *bc, size_t numBlocks)
+    {
+        cvtt::PixelBlockU8 *o = reinterpret_cast<cvtt::PixelBlockU8 *>(outBlocks);
+        for (size_t b = 0; b + cvtt::NumParallelBlocks <= numBlocks; b += cvtt::NumParallelBlocks)
+            cvtt::Kernels::DecodeBC7(o + b, bc + b * 16);
+    }
+}

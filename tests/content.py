@@ -1,0 +1,98 @@
+"""Deterministic test content: groups of 8 PixelBlockU8 covering the cases SURVEY.md §8(c)
+lists (random, smooth gradients, solid colours, two-colour, opaque, binary alpha, min-alpha
+exactly 250 / 251 -- the BC67.cpp:1072 threshold -- and groups mixing opaque and alpha blocks).
+"""
+import numpy as np
+
+from convectionkernels_amd import synth
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def mixed_ldr_blocks(seed, groups):
+    """(groups*8, 16, 4) uint8."""
+    rng = _rng(seed)
+    out = np.zeros((groups * 8, 16, 4), np.uint8)
+    yy, xx = np.divmod(np.arange(16), 4)
+    for g in range(groups):
+        kind = g % 12
+        for b in range(8):
+            blk = out[g * 8 + b]
+            k = kind
+            if kind == 11:  # mix of everything inside one group
+                k = int(rng.integers(0, 11))
+            if k == 0:  # uniform random RGBA
+                blk[:] = rng.integers(0, 256, (16, 4))
+            elif k == 1:  # random opaque
+                blk[:] = rng.integers(0, 256, (16, 4))
+                blk[:, 3] = 255
+            elif k == 2:  # smooth gradient, opaque
+                c0 = rng.integers(0, 256, 3).astype(np.float64)
+                dx = rng.normal(0, 12, 3)
+                dy = rng.normal(0, 12, 3)
+                v = c0[None, :] + xx[:, None] * dx[None, :] + yy[:, None] * dy[None, :]
+                blk[:, :3] = np.clip(np.rint(v), 0, 255)
+                blk[:, 3] = 255
+            elif k == 3:  # smooth gradient with smooth alpha
+                c0 = rng.integers(0, 256, 4).astype(np.float64)
+                dx = rng.normal(0, 10, 4)
+                dy = rng.normal(0, 10, 4)
+                v = c0[None, :] + xx[:, None] * dx[None, :] + yy[:, None] * dy[None, :]
+                blk[:] = np.clip(np.rint(v), 0, 255)
+            elif k == 4:  # solid colour (opaque or not)
+                blk[:] = rng.integers(0, 256, 4)[None, :]
+                if b & 1:
+                    blk[:, 3] = 255
+            elif k == 5:  # two colours along a random partition
+                ca = rng.integers(0, 256, 4)
+                cb = rng.integers(0, 256, 4)
+                m = rng.integers(0, 2, 16).astype(bool)
+                blk[:] = np.where(m[:, None], ca[None, :], cb[None, :])
+                if b & 2:
+                    blk[:, 3] = 255
+            elif k == 6:  # binary (punch-through) alpha over noise
+                blk[:] = rng.integers(0, 256, (16, 4))
+                blk[:, 3] = np.where(rng.integers(0, 2, 16) > 0, 255, 0)
+                if b == 3:
+                    blk[:, 3] = 0
+                if b == 5:
+                    blk[:, 3] = 255
+            elif k == 7:  # min alpha exactly 250 / 251 / 254 / 255
+                blk[:] = rng.integers(0, 256, (16, 4))
+                lo = (250, 251, 254, 255)[b & 3]
+                blk[:, 3] = rng.integers(lo, 256, 16)
+                blk[int(rng.integers(0, 16)), 3] = lo
+            elif k == 8:  # opaque and alpha blocks in the same group
+                blk[:] = rng.integers(0, 256, (16, 4))
+                if b % 3 == 0:
+                    blk[:, 3] = 255
+            elif k == 9:  # low-variance noise around a colour (typical photo block)
+                c0 = rng.integers(16, 240, 4).astype(np.float64)
+                v = c0[None, :] + rng.normal(0, 6, (16, 4))
+                blk[:] = np.clip(np.rint(v), 0, 255)
+                if b & 1:
+                    blk[:, 3] = 255
+            else:  # k == 10: extremes / saturated values
+                blk[:] = rng.choice(np.array([0, 1, 127, 128, 254, 255], np.uint8), (16, 4))
+                if b & 4:
+                    blk[:, 3] = 255
+    return out
+
+
+def known_answer_group_ldr():
+    """SURVEY.md App. H input group (no RNG)."""
+    blk = np.zeros((8, 16, 4), np.uint8)
+    for b in range(8):
+        for p in range(16):
+            for c in range(4):
+                v = (29 * b + 13 * p + 71 * c + (p * p + 3 * b) * (c + 1)) & 0xFF
+                if b >= 4 and c == 3:
+                    v = 255
+                blk[b, p, c] = v
+    return blk
+
+
+def config_blocks(seed, width, height, opaque=False):
+    return synth.tile_blocks(synth.image_rgba8(seed, width, height, opaque=opaque))
