@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): EncodeBC7, default-constructed BC7EncodingPlan +
+default Options, 4096x4096 uniform-random RGBA (SplitMix64 seed 2) per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path over one image's PixelBlocks, inputs resident in HBM.
+With N ranks every rank encodes its own image (block-row shard of an N-times taller image:
+groups are independent) and the packed output is gathered with RCCL
+(all_gather over xGMI) inside the timed step.  value = blocks of all ranks / max-rank time.
+
+Prints ONE JSON line on rank 0, with `roofline` (dominant kernel, HIP events on the launch
+stream) and `cpu_baseline` (the real reference from oracle/_ref when it is present, else the
+C port, timed on this box's host cores on a bounded sample and compared with the GPU output).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_BLOCK = 80  # 64 B PixelBlockU8 in + 16 B out
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(blocks, gpu_out, opt_bytes, plan_bytes, rcp, budget_s=12.0):
+    """Time the CPU path on a bounded sample of the same workload and check GPU == CPU on it."""
+    from oracle import pyref
+    kind = "port"
+    enc = None
+    if pyref.RefLib.available(fast=True):
+        ref = pyref.RefLib(fast=True)
+        if (ref.probe_rcp() == rcp).all():
+            kind = "reference"
+            enc = lambda b: ref.encode_bc7(b, opt_bytes, plan_bytes)
+    if enc is None:
+        orc = pyref.OracleLib()
+        enc = lambda b: orc.encode_bc7(b, opt_bytes, plan_bytes, rcp, 1)
+    cores = os.cpu_count() or 1
+    chunk = 256  # blocks per call (32 groups)
+    n_chunks = blocks.shape[0] // chunk
+    next_chunk = [0]
+    done = []
+    lock = threading.Lock()
+    t0 = time.perf_counter()
+    mism = [0]
+
+    def worker():
+        while True:
+            with lock:
+                i = next_chunk[0]
+                if i >= n_chunks or time.perf_counter() - t0 > budget_s:
+                    return
+                next_chunk[0] += 1
+            out = enc(blocks[i * chunk:(i + 1) * chunk])
+            bad = int((out != gpu_out[i * chunk:(i + 1) * chunk]).any(axis=1).sum())
+            with lock:
+                done.append(chunk)
+                mism[0] += bad
+
+    threads = [threading.Thread(target=worker) for _ in range(cores)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    el = time.perf_counter() - t0
+    nblk = int(sum(done))
+    return {
+        "value": nblk / el / 1e6, "unit": "Mblocks/s", "cores": cores, "kind": kind,
+        "sample": "first %d blocks of the same image, %d threads x %d-block calls, %.1f s" % (nblk, cores, chunk, el),
+        "gpu_mismatching_blocks": mism[0], "blocks_checked": nblk,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=4096, help="image edge in pixels (default: BASELINE config 2)")
+    ap.add_argument("--opaque", action="store_true", help="variant 2b: alpha forced to 255 (modes 0-3 run)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from convectionkernels_amd import api, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    ctx = api.Context(dev.index)
+    rcp = ctx.get_rcp_table()  # this box's host RCPPS: "bit-exact vs the CPU path on the same box"
+    opt, plan = api.Options(), api.BC7EncodingPlan()
+
+    # synthetic input: SplitMix64, seed 2 (+rank for the other shards of the tall image)
+    img = synth.image_rgba8(2 + rank, args.size, args.size, opaque=args.opaque)
+    blocks = synth.tile_blocks(img)
+    nblk = blocks.shape[0]
+    d_in = torch.from_numpy(blocks).to(dev)
+    d_out = torch.empty((nblk, 16), dtype=torch.uint8, device=dev)
+    gathered = torch.empty((world * nblk, 16), dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def step():
+        ctx.encode_bc7(d_in, opt, plan, out=d_out)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, d_out)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # kernel-only timing with events on the launch stream (torch's current stream is the one
+    # handed to the C ABI), per step
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        evs[i][0].record()
+        ctx.encode_bc7(d_in, opt, plan, out=d_out)
+        evs[i][1].record()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, d_out)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in evs]
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    result = None
+    if rank == 0:
+        total_blocks = nblk * world * args.steps
+        mblocks = total_blocks / elapsed / 1e6
+        k_ms = float(np.mean(kernel_ms))
+        achieved = ALGO_BYTES_PER_BLOCK * nblk / (k_ms * 1e-3) / 1e9
+        result = {
+            "metric": "bc7_encode_default_plan_throughput",
+            "value": mblocks,
+            "unit": "Mblocks/s",
+            "gpixel_per_s": mblocks * 16.0 / 1e3,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32+u16 (bit-exact emulation of the reference's SSE2 lanes)",
+            "data": "synthetic",
+            "config": {
+                "workload": "EncodeBC7, BC7EncodingPlan() + Options(), %dx%d SplitMix64 random RGBA%s, seed 2+rank, "
+                            "%d blocks per GPU (BASELINE configs[1])" % (args.size, args.size, " alpha=255" if args.opaque else "", nblk),
+                "flags": "0x%x" % opt.flags, "refineRoundsBC7": opt.refineRoundsBC7,
+                "exchange": "all_gather of packed blocks (RCCL)" if world > 1 else "none",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "cvttmi_bc7_kernel", "kernel_ms": k_ms,
+                "note": "VALU-bound search: %d algorithmic bytes per block; see DESIGN.md for the lane-op model" % ALGO_BYTES_PER_BLOCK,
+            },
+        }
+        if not args.no_cpu and world == 1:
+            out_host = d_out.cpu().numpy()
+            result["cpu_baseline"] = cpu_baseline(blocks, out_host, np.frombuffer(opt.tobytes(), np.uint8).copy(),
+                                                  np.frombuffer(plan.tobytes(), np.uint8).copy(), rcp)
+            result["bit_exact_vs_cpu"] = result["cpu_baseline"]["gpu_mismatching_blocks"] == 0
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

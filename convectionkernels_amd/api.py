@@ -1,0 +1,281 @@
+"""Python host-side mirror of the reference's public interface for the hot path
+(reference ConvectionKernels.h:73-103 ``Options``, 142-199 ``BC7EncodingPlan``, 236-277
+``cvtt::Kernels``), on top of the C ABI in ``include/cvtt_mi355x.h``.
+
+PyTorch is plumbing only (device memory / streams); numpy arrays go through the library's
+own pinned staging.  There is no CPU fallback: if the HIP library cannot be loaded or no
+gfx950 device is present every encode raises ``CvttError``.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libcvtt_mi355x.so")
+
+NumParallelBlocks = 8  # reference ConvectionKernels.h:71
+
+
+class Flags:
+    """cvtt::Flags, reference ConvectionKernels.h:33-69."""
+    BC7_FastIndexing = 0x008
+    BC7_TrySingleColor = 0x010
+    BC7_RespectPunchThrough = 0x020
+    BC6H_FastIndexing = 0x040
+    S3TC_Exhaustive = 0x080
+    S3TC_Paranoid = 0x100
+    Uniform = 0x200
+    ETC_UseFakeBT709 = 0x400
+    ETC_FakeBT709Accurate = 0x800
+    Fastest = BC6H_FastIndexing | BC7_FastIndexing | S3TC_Paranoid
+    Faster = Fastest
+    Fast = BC7_FastIndexing | S3TC_Paranoid
+    Default = BC7_FastIndexing | S3TC_Paranoid
+    Better = S3TC_Paranoid | S3TC_Exhaustive
+    Ultra = BC7_TrySingleColor | S3TC_Paranoid | S3TC_Exhaustive | ETC_FakeBT709Accurate
+
+
+class Options(ctypes.Structure):
+    """cvtt::Options (44 bytes)."""
+    _fields_ = [
+        ("flags", ctypes.c_uint32),
+        ("threshold", ctypes.c_float),
+        ("redWeight", ctypes.c_float),
+        ("greenWeight", ctypes.c_float),
+        ("blueWeight", ctypes.c_float),
+        ("alphaWeight", ctypes.c_float),
+        ("refineRoundsBC7", ctypes.c_int32),
+        ("refineRoundsBC6H", ctypes.c_int32),
+        ("refineRoundsIIC", ctypes.c_int32),
+        ("refineRoundsS3TC", ctypes.c_int32),
+        ("seedPoints", ctypes.c_int32),
+    ]
+
+    def __init__(self, **kw):
+        super().__init__()
+        f32 = np.float32
+        self.flags = Flags.Default
+        self.threshold = 0.5
+        self.redWeight = float(f32(0.2125) / f32(0.7154))
+        self.greenWeight = 1.0
+        self.blueWeight = float(f32(0.0721) / f32(0.7154))
+        self.alphaWeight = 1.0
+        self.refineRoundsBC7 = 2
+        self.refineRoundsBC6H = 3
+        self.refineRoundsIIC = 8
+        self.refineRoundsS3TC = 2
+        self.seedPoints = 4
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError(k)
+            setattr(self, k, v)
+
+    def tobytes(self):
+        return bytes(self)
+
+    @classmethod
+    def frombytes(cls, b):
+        o = cls()
+        ctypes.memmove(ctypes.addressof(o), bytes(b), ctypes.sizeof(cls))
+        return o
+
+
+class BC7EncodingPlan(ctypes.Structure):
+    """cvtt::BC7EncodingPlan (808 bytes); default = every shape and partition, 4 seed points."""
+    kNumRGBAShapes = 129
+    kNumRGBShapes = 243
+    _fields_ = [
+        ("mode1PartitionEnabled", ctypes.c_uint64),
+        ("mode2PartitionEnabled", ctypes.c_uint64),
+        ("mode3PartitionEnabled", ctypes.c_uint64),
+        ("mode0PartitionEnabled", ctypes.c_uint16),
+        ("mode7RGBAPartitionEnabled", ctypes.c_uint64),
+        ("mode7RGBPartitionEnabled", ctypes.c_uint64),
+        ("mode4SP", (ctypes.c_uint8 * 2) * 4),
+        ("mode5SP", ctypes.c_uint8 * 4),
+        ("mode6Enabled", ctypes.c_uint8),
+        ("seedPointsForShapeRGB", ctypes.c_uint8 * 243),
+        ("seedPointsForShapeRGBA", ctypes.c_uint8 * 129),
+        ("rgbaShapeList", ctypes.c_uint8 * 129),
+        ("rgbaNumShapesToEvaluate", ctypes.c_uint8),
+        ("rgbShapeList", ctypes.c_uint8 * 243),
+        ("rgbNumShapesToEvaluate", ctypes.c_uint8),
+    ]
+
+    def __init__(self):
+        super().__init__()
+        full = 0xFFFFFFFFFFFFFFFF
+        self.mode0PartitionEnabled = 0xFFFF
+        self.mode1PartitionEnabled = full
+        self.mode2PartitionEnabled = full
+        self.mode3PartitionEnabled = full
+        self.mode7RGBAPartitionEnabled = full
+        self.mode7RGBPartitionEnabled = full
+        self.mode6Enabled = 1
+        for i in range(4):
+            self.mode4SP[i][0] = 4
+            self.mode4SP[i][1] = 4
+            self.mode5SP[i] = 4
+        for i in range(243):
+            self.rgbShapeList[i] = i
+            self.seedPointsForShapeRGB[i] = 4
+        for i in range(129):
+            self.rgbaShapeList[i] = i
+            self.seedPointsForShapeRGBA[i] = 4
+        self.rgbNumShapesToEvaluate = 243
+        self.rgbaNumShapesToEvaluate = 129
+
+    def tobytes(self):
+        return bytes(self)
+
+    @classmethod
+    def frombytes(cls, b):
+        o = cls()
+        ctypes.memmove(ctypes.addressof(o), bytes(b), ctypes.sizeof(cls))
+        return o
+
+
+assert ctypes.sizeof(Options) == 44
+assert ctypes.sizeof(BC7EncodingPlan) == 808
+
+
+class CvttError(RuntimeError):
+    pass
+
+
+_EXPORTS = (
+    "cvttmi_default_options", "cvttmi_default_bc7_plan", "cvttmi_create", "cvttmi_destroy",
+    "cvttmi_last_error", "cvttmi_set_rcp_table", "cvttmi_get_rcp_table",
+    "cvttmi_encode_bc7_device", "cvttmi_encode_bc7", "cvttmi_timing_enable", "cvttmi_timing_read",
+)
+
+_lib = None
+
+
+def load_library():
+    """dlopen the HIP library (loudly fails when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise CvttError("%s is missing: build it with `make -C convectionkernels_amd/csrc` "
+                        "(or __graft_entry__.build())" % _LIB_PATH)
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name in _EXPORTS:
+        if not hasattr(lib, name):
+            raise CvttError("symbol %s missing from %s" % (name, _LIB_PATH))
+    lib.cvttmi_last_error.restype = ctypes.c_char_p
+    lib.cvttmi_last_error.argtypes = [ctypes.c_void_p]
+    lib.cvttmi_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+    lib.cvttmi_destroy.argtypes = [ctypes.c_void_p]
+    lib.cvttmi_set_rcp_table.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.cvttmi_get_rcp_table.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.cvttmi_encode_bc7_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.cvttmi_encode_bc7.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                      ctypes.c_void_p, ctypes.c_void_p]
+    lib.cvttmi_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.cvttmi_timing_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return _EXPORTS
+
+
+class Context:
+    """One encoder context on one HIP device (tables in HBM, staging buffers, rcp table)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.cvttmi_create(ctypes.byref(self._h), int(device))
+        if rc != 0:
+            raise CvttError("cvttmi_create(device=%d) failed with %d (no gfx950 device?)" % (device, rc))
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            self._lib.cvttmi_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.cvttmi_last_error(self._h)
+            raise CvttError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    # -- reciprocal table (host RCPPS probe; see include/cvtt_mi355x.h) --
+    def get_rcp_table(self):
+        out = np.zeros(17, np.float32)
+        self._check(self._lib.cvttmi_get_rcp_table(self._h, out.ctypes.data), "get_rcp_table")
+        return out
+
+    def set_rcp_table(self, lut):
+        lut = np.ascontiguousarray(lut, np.float32)
+        assert lut.size == 17
+        self._check(self._lib.cvttmi_set_rcp_table(self._h, lut.ctypes.data), "set_rcp_table")
+
+    # -- timing of the kernels launched by *_device calls (HIP events on the launch stream) --
+    def timing_enable(self, on=True):
+        self._check(self._lib.cvttmi_timing_enable(self._h, 1 if on else 0), "timing_enable")
+
+    def timing_read(self):
+        ms = ctypes.c_double()
+        n = ctypes.c_uint64()
+        self._check(self._lib.cvttmi_timing_read(self._h, ctypes.byref(ms), ctypes.byref(n)), "timing_read")
+        return ms.value, n.value
+
+    # -- BC7 --
+    def encode_bc7(self, blocks, options=None, plan=None, out=None, stream=None):
+        """Batched cvtt::Kernels::EncodeBC7.  ``blocks``: (N,16,4) uint8 numpy array (host
+        path) or a torch uint8 tensor on this context's GPU (device path, asynchronous on
+        ``stream`` / the current torch stream).  N must be a multiple of 8."""
+        options = options if options is not None else Options()
+        plan = plan if plan is not None else BC7EncodingPlan()
+        if isinstance(blocks, np.ndarray):
+            b = np.ascontiguousarray(blocks, np.uint8)
+            n = b.size // 64
+            if b.size % 64 or n % NumParallelBlocks:
+                raise CvttError("blocks must hold a multiple of 8 PixelBlockU8")
+            res = np.empty((n, 16), np.uint8) if out is None else out
+            self._check(self._lib.cvttmi_encode_bc7(self._h, res.ctypes.data, b.ctypes.data, n,
+                                                    ctypes.addressof(options), ctypes.addressof(plan)), "encode_bc7")
+            return res
+        import torch
+        if not (isinstance(blocks, torch.Tensor) and blocks.is_cuda and blocks.dtype == torch.uint8):
+            raise CvttError("blocks must be a numpy uint8 array or a CUDA uint8 tensor")
+        b = blocks.contiguous()
+        n = b.numel() // 64
+        if b.numel() % 64 or n % NumParallelBlocks:
+            raise CvttError("blocks must hold a multiple of 8 PixelBlockU8")
+        res = torch.empty((n, 16), dtype=torch.uint8, device=b.device) if out is None else out
+        if stream is None:
+            stream = torch.cuda.current_stream(b.device).cuda_stream
+        self._check(self._lib.cvttmi_encode_bc7_device(self._h, res.data_ptr(), b.data_ptr(), n,
+                                                       ctypes.addressof(options), ctypes.addressof(plan),
+                                                       ctypes.c_void_p(stream)), "encode_bc7_device")
+        return res
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+# ---- cvtt::Kernels-style free functions (8-block call convention of the reference) ----
+def EncodeBC7(pBlocks, options=None, encodingPlan=None, device=0):
+    """cvtt::Kernels::EncodeBC7 (reference ConvectionKernels_API.cpp:41-54): any multiple of
+    NumParallelBlocks blocks; returns the packed 16-byte blocks."""
+    return default_context(device).encode_bc7(pBlocks, options, encodingPlan)

@@ -1,0 +1,37 @@
+// Shared host/device declarations of the MI355X encoder (product code).
+#ifndef CVTTMI_DEVICE_H
+#define CVTTMI_DEVICE_H
+
+#include <stdint.h>
+#include "../../include/cvtt_mi355x.h"
+
+// Constant tables resident in HBM (uploaded once per context, read through the scalar
+// cache: every access in the kernels uses a wave-uniform index).
+struct CvttDeviceTables
+{
+    uint16_t shapeMask[243];   // pixel bitmask of every BC7 shape (tools/gen_tables.py)
+    uint16_t partition2[64];   // two-subset partition bitmaps
+    uint32_t partition3[64];   // three-subset partition maps, 2 bits per pixel
+    uint8_t shapes2[64][2];    // shape ids of the subsets of a two-subset partition
+    uint8_t shapes3[64][3];    // ... three-subset partition
+    uint8_t anchor2[64];
+    uint8_t anchor3[64][2];
+    // Util::ComputeTweakFactors (reference ConvectionKernels_Util.cpp:75-84) evaluated on
+    // the host in binary32 for range = 4, 8, 16 (index = log2(range) - 2)
+    float tweakFactors[3][4][2];
+    float rcpTable[17];        // host RCPPS(i), i = 1..16
+    float rcpMaxIndex[5];      // 1.0f / ((1 << bits) - 1), bits = 0..4 (entry 0 unused)
+};
+
+// Per-launch uniform parameters (kernel argument, lives in SGPRs).
+struct CvttBc7Args
+{
+    float w[4];      // Util::FillWeights (reference ConvectionKernels_Util.cpp:62-73)
+    float wSq[4];    // w*w, rounded once (reference BC67.cpp:1047-1050)
+    float rcpW[4];   // EndpointRefiner::Init m_rcpChannelWeights (EndpointRefiner.h:52-58)
+    uint32_t flags;
+    int32_t refineRounds;
+    uint32_t numBlocks;
+};
+
+#endif

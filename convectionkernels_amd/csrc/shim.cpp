@@ -1,0 +1,427 @@
+// Host side of the C ABI declared in include/cvtt_mi355x.h.
+//
+// Mirrors what the reference's API glue does around its per-format computers
+// (reference ConvectionKernels_API.cpp:41-54: Util::FillWeights, then one Pack per group),
+// except that a call covers a whole batch of groups and the work happens in HIP kernels.
+// There is deliberately no CPU implementation here: without a gfx950 device every encode
+// entry point fails with CVTTMI_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <xmmintrin.h>
+
+#include <string>
+
+#include "cvtt_device.h"
+#include "bc7_tables.h"
+
+extern "C" hipError_t cvttmi_launch_bc7(const void *d_blocks, void *d_out, const CvttBc7Args *args,
+                                        const CvttDeviceTables *d_tables, const cvttmi_bc7_plan *d_plan,
+                                        hipStream_t stream);
+
+static_assert(sizeof(cvttmi_options) == 44, "cvtt::Options layout");
+static_assert(sizeof(cvttmi_bc7_plan) == 808, "cvtt::BC7EncodingPlan layout");
+
+struct cvttmi_context
+{
+    int device;
+    CvttDeviceTables hostTables;
+    CvttDeviceTables *dTables;
+    // plan staging: a small ring of device plan slots so back-to-back launches with
+    // different plans never race with an in-flight kernel
+    static const int kPlanSlots = 8;
+    cvttmi_bc7_plan *dPlans;
+    cvttmi_bc7_plan lastPlan[kPlanSlots];
+    bool planValid[kPlanSlots];
+    int nextPlanSlot;
+    // host-buffer staging
+    void *pinnedIn;
+    void *pinnedOut;
+    size_t pinnedInBytes, pinnedOutBytes;
+    void *dIn;
+    void *dOut;
+    size_t dInBytes, dOutBytes;
+    hipStream_t stream;
+    // timing
+    bool timing;
+    hipEvent_t evStart, evStop;
+    double totalMs;
+    uint64_t launches;
+    std::string lastError;
+};
+
+namespace
+{
+    int fail(cvttmi_context *ctx, int code, const char *what, hipError_t e = hipSuccess)
+    {
+        if (ctx)
+        {
+            ctx->lastError = what;
+            if (e != hipSuccess)
+            {
+                ctx->lastError += ": ";
+                ctx->lastError += hipGetErrorString(e);
+            }
+        }
+        return code;
+    }
+
+    // Util::ComputeTweakFactors, reference ConvectionKernels_Util.cpp:75-84 (binary32 on the host)
+    void tweakFactors(int tweak, int range, float out[2])
+    {
+        const int totalUnits = range - 1;
+        const int minOutsideUnits = (tweak >> 1) & 1;
+        const int maxOutsideUnits = tweak & 1;
+        const int insideUnits = totalUnits - minOutsideUnits - maxOutsideUnits;
+        volatile float a = -static_cast<float>(minOutsideUnits) / static_cast<float>(insideUnits);
+        volatile float b = static_cast<float>(maxOutsideUnits) / static_cast<float>(insideUnits) + 1.0f;
+        out[0] = a;
+        out[1] = b;
+    }
+
+    void fillTables(CvttDeviceTables &t)
+    {
+        memset(&t, 0, sizeof(t));
+        for (int i = 0; i < 243; i++)
+            t.shapeMask[i] = k_shape_mask[i];
+        for (int i = 0; i < 64; i++)
+        {
+            t.partition2[i] = k_partition2[i];
+            t.partition3[i] = k_partition3[i];
+            t.shapes2[i][0] = k_shapes2[i * 2 + 0];
+            t.shapes2[i][1] = k_shapes2[i * 2 + 1];
+            for (int s = 0; s < 3; s++)
+                t.shapes3[i][s] = k_shapes3[i * 3 + s];
+            t.anchor2[i] = k_anchor2[i];
+            t.anchor3[i][0] = k_anchor3[i * 2 + 0];
+            t.anchor3[i][1] = k_anchor3[i * 2 + 1];
+        }
+        for (int r = 0; r < 3; r++)
+            for (int tw = 0; tw < 4; tw++)
+                tweakFactors(tw, 4 << r, t.tweakFactors[r][tw]);
+        for (int i = 0; i <= 16; i++)
+        {
+            const float v = static_cast<float>(i == 0 ? 1 : i);
+            t.rcpTable[i] = _mm_cvtss_f32(_mm_rcp_ps(_mm_set1_ps(v)));
+        }
+        t.rcpMaxIndex[0] = 0.0f;
+        for (int bits = 1; bits <= 4; bits++)
+        {
+            volatile float r = 1.0f / static_cast<float>((1 << bits) - 1);
+            t.rcpMaxIndex[bits] = r;
+        }
+    }
+
+    int uploadTables(cvttmi_context *ctx)
+    {
+        hipError_t e = hipMemcpy(ctx->dTables, &ctx->hostTables, sizeof(CvttDeviceTables), hipMemcpyHostToDevice);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "hipMemcpy(tables)", e);
+        return CVTTMI_OK;
+    }
+
+    int stagePlan(cvttmi_context *ctx, const cvttmi_bc7_plan *plan, hipStream_t stream, const cvttmi_bc7_plan **dPlanOut)
+    {
+        for (int i = 0; i < cvttmi_context::kPlanSlots; i++)
+        {
+            if (ctx->planValid[i] && memcmp(&ctx->lastPlan[i], plan, sizeof(*plan)) == 0)
+            {
+                *dPlanOut = ctx->dPlans + i;
+                return CVTTMI_OK;
+            }
+        }
+        const int slot = ctx->nextPlanSlot;
+        ctx->nextPlanSlot = (slot + 1) % cvttmi_context::kPlanSlots;
+        // the slot may still be read by an earlier launch on another stream: be conservative
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "hipDeviceSynchronize", e);
+        memcpy(&ctx->lastPlan[slot], plan, sizeof(*plan));
+        ctx->planValid[slot] = true;
+        e = hipMemcpy(ctx->dPlans + slot, plan, sizeof(*plan), hipMemcpyHostToDevice);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "hipMemcpy(plan)", e);
+        (void)stream;
+        *dPlanOut = ctx->dPlans + slot;
+        return CVTTMI_OK;
+    }
+
+    int ensureStaging(cvttmi_context *ctx, size_t inBytes, size_t outBytes)
+    {
+        hipError_t e;
+        if (ctx->pinnedInBytes < inBytes)
+        {
+            if (ctx->pinnedIn) hipHostFree(ctx->pinnedIn);
+            if (ctx->dIn) hipFree(ctx->dIn);
+            ctx->pinnedIn = ctx->dIn = NULL;
+            ctx->pinnedInBytes = ctx->dInBytes = 0;
+            if ((e = hipHostMalloc(&ctx->pinnedIn, inBytes)) != hipSuccess) return fail(ctx, CVTTMI_E_HIP, "hipHostMalloc", e);
+            if ((e = hipMalloc(&ctx->dIn, inBytes)) != hipSuccess) return fail(ctx, CVTTMI_E_HIP, "hipMalloc", e);
+            ctx->pinnedInBytes = ctx->dInBytes = inBytes;
+        }
+        if (ctx->pinnedOutBytes < outBytes)
+        {
+            if (ctx->pinnedOut) hipHostFree(ctx->pinnedOut);
+            if (ctx->dOut) hipFree(ctx->dOut);
+            ctx->pinnedOut = ctx->dOut = NULL;
+            ctx->pinnedOutBytes = ctx->dOutBytes = 0;
+            if ((e = hipHostMalloc(&ctx->pinnedOut, outBytes)) != hipSuccess) return fail(ctx, CVTTMI_E_HIP, "hipHostMalloc", e);
+            if ((e = hipMalloc(&ctx->dOut, outBytes)) != hipSuccess) return fail(ctx, CVTTMI_E_HIP, "hipMalloc", e);
+            ctx->pinnedOutBytes = ctx->dOutBytes = outBytes;
+        }
+        return CVTTMI_OK;
+    }
+
+    // Util::FillWeights (reference ConvectionKernels_Util.cpp:62-73) + the derived per-call
+    // constants the reference computes in scalar float on the host.
+    void fillWeightArgs(const cvttmi_options *o, float w[4], float wSq[4], float rcpW[4])
+    {
+        if (o->flags & CVTTMI_FLAG_UNIFORM)
+            w[0] = w[1] = w[2] = w[3] = 1.0f;
+        else
+        {
+            w[0] = o->redWeight;
+            w[1] = o->greenWeight;
+            w[2] = o->blueWeight;
+            w[3] = o->alphaWeight;
+        }
+        for (int ch = 0; ch < 4; ch++)
+        {
+            volatile float sq = w[ch] * w[ch];
+            wSq[ch] = sq;
+            volatile float r = 1.0f;
+            if (w[ch] != 0.0f)
+                r = 1.0f / w[ch];
+            rcpW[ch] = r;
+        }
+    }
+}
+
+extern "C"
+{
+    void cvttmi_default_options(cvttmi_options *out)
+    {
+        // cvtt::Options::Options(), reference ConvectionKernels.h:89-102
+        out->flags = CVTTMI_FLAGS_DEFAULT;
+        out->threshold = 0.5f;
+        out->redWeight = 0.2125f / 0.7154f;
+        out->greenWeight = 1.0f;
+        out->blueWeight = 0.0721f / 0.7154f;
+        out->alphaWeight = 1.0f;
+        out->refineRoundsBC7 = 2;
+        out->refineRoundsBC6H = 3;
+        out->refineRoundsIIC = 8;
+        out->refineRoundsS3TC = 2;
+        out->seedPoints = 4;
+    }
+
+    void cvttmi_default_bc7_plan(cvttmi_bc7_plan *p)
+    {
+        // cvtt::BC7EncodingPlan::BC7EncodingPlan(), reference ConvectionKernels.h:166-198:
+        // every shape, every partition, four seed points
+        memset(p, 0, sizeof(*p));
+        p->mode0PartitionEnabled = 0xffff;
+        p->mode1PartitionEnabled = p->mode2PartitionEnabled = p->mode3PartitionEnabled = ~0ull;
+        p->mode7RGBAPartitionEnabled = p->mode7RGBPartitionEnabled = ~0ull;
+        p->mode6Enabled = 1;
+        memset(p->mode4SP, 4, sizeof(p->mode4SP));
+        memset(p->mode5SP, 4, sizeof(p->mode5SP));
+        memset(p->seedPointsForShapeRGB, 4, sizeof(p->seedPointsForShapeRGB));
+        memset(p->seedPointsForShapeRGBA, 4, sizeof(p->seedPointsForShapeRGBA));
+        for (int i = 0; i < 243; i++)
+            p->rgbShapeList[i] = static_cast<uint8_t>(i);
+        for (int i = 0; i < 129; i++)
+            p->rgbaShapeList[i] = static_cast<uint8_t>(i);
+        p->rgbNumShapesToEvaluate = 243;
+        p->rgbaNumShapesToEvaluate = 129;
+    }
+
+    int cvttmi_create(cvttmi_context **out, int device)
+    {
+        if (!out)
+            return CVTTMI_E_INVALID;
+        *out = NULL;
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+            return CVTTMI_E_NO_DEVICE;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+            return CVTTMI_E_NO_DEVICE;
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return CVTTMI_E_NO_DEVICE; // kernels are built for gfx950 only
+        if (hipSetDevice(device) != hipSuccess)
+            return CVTTMI_E_NO_DEVICE;
+
+        cvttmi_context *ctx = new cvttmi_context();
+        ctx->device = device;
+        ctx->dTables = NULL;
+        ctx->dPlans = NULL;
+        ctx->nextPlanSlot = 0;
+        for (int i = 0; i < cvttmi_context::kPlanSlots; i++)
+            ctx->planValid[i] = false;
+        ctx->pinnedIn = ctx->pinnedOut = ctx->dIn = ctx->dOut = NULL;
+        ctx->pinnedInBytes = ctx->pinnedOutBytes = ctx->dInBytes = ctx->dOutBytes = 0;
+        ctx->stream = NULL;
+        ctx->timing = false;
+        ctx->totalMs = 0.0;
+        ctx->launches = 0;
+        fillTables(ctx->hostTables);
+        hipError_t e;
+        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->dTables), sizeof(CvttDeviceTables))) != hipSuccess ||
+            (e = hipMalloc(reinterpret_cast<void **>(&ctx->dPlans), sizeof(cvttmi_bc7_plan) * cvttmi_context::kPlanSlots)) != hipSuccess ||
+            (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
+            (e = hipEventCreate(&ctx->evStart)) != hipSuccess || (e = hipEventCreate(&ctx->evStop)) != hipSuccess)
+        {
+            delete ctx;
+            return CVTTMI_E_HIP;
+        }
+        if (uploadTables(ctx) != CVTTMI_OK)
+        {
+            delete ctx;
+            return CVTTMI_E_HIP;
+        }
+        *out = ctx;
+        return CVTTMI_OK;
+    }
+
+    void cvttmi_destroy(cvttmi_context *ctx)
+    {
+        if (!ctx)
+            return;
+        hipSetDevice(ctx->device);
+        hipDeviceSynchronize();
+        if (ctx->dTables) hipFree(ctx->dTables);
+        if (ctx->dPlans) hipFree(ctx->dPlans);
+        if (ctx->pinnedIn) hipHostFree(ctx->pinnedIn);
+        if (ctx->pinnedOut) hipHostFree(ctx->pinnedOut);
+        if (ctx->dIn) hipFree(ctx->dIn);
+        if (ctx->dOut) hipFree(ctx->dOut);
+        if (ctx->stream) hipStreamDestroy(ctx->stream);
+        hipEventDestroy(ctx->evStart);
+        hipEventDestroy(ctx->evStop);
+        delete ctx;
+    }
+
+    const char *cvttmi_last_error(const cvttmi_context *ctx)
+    {
+        return ctx ? ctx->lastError.c_str() : "no context";
+    }
+
+    int cvttmi_set_rcp_table(cvttmi_context *ctx, const float lut[17])
+    {
+        if (!ctx || !lut)
+            return CVTTMI_E_INVALID;
+        hipSetDevice(ctx->device);
+        hipDeviceSynchronize();
+        for (int i = 1; i <= 16; i++)
+            ctx->hostTables.rcpTable[i] = lut[i];
+        ctx->hostTables.rcpTable[0] = lut[1];
+        return uploadTables(ctx);
+    }
+
+    int cvttmi_get_rcp_table(const cvttmi_context *ctx, float lut[17])
+    {
+        if (!ctx || !lut)
+            return CVTTMI_E_INVALID;
+        for (int i = 0; i <= 16; i++)
+            lut[i] = ctx->hostTables.rcpTable[i];
+        return CVTTMI_OK;
+    }
+
+    int cvttmi_timing_enable(cvttmi_context *ctx, int enable)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        ctx->timing = enable != 0;
+        ctx->totalMs = 0.0;
+        ctx->launches = 0;
+        return CVTTMI_OK;
+    }
+
+    int cvttmi_timing_read(cvttmi_context *ctx, double *totalMs, uint64_t *launches)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        if (totalMs) *totalMs = ctx->totalMs;
+        if (launches) *launches = ctx->launches;
+        return CVTTMI_OK;
+    }
+
+    int cvttmi_encode_bc7_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
+                                 const cvttmi_options *options, const cvttmi_bc7_plan *plan, void *hipStream)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        if (!d_out || !d_blocks || !options || !plan || (numBlocks % 8) != 0 || numBlocks > 0xfffffff0u)
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        if (options->flags & CVTTMI_FLAG_BC7_TRY_SINGLE_COLOR)
+            return fail(ctx, CVTTMI_E_UNSUPPORTED, "BC7_TrySingleColor is not implemented on the GPU path");
+        if (options->flags & CVTTMI_FLAG_BC7_RESPECT_PUNCHTHROUGH)
+            return fail(ctx, CVTTMI_E_UNSUPPORTED, "BC7_RespectPunchThrough is not implemented on the GPU path");
+        if (numBlocks == 0)
+            return CVTTMI_OK;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        hipStream_t stream = static_cast<hipStream_t>(hipStream);
+
+        const cvttmi_bc7_plan *dPlan = NULL;
+        int rc = stagePlan(ctx, plan, stream, &dPlan);
+        if (rc != CVTTMI_OK)
+            return rc;
+
+        CvttBc7Args args;
+        fillWeightArgs(options, args.w, args.wSq, args.rcpW);
+        args.flags = options->flags;
+        args.refineRounds = options->refineRoundsBC7;
+        args.numBlocks = static_cast<uint32_t>(numBlocks);
+
+        if (ctx->timing)
+            hipEventRecord(ctx->evStart, stream);
+        e = cvttmi_launch_bc7(d_blocks, d_out, &args, ctx->dTables, dPlan, stream);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "bc7 kernel launch", e);
+        if (ctx->timing)
+        {
+            hipEventRecord(ctx->evStop, stream);
+            hipEventSynchronize(ctx->evStop);
+            float ms = 0.0f;
+            hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop);
+            ctx->totalMs += ms;
+            ctx->launches += 1;
+        }
+        return CVTTMI_OK;
+    }
+
+    int cvttmi_encode_bc7(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
+                          const cvttmi_options *options, const cvttmi_bc7_plan *plan)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        if (!out || !blocks || !options || !plan || (numBlocks % 8) != 0)
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        if (numBlocks == 0)
+            return CVTTMI_OK;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        const size_t inBytes = numBlocks * 64, outBytes = numBlocks * 16;
+        int rc = ensureStaging(ctx, inBytes, outBytes);
+        if (rc != CVTTMI_OK)
+            return rc;
+        memcpy(ctx->pinnedIn, blocks, inBytes);
+        if ((e = hipMemcpyAsync(ctx->dIn, ctx->pinnedIn, inBytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "H2D", e);
+        rc = cvttmi_encode_bc7_device(ctx, ctx->dOut, ctx->dIn, numBlocks, options, plan, ctx->stream);
+        if (rc != CVTTMI_OK)
+            return rc;
+        if ((e = hipMemcpyAsync(ctx->pinnedOut, ctx->dOut, outBytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "D2H", e);
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "kernel execution", e);
+        memcpy(out, ctx->pinnedOut, outBytes);
+        return CVTTMI_OK;
+    }
+}

@@ -1,0 +1,130 @@
+/* cvtt_mi355x.h -- C ABI of the MI355X-native block-texture encoder.
+ *
+ * This is the drop-in boundary for the hot path of elasota/ConvectionKernels: the
+ * per-block endpoint / partition / index search behind
+ *     cvtt::Kernels::EncodeBC7        (reference ConvectionKernels.h:251, ConvectionKernels_API.cpp:41-54)
+ *     cvtt::Kernels::EncodeBC1        (reference ConvectionKernels.h:242, ConvectionKernels_API.cpp:86-99)
+ *     cvtt::Kernels::EncodeBC6HU/S    (reference ConvectionKernels.h:249-250, API.cpp:56-84)
+ *     cvtt::Kernels::EncodeETC2[RGBA] (reference ConvectionKernels.h:253-254, API.cpp:216-229, 270-286)
+ *
+ * Plain pointers and sizes only.  The PODs below are byte-compatible with the reference's
+ * cvtt::Options (ConvectionKernels.h:73-103, 44 bytes) and cvtt::BC7EncodingPlan
+ * (ConvectionKernels.h:142-199, 808 bytes), so a reference user passes the address of the
+ * structs they already have.
+ *
+ * Batch semantics: every encode call takes numBlocks (a multiple of 8) PixelBlocks stored
+ * contiguously; group g = blocks [8g, 8g+8) is exactly what ONE call of the corresponding
+ * cvtt::Kernels::Encode* consumes (ConvectionKernels.h:241), including the reference's
+ * cross-lane coupling inside a group.  Output block i is bit-identical
+ * to what the reference's SSE2 path writes for input block i.
+ *
+ * Error behaviour: the reference's entry points are void and assert on NULL
+ * (ConvectionKernels_API.cpp:43-44).  Here every call returns 0 on success or a negative
+ * CVTTMI_E_* code; nothing is written to the output on failure.  There is NO CPU fallback:
+ * if no HIP device / kernel image is available the call fails with CVTTMI_E_NO_DEVICE.
+ */
+#ifndef CVTT_MI355X_H
+#define CVTT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVTTMI_OK 0
+#define CVTTMI_E_INVALID (-1)     /* NULL pointer, numBlocks not a multiple of 8, ... */
+#define CVTTMI_E_UNSUPPORTED (-2) /* flag / format combination not implemented on the GPU path */
+#define CVTTMI_E_NO_DEVICE (-3)   /* no HIP device, or device is not gfx950 */
+#define CVTTMI_E_HIP (-4)         /* a HIP runtime call failed; see cvttmi_last_error() */
+
+/* mirrors cvtt::Flags (ConvectionKernels.h:33-69) */
+#define CVTTMI_FLAG_BC7_FAST_INDEXING 0x008u
+#define CVTTMI_FLAG_BC7_TRY_SINGLE_COLOR 0x010u
+#define CVTTMI_FLAG_BC7_RESPECT_PUNCHTHROUGH 0x020u
+#define CVTTMI_FLAG_BC6H_FAST_INDEXING 0x040u
+#define CVTTMI_FLAG_S3TC_EXHAUSTIVE 0x080u
+#define CVTTMI_FLAG_S3TC_PARANOID 0x100u
+#define CVTTMI_FLAG_UNIFORM 0x200u
+#define CVTTMI_FLAG_ETC_USE_FAKE_BT709 0x400u
+#define CVTTMI_FLAG_ETC_FAKE_BT709_ACCURATE 0x800u
+#define CVTTMI_FLAGS_DEFAULT (CVTTMI_FLAG_BC7_FAST_INDEXING | CVTTMI_FLAG_S3TC_PARANOID)
+
+/* byte image of cvtt::Options, ConvectionKernels.h:73-103 */
+typedef struct cvttmi_options
+{
+    uint32_t flags;
+    float threshold;
+    float redWeight;
+    float greenWeight;
+    float blueWeight;
+    float alphaWeight;
+    int32_t refineRoundsBC7;
+    int32_t refineRoundsBC6H;
+    int32_t refineRoundsIIC;
+    int32_t refineRoundsS3TC;
+    int32_t seedPoints;
+} cvttmi_options;
+
+/* byte image of cvtt::BC7EncodingPlan, ConvectionKernels.h:142-199 */
+typedef struct cvttmi_bc7_plan
+{
+    uint64_t mode1PartitionEnabled;
+    uint64_t mode2PartitionEnabled;
+    uint64_t mode3PartitionEnabled;
+    uint16_t mode0PartitionEnabled;
+    uint64_t mode7RGBAPartitionEnabled;
+    uint64_t mode7RGBPartitionEnabled;
+    uint8_t mode4SP[4][2];
+    uint8_t mode5SP[4];
+    uint8_t mode6Enabled;
+    uint8_t seedPointsForShapeRGB[243];
+    uint8_t seedPointsForShapeRGBA[129];
+    uint8_t rgbaShapeList[129];
+    uint8_t rgbaNumShapesToEvaluate;
+    uint8_t rgbShapeList[243];
+    uint8_t rgbNumShapesToEvaluate;
+} cvttmi_bc7_plan;
+
+typedef struct cvttmi_context cvttmi_context;
+
+/* Default-constructed PODs (cvtt::Options(), cvtt::BC7EncodingPlan()). */
+void cvttmi_default_options(cvttmi_options *out);
+void cvttmi_default_bc7_plan(cvttmi_bc7_plan *out);
+
+/* Create a context on HIP device `device`: uploads the constant tables to HBM and
+ * probes the host's RCPPS table (the reference's EndpointRefiner uses _mm_rcp_ps,
+ * ConvectionKernels_EndpointRefiner.h:106, whose result is CPU-model specific; the
+ * argument is always an integer 1..16, so the kernels take it as a 17-entry table and
+ * "bit-exact vs. the CPU path on the same box" is well defined). */
+int cvttmi_create(cvttmi_context **out, int device);
+void cvttmi_destroy(cvttmi_context *ctx);
+const char *cvttmi_last_error(const cvttmi_context *ctx);
+
+/* Override / read the reciprocal table: lut[i] = rcpps(i), i = 1..16 (lut[0] ignored). */
+int cvttmi_set_rcp_table(cvttmi_context *ctx, const float lut[17]);
+int cvttmi_get_rcp_table(const cvttmi_context *ctx, float lut[17]);
+
+/* ---- device-resident entry points: d_blocks / d_out are HBM pointers on the context's
+ * device; the launch is asynchronous on `hipStream` (a hipStream_t, NULL = default). ---- */
+
+/* replaces cvtt::Kernels::EncodeBC7 (ConvectionKernels_API.cpp:41-54): numBlocks * 64 B
+ * of PixelBlockU8 in, numBlocks * 16 B out. */
+int cvttmi_encode_bc7_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
+                             const cvttmi_options *options, const cvttmi_bc7_plan *plan, void *hipStream);
+
+/* ---- host-buffer convenience entry points: stage through pinned memory, launch, copy
+ * back, synchronise.  Same semantics as the *_device calls. ---- */
+int cvttmi_encode_bc7(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
+                      const cvttmi_options *options, const cvttmi_bc7_plan *plan);
+
+/* Time (ms, HIP events on the launch stream) and launch count of the kernels of the most
+ * recent *_device call sequence since cvttmi_timing_reset(); used by bench.py's roofline. */
+int cvttmi_timing_enable(cvttmi_context *ctx, int enable);
+int cvttmi_timing_read(cvttmi_context *ctx, double *totalMs, uint64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

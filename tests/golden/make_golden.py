@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors with the REAL reference (oracle/_ref, compiled from
+/root/reference by oracle/Makefile with the canonical flags of SURVEY.md App. C).
+
+Run in the build container only:   python tests/golden/make_golden.py
+Outputs (data only -- inputs, expected outputs, the generating host's RCPPS table):
+    tests/golden/bc7_mixed.npz      mixed-content groups x option/plan variants
+    tests/golden/known_answers.npz  SURVEY.md App. H group (BC7/BC1/ETC2RGBA/BC6HU)
+    tests/golden/config_hashes.json SHA-256 of whole-image outputs for the BASELINE configs
+"""
+import hashlib
+import json
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import content  # noqa: E402
+from oracle import pyref  # noqa: E402
+
+
+def bc7_variants(ref):
+    P = pyref
+    v = {
+        "default": (P.make_options(), ref.default_plan()),
+        "uniform": (P.make_options(flags=P.FLAGS_DEFAULT | P.FLAG_UNIFORM), ref.default_plan()),
+        "punchthrough": (P.make_options(flags=P.FLAGS_DEFAULT | P.FLAG_BC7_RESPECT_PUNCHTHROUGH), ref.default_plan()),
+        "better": (P.make_options(flags=P.FLAGS_BETTER), ref.default_plan()),
+        "refine1": (P.make_options(refine_bc7=1), ref.default_plan()),
+        "refine3": (P.make_options(refine_bc7=3), ref.default_plan()),
+        "weights": (P.make_options(weights=(0.5, 1.0, 0.25, 2.0)), ref.default_plan()),
+    }
+    for q in (1, 20, 60, 100):
+        v["quality%d" % q] = (P.make_options(), ref.plan_from_quality(q))
+    return v
+
+
+def parallel_encode(fn, blocks, per_out, threads=8):
+    n = blocks.shape[0]
+    groups = n // 8
+    cuts = [8 * (groups * i // threads) for i in range(threads + 1)]
+    out = np.zeros((n, per_out), np.uint8)
+
+    def work(i):
+        a, b = cuts[i], cuts[i + 1]
+        if b > a:
+            out[a:b] = fn(blocks[a:b])
+
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work, range(threads)))
+    return out
+
+
+def main():
+    ref = pyref.RefLib()
+    fast = pyref.RefLib(fast=True)
+    rcp = ref.probe_rcp()
+
+    # ---- mixed content x variants ----
+    blocks = content.mixed_ldr_blocks(20260929, 24)
+    arrays = {"blocks": blocks, "rcp": rcp}
+    names = []
+    for name, (opt, plan) in bc7_variants(ref).items():
+        out = ref.encode_bc7(blocks, opt, plan)
+        assert (out == fast.encode_bc7(blocks, opt, plan)).all(), name  # BC7 is build-stable
+        arrays["opt_" + name] = opt
+        arrays["plan_" + name] = plan
+        arrays["out_" + name] = out
+        names.append(name)
+    arrays["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "bc7_mixed.npz"), **arrays)
+
+    # ---- known answers (App. H) ----
+    ka = content.known_answer_group_ldr()
+    opt = pyref.make_options()
+    np.savez_compressed(os.path.join(HERE, "known_answers.npz"), blocks=ka, rcp=rcp,
+                        bc7=ref.encode_bc7(ka, opt, ref.default_plan()),
+                        bc1=ref.encode_bc1(ka, opt),
+                        etc2rgba=ref.encode_etc2(ka, opt, 1))
+
+    # ---- whole-image hashes for the BASELINE.json configs ----
+    hashes = {"rcp_hex": [int(x) for x in rcp.view(np.uint32)]}
+    plan = ref.default_plan()
+    b = content.config_blocks(1, 256, 256)
+    hashes["config1_bc1_256_seed1"] = hashlib.sha256(ref.encode_bc1(b, opt).tobytes()).hexdigest()
+    for key, seed, opaque in (("config2_bc7_4096_seed2", 2, False), ("config2b_bc7_4096_seed2_opaque", 2, True)):
+        b = content.config_blocks(seed, 4096, 4096, opaque=opaque)
+        out = parallel_encode(lambda x: fast.encode_bc7(x, opt, plan), b, 16)
+        hashes[key] = hashlib.sha256(out.tobytes()).hexdigest()
+        # first 64 groups kept verbatim so a failing hash can be localised
+        np.save(os.path.join(HERE, key + "_head.npy"), out[:512])
+        print(key, hashes[key])
+    with open(os.path.join(HERE, "config_hashes.json"), "w") as f:
+        json.dump(hashes, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""GPU parity tests (-m gpu): the HIP BC7 path, called through the C ABI, against
+(1) the committed golden vectors from the real reference, (2) the C oracle on seeded inputs,
+(3) oracle/_ref on this box when it travelled, (4) whole-image hashes at BASELINE sizes."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import content
+from oracle import pyref
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+GPU_VARIANTS = ["default", "uniform", "better", "refine1", "refine3", "weights",
+                "quality1", "quality20", "quality60", "quality100"]
+
+
+def _api():
+    from convectionkernels_amd import api
+    return api
+
+
+def _diff(a, b):
+    return np.nonzero((np.asarray(a) != np.asarray(b)).any(axis=1))[0]
+
+
+def test_known_answers(gpu_ctx):
+    api = _api()
+    g = np.load(os.path.join(GOLD, "known_answers.npz"))
+    gpu_ctx.set_rcp_table(g["rcp"])
+    out = gpu_ctx.encode_bc7(g["blocks"], api.Options(), api.BC7EncodingPlan())
+    assert _diff(out, g["bc7"]).size == 0
+    assert out[0].tobytes().hex() == "108a856ce10f2c7dcac90b5c0a5d2acf"
+
+
+@pytest.mark.parametrize("name", GPU_VARIANTS)
+def test_golden_mixed(gpu_ctx, name):
+    api = _api()
+    g = np.load(os.path.join(GOLD, "bc7_mixed.npz"))
+    gpu_ctx.set_rcp_table(g["rcp"])
+    out = gpu_ctx.encode_bc7(g["blocks"], api.Options.frombytes(g["opt_" + name]),
+                             api.BC7EncodingPlan.frombytes(g["plan_" + name]))
+    bad = _diff(out, g["out_" + name])
+    assert bad.size == 0, "blocks %s differ" % bad[:8]
+
+
+def test_vs_oracle_seeded(gpu_ctx, oracle_lib):
+    """fresh seeded content, host RCPPS table of THIS box on both sides"""
+    api = _api()
+    rcp = oracle_lib.probe_rcp()
+    gpu_ctx.set_rcp_table(rcp)
+    blocks = content.mixed_ldr_blocks(4242, 24)
+    for opt in (api.Options(), api.Options(flags=api.Flags.Better), api.Options(flags=api.Flags.Default | api.Flags.Uniform)):
+        exp = oracle_lib.encode_bc7(blocks, np.frombuffer(opt.tobytes(), np.uint8).copy(),
+                                    np.frombuffer(api.BC7EncodingPlan().tobytes(), np.uint8).copy(), rcp, threads=8)
+        out = gpu_ctx.encode_bc7(blocks, opt, api.BC7EncodingPlan())
+        bad = _diff(out, exp)
+        assert bad.size == 0, "flags %x blocks %s" % (opt.flags, bad[:8])
+
+
+def test_vs_reference_on_this_box(gpu_ctx, ref_lib):
+    """bit-exact vs the reference CPU path on the same box (its own RCPPS)"""
+    api = _api()
+    gpu_ctx.set_rcp_table(ref_lib.probe_rcp())
+    blocks = content.config_blocks(2, 256, 256)
+    blocks = np.concatenate([blocks, content.config_blocks(2, 128, 128, opaque=True)])
+    exp = ref_lib.encode_bc7(blocks, ref_lib.default_options(), ref_lib.default_plan())
+    out = gpu_ctx.encode_bc7(blocks, api.Options(), api.BC7EncodingPlan())
+    assert _diff(out, exp).size == 0
+
+
+def test_device_tensor_path_and_ragged_sizes(gpu_ctx, oracle_lib):
+    import torch
+    api = _api()
+    rcp = oracle_lib.probe_rcp()
+    gpu_ctx.set_rcp_table(rcp)
+    blocks = content.mixed_ldr_blocks(77, 5)  # 40 blocks: 2.5 waves
+    exp = oracle_lib.encode_bc7(blocks, pyref.make_options(), np.frombuffer(api.BC7EncodingPlan().tobytes(), np.uint8).copy(), rcp, threads=8)
+    for n in (8, 16, 24, 40):
+        t = torch.from_numpy(blocks[:n].copy()).cuda()
+        out = gpu_ctx.encode_bc7(t, api.Options(), api.BC7EncodingPlan())
+        torch.cuda.synchronize()
+        assert _diff(out.cpu().numpy(), exp[:n]).size == 0
+    # empty input is a no-op, non-multiple of 8 is rejected
+    assert gpu_ctx.encode_bc7(np.zeros((0, 16, 4), np.uint8)).shape[0] == 0
+    with pytest.raises(api.CvttError):
+        gpu_ctx.encode_bc7(np.zeros((4, 16, 4), np.uint8))
+
+
+def test_unsupported_flags_fail_loudly(gpu_ctx):
+    api = _api()
+    with pytest.raises(api.CvttError):
+        gpu_ctx.encode_bc7(np.zeros((8, 16, 4), np.uint8), api.Options(flags=api.Flags.Ultra))
+
+
+def test_config2_full_size_hash(gpu_ctx):
+    """BASELINE config 2: 4096x4096 random RGBA, seed 2 (1,048,576 blocks) -- SHA-256 of the
+    whole output equals the reference's (generated with the recorded RCPPS table)."""
+    import torch
+    api = _api()
+    h = json.load(open(os.path.join(GOLD, "config_hashes.json")))
+    gpu_ctx.set_rcp_table(np.array(h["rcp_hex"], np.uint32).view(np.float32))
+    for key, opaque in (("config2_bc7_4096_seed2", False), ("config2b_bc7_4096_seed2_opaque", True)):
+        blocks = content.config_blocks(2, 4096, 4096, opaque=opaque)
+        t = torch.from_numpy(blocks).cuda()
+        out = gpu_ctx.encode_bc7(t, api.Options(), api.BC7EncodingPlan())
+        torch.cuda.synchronize()
+        out = out.cpu().numpy()
+        head = np.load(os.path.join(GOLD, key + "_head.npy"))
+        assert _diff(out[:512], head).size == 0
+        assert hashlib.sha256(out.tobytes()).hexdigest() == h[key]
