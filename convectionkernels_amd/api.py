@@ -158,13 +158,14 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_LIB_PATH):
+    path = os.environ.get("CVTTMI_LIB", _LIB_PATH)  # override: A/B builds of the same library
+    if not os.path.exists(path):
         raise CvttError("%s is missing: build it with `make -C convectionkernels_amd/csrc` "
-                        "(or __graft_entry__.build())" % _LIB_PATH)
-    lib = ctypes.CDLL(_LIB_PATH)
+                        "(or __graft_entry__.build())" % path)
+    lib = ctypes.CDLL(path)
     for name in _EXPORTS:
         if not hasattr(lib, name):
-            raise CvttError("symbol %s missing from %s" % (name, _LIB_PATH))
+            raise CvttError("symbol %s missing from %s" % (name, path))
     lib.cvttmi_last_error.restype = ctypes.c_char_p
     lib.cvttmi_last_error.argtypes = [ctypes.c_void_p]
     lib.cvttmi_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]

@@ -28,6 +28,11 @@
 
 #include "cvtt_device.h"
 
+// minimum waves per SIMD the register allocator must leave room for (512 VGPR+AGPR / waves)
+#ifndef CVTT_BC7_WAVES
+#define CVTT_BC7_WAVES 3
+#endif
+
 namespace
 {
 typedef uint32_t u32;
@@ -52,6 +57,26 @@ __device__ __forceinline__ float clampRound(float v, float hi)
 __device__ __forceinline__ float byteF(u32 pk, int ch) { return (float)((pk >> (8 * ch)) & 0xffu); }
 __device__ __forceinline__ int byteI(u32 pk, int ch) { return (int)((pk >> (8 * ch)) & 0xffu); }
 
+// Fetch a packed pixel through an empty asm so the optimiser treats it as a fresh value:
+// without it LICM hoists all 64 byte->float conversions (and their weighted products) out of
+// the trial loops and keeps ~190 extra VGPRs alive for the whole kernel.
+__device__ __forceinline__ u32 fetchPixel(u32 pk)
+{
+    asm volatile("" : "+v"(pk));
+    return pk;
+}
+
+// Same trick for wave-uniform values (shape masks): keeps the 16 per-pixel bit tests as
+// s_bitcmp on one SGPR instead of 16 hoisted 64-bit lane masks.
+__device__ __forceinline__ u32 opaqueUniform(u32 v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
+// 24-bit integer multiply-add: full-rate v_mad_i32_i24 (operands here are < 2^16)
+__device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
+
 struct Unfinished
 {
     float base[4];
@@ -75,9 +100,10 @@ __device__ __forceinline__ void pcaEndpoints(const u32 (&pix)[16], u32 mask, con
     {
         if ((mask >> px) & 1u)
         {
+            const u32 pk = fetchPixel(pix[px]);
 #pragma unroll
             for (int ch = 0; ch < N; ch++)
-                centroid[ch] = centroid[ch] + byteF(pix[px], ch) * w[ch];
+                centroid[ch] = centroid[ch] + byteF(pk, ch) * w[ch];
             count = count + 1.0f;
         }
     }
@@ -95,10 +121,11 @@ __device__ __forceinline__ void pcaEndpoints(const u32 (&pix)[16], u32 mask, con
     {
         if ((mask >> px) & 1u)
         {
+            const u32 pk = fetchPixel(pix[px]);
             float diff[N];
 #pragma unroll
             for (int ch = 0; ch < N; ch++)
-                diff[ch] = byteF(pix[px], ch) * w[ch] - centroid[ch];
+                diff[ch] = byteF(pk, ch) * w[ch] - centroid[ch];
             int index = 0;
 #pragma unroll
             for (int row = 0; row < N; row++)
@@ -156,10 +183,11 @@ __device__ __forceinline__ void pcaEndpoints(const u32 (&pix)[16], u32 mask, con
     {
         if ((mask >> px) & 1u)
         {
+            const u32 pk = fetchPixel(pix[px]);
             float dist = 0.0f;
 #pragma unroll
             for (int ch = 0; ch < N; ch++)
-                dist = dist + direction[ch] * (byteF(pix[px], ch) * w[ch] - centroid[ch]);
+                dist = dist + direction[ch] * (byteF(pk, ch) * w[ch] - centroid[ch]);
             minDist = sseMin(minDist, dist);
             maxDist = sseMax(maxDist, dist);
         }
@@ -287,8 +315,8 @@ __device__ __forceinline__ void evalShape(const u32 (&pix)[16], u32 mask, const 
         for (int px = 0; px < 16; px++)
             if ((mask >> px) & 1u)
             {
-                const int d = 255 - byteI(pix[px], 3);
-                acc += (u32)(d * d);
+                const int d = 255 - byteI(fetchPixel(pix[px]), 3);
+                acc = (u32)mad24(d, d, (int)acc);
             }
         staticAlphaError = uniformErr ? (float)(int)acc : (float)(int)acc * A.wSq[3];
     }
@@ -339,7 +367,7 @@ __device__ __forceinline__ void evalShape(const u32 (&pix)[16], u32 mask, const 
                     {
                         origin[ch] = (float)ep[0][ch];
                         epDW[ch] = ((float)ep[1][ch] - origin[ch]) * A.w[ch];
-                        recBase[ch] = ep[0][ch] * 64 + 32;
+                        recBase[ch] = (ep[0][ch] << 6) + 32;
                         recDelta[ch] = ep[1][ch] - ep[0][ch];
                     }
                     float lenSq = epDW[0] * epDW[0];
@@ -353,6 +381,7 @@ __device__ __forceinline__ void evalShape(const u32 (&pix)[16], u32 mask, const 
                         axis[ch] = epDW[ch] * A.w[ch] * mvdls;
                 }
 
+                const u32 m = opaqueUniform(mask);
                 u32 err[4] = {0, 0, 0, 0};
                 float slowErr = 0.0f;
                 float tv[4] = {0, 0, 0, 0}, vs[4] = {0, 0, 0, 0};
@@ -362,9 +391,9 @@ __device__ __forceinline__ void evalShape(const u32 (&pix)[16], u32 mask, const 
 #pragma unroll
                 for (int px = 0; px < 16; px++)
                 {
-                    if ((mask >> px) & 1u)
+                    if ((m >> px) & 1u)
                     {
-                        const u32 pk = pix[px];
+                        const u32 pk = fetchPixel(pix[px]);
                         // SelectIndexLDR (reference IndexSelector.h:124-131)
                         float dist = (byteF(pk, 0) - origin[0]) * axis[0];
 #pragma unroll
@@ -376,13 +405,13 @@ __device__ __forceinline__ void evalShape(const u32 (&pix)[16], u32 mask, const 
                         if (FAST)
                         {
                             // ReconstructLDR_BC7 + ComputeErrorLDR (IndexSelector.h:90-100, BCCommon.h:24-29)
-                            const int wgt = (weightRcp * index + 256) >> 9;
+                            const int wgt = mad24(weightRcp, index, 256) >> 9;
 #pragma unroll
                             for (int ch = 0; ch < NRC; ch++)
                             {
-                                const int rec = (recBase[ch] + wgt * recDelta[ch]) >> 6;
+                                const int rec = mad24(wgt, recDelta[ch], recBase[ch]) >> 6;
                                 const int d = rec - byteI(pk, ch);
-                                err[ch] += (u32)(d * d);
+                                err[ch] = (u32)mad24(d, d, (int)err[ch]);
                             }
                         }
                         else
@@ -398,14 +427,14 @@ __device__ __forceinline__ void evalShape(const u32 (&pix)[16], u32 mask, const 
                                 if (probe == 0) cand = index;
                                 const int baseIndex = index;
                                 (void)baseIndex;
-                                const int wgt = (weightRcp * cand + 256) >> 9;
+                                const int wgt = mad24(weightRcp, cand, 256) >> 9;
                                 u32 e4[4] = {0, 0, 0, 0};
 #pragma unroll
                                 for (int ch = 0; ch < NRC; ch++)
                                 {
-                                    const int rec = (recBase[ch] + wgt * recDelta[ch]) >> 6;
+                                    const int rec = mad24(wgt, recDelta[ch], recBase[ch]) >> 6;
                                     const int d = rec - byteI(pk, ch);
-                                    e4[ch] = (u32)(d * d);
+                                    e4[ch] = (u32)__mul24(d, d);
                                 }
                                 float e;
                                 if (uniformErr)
@@ -659,7 +688,7 @@ __device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int ind
 #pragma unroll
                 for (int ch = 0; ch < 4; ch++)
                 {
-                    recBase[ch] = ep[0][ch] * 64 + 32;
+                    recBase[ch] = (ep[0][ch] << 6) + 32;
                     recDelta[ch] = ep[1][ch] - ep[0][ch];
                 }
             }
@@ -673,7 +702,7 @@ __device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int ind
 #pragma unroll
             for (int px = 0; px < 16; px++)
             {
-                const u32 pk = pix[px];
+                const u32 pk = fetchPixel(pix[px]);
                 float dist = (byteF(pk, 0) - origin[0]) * axis[0];
                 dist = dist + (byteF(pk, 1) - origin[1]) * axis[1];
                 dist = dist + (byteF(pk, 2) - origin[2]) * axis[2];
@@ -683,18 +712,18 @@ __device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int ind
 
                 if (FAST)
                 {
-                    const int wgt = (rgbWR * iRGB + 256) >> 9;
+                    const int wgt = mad24(rgbWR, iRGB, 256) >> 9;
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++)
                     {
-                        const int rec = (recBase[ch] + wgt * recDelta[ch]) >> 6;
+                        const int rec = mad24(wgt, recDelta[ch], recBase[ch]) >> 6;
                         const int d = rec - byteI(pk, ch);
-                        err[ch] += (u32)(d * d);
+                        err[ch] = (u32)mad24(d, d, (int)err[ch]);
                     }
-                    const int wa = (alphaWR * iA + 256) >> 9;
-                    const int recA = (recBase[3] + wa * recDelta[3]) >> 6;
+                    const int wa = mad24(alphaWR, iA, 256) >> 9;
+                    const int recA = mad24(wa, recDelta[3], recBase[3]) >> 6;
                     const int dA = recA - byteI(pk, 3);
-                    err[3] += (u32)(dA * dA);
+                    err[3] = (u32)mad24(dA, dA, (int)err[3]);
                 }
                 else
                 {
@@ -714,19 +743,19 @@ __device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int ind
                             candRGB = (iRGB + 1 < rgbRange - 1) ? iRGB + 1 : rgbRange - 1;
                             candA = (iA + 1 < alphaRange - 1) ? iA + 1 : alphaRange - 1;
                         }
-                        const int wgt = (rgbWR * candRGB + 256) >> 9;
+                        const int wgt = mad24(rgbWR, candRGB, 256) >> 9;
                         u32 e3[3];
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++)
                         {
-                            const int rec = (recBase[ch] + wgt * recDelta[ch]) >> 6;
+                            const int rec = mad24(wgt, recDelta[ch], recBase[ch]) >> 6;
                             const int d = rec - byteI(pk, ch);
-                            e3[ch] = (u32)(d * d);
+                            e3[ch] = (u32)__mul24(d, d);
                         }
-                        const int wa = (alphaWR * candA + 256) >> 9;
-                        const int recA = (recBase[3] + wa * recDelta[3]) >> 6;
+                        const int wa = mad24(alphaWR, candA, 256) >> 9;
+                        const int recA = mad24(wa, recDelta[3], recBase[3]) >> 6;
                         const int dA = recA - byteI(pk, 3);
-                        const u32 e1 = (u32)(dA * dA);
+                        const u32 e1 = (u32)__mul24(dA, dA);
                         float er, ea;
                         if (uniformErr)
                         {
@@ -877,10 +906,11 @@ __device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int ind
 } // namespace
 
 template <bool FAST>
-__global__ __launch_bounds__(64) void cvttmi_bc7_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
                                                         const CvttBc7Args A, const CvttDeviceTables *__restrict__ T,
-                                                        const cvttmi_bc7_plan *__restrict__ plan)
+                                                        const CvttBc7DevicePlan *__restrict__ dplan)
 {
+    const cvttmi_bc7_plan *__restrict__ plan = &dplan->plan;
     const int lane = threadIdx.x;
     const u32 blockIndex = blockIdx.x * 16u + (u32)(lane >> 2);
     const bool valid = blockIndex < A.numBlocks;
@@ -1036,6 +1066,7 @@ __global__ __launch_bounds__(64) void cvttmi_bc7_kernel(const uint8_t *__restric
             {
                 u32 mask = 0xffffu;
                 int numTweak;
+                bool rgbListed = true, rgbaListed = true;
                 if (dual)
                     numTweak = partition ? numSP1 : numSP0;
                 else
@@ -1047,6 +1078,9 @@ __global__ __launch_bounds__(64) void cvttmi_bc7_kernel(const uint8_t *__restric
                         shape = T->shapes3[partition][s];
                     mask = T->shapeMask[shape];
                     numTweak = isRGB ? plan->seedPointsForShapeRGB[shape] : plan->seedPointsForShapeRGBA[shape];
+                    rgbListed = ((dplan->rgbListed[shape >> 5] >> (shape & 31)) & 1u) != 0;
+                    if (!isRGB)
+                        rgbaListed = ((dplan->rgbaListed[shape >> 5] >> (shape & 31)) & 1u) != 0;
                 }
                 if (numTweak > 4)
                     numTweak = 4;
@@ -1061,9 +1095,12 @@ __global__ __launch_bounds__(64) void cvttmi_bc7_kernel(const uint8_t *__restric
 
                 Unfinished u;
                 {
-                    const bool need3 = dual || isRGB || anyWantsExpand;
-                    const bool need4 = !dual && !isRGB && anyWantsPCA4;
+                    const bool need3 = (dual || isRGB || anyWantsExpand) && rgbListed;
+                    const bool need4 = !dual && !isRGB && anyWantsPCA4 && rgbaListed;
                     Unfinished u3, u4;
+#pragma unroll
+                    for (int ch = 0; ch < 4; ch++)
+                        u3.base[ch] = u3.offset[ch] = u4.base[ch] = u4.offset[ch] = 0.0f;
                     if (need3)
                         pcaEndpoints<3>(pix, mask, rw, -1, u3);
                     if (need4)
@@ -1076,18 +1113,32 @@ __global__ __launch_bounds__(64) void cvttmi_bc7_kernel(const uint8_t *__restric
                     }
                     u.base[3] = 255.0f;
                     u.offset[3] = 0.0f;
-                    if (need4 && wantPCA4)
-                        u = u4;
+                    if (!dual && !isRGB)
+                    {
+                        if (wantPCA4)
+                            u = u4; // zeros when the shape is not in rgbaShapeList
+                        else if (!rgbaListed)
+                        {
+#pragma unroll
+                            for (int ch = 0; ch < 4; ch++)
+                                u.base[ch] = u.offset[ch] = 0.0f;
+                        }
+                    }
                 }
 
                 ShapeBest b, bA;
                 bA.err = 0.0f;
                 bA.ep0 = bA.ep1 = bA.idxLo = bA.idxHi = 0;
+#ifndef CVTT_EXP_NO_DUAL
                 if (dual)
                     evalDual<FAST>(pix, mode, partition, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
-                else if (isRGB)
+                else
+#endif
+#ifndef CVTT_EXP_NO_RGB
+                if (isRGB)
                     evalShape<3, FAST>(pix, mask, md, u, numTweak, A, T, numRefine, lane, b);
                 else
+#endif
                     evalShape<4, FAST>(pix, mask, md, u, numTweak, A, T, numRefine, lane, b);
 
                 totalError = totalError + b.err;
@@ -1334,7 +1385,7 @@ __global__ __launch_bounds__(64) void cvttmi_bc7_kernel(const uint8_t *__restric
 }
 
 extern "C" hipError_t cvttmi_launch_bc7(const void *d_blocks, void *d_out, const CvttBc7Args *args,
-                                        const CvttDeviceTables *d_tables, const cvttmi_bc7_plan *d_plan,
+                                        const CvttDeviceTables *d_tables, const CvttBc7DevicePlan *d_plan,
                                         hipStream_t stream)
 {
     const uint32_t waves = (args->numBlocks + 15u) / 16u;

@@ -23,6 +23,17 @@ struct CvttDeviceTables
     float rcpMaxIndex[5];      // 1.0f / ((1 << bits) - 1), bits = 0..4 (entry 0 unused)
 };
 
+// The caller's plan plus two bitmaps derived on the host: which shapes the plan's
+// rgbShapeList / rgbaShapeList actually name.  The reference only computes PCA seeds for
+// listed shapes (BC67.cpp:1085-1144); a shape with seed points that is NOT listed keeps the
+// zero-initialised seeds of the canonical oracle build (hazard H5).
+struct CvttBc7DevicePlan
+{
+    cvttmi_bc7_plan plan;
+    uint32_t rgbListed[8];
+    uint32_t rgbaListed[5];
+};
+
 // Per-launch uniform parameters (kernel argument, lives in SGPRs).
 struct CvttBc7Args
 {

@@ -18,7 +18,7 @@
 #include "bc7_tables.h"
 
 extern "C" hipError_t cvttmi_launch_bc7(const void *d_blocks, void *d_out, const CvttBc7Args *args,
-                                        const CvttDeviceTables *d_tables, const cvttmi_bc7_plan *d_plan,
+                                        const CvttDeviceTables *d_tables, const CvttBc7DevicePlan *d_plan,
                                         hipStream_t stream);
 
 static_assert(sizeof(cvttmi_options) == 44, "cvtt::Options layout");
@@ -32,7 +32,7 @@ struct cvttmi_context
     // plan staging: a small ring of device plan slots so back-to-back launches with
     // different plans never race with an in-flight kernel
     static const int kPlanSlots = 8;
-    cvttmi_bc7_plan *dPlans;
+    CvttBc7DevicePlan *dPlans;
     cvttmi_bc7_plan lastPlan[kPlanSlots];
     bool planValid[kPlanSlots];
     int nextPlanSlot;
@@ -122,7 +122,7 @@ namespace
         return CVTTMI_OK;
     }
 
-    int stagePlan(cvttmi_context *ctx, const cvttmi_bc7_plan *plan, hipStream_t stream, const cvttmi_bc7_plan **dPlanOut)
+    int stagePlan(cvttmi_context *ctx, const cvttmi_bc7_plan *plan, hipStream_t stream, const CvttBc7DevicePlan **dPlanOut)
     {
         for (int i = 0; i < cvttmi_context::kPlanSlots; i++)
         {
@@ -140,7 +140,21 @@ namespace
             return fail(ctx, CVTTMI_E_HIP, "hipDeviceSynchronize", e);
         memcpy(&ctx->lastPlan[slot], plan, sizeof(*plan));
         ctx->planValid[slot] = true;
-        e = hipMemcpy(ctx->dPlans + slot, plan, sizeof(*plan), hipMemcpyHostToDevice);
+        CvttBc7DevicePlan staged;
+        memset(&staged, 0, sizeof(staged));
+        staged.plan = *plan;
+        for (int i = 0; i < plan->rgbNumShapesToEvaluate; i++)
+        {
+            const int shape = plan->rgbShapeList[i];
+            staged.rgbListed[shape >> 5] |= 1u << (shape & 31);
+        }
+        for (int i = 0; i < plan->rgbaNumShapesToEvaluate; i++)
+        {
+            const int shape = plan->rgbaShapeList[i];
+            if (shape < 129)
+                staged.rgbaListed[shape >> 5] |= 1u << (shape & 31);
+        }
+        e = hipMemcpy(ctx->dPlans + slot, &staged, sizeof(staged), hipMemcpyHostToDevice);
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_HIP, "hipMemcpy(plan)", e);
         (void)stream;
@@ -270,7 +284,7 @@ extern "C"
         fillTables(ctx->hostTables);
         hipError_t e;
         if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->dTables), sizeof(CvttDeviceTables))) != hipSuccess ||
-            (e = hipMalloc(reinterpret_cast<void **>(&ctx->dPlans), sizeof(cvttmi_bc7_plan) * cvttmi_context::kPlanSlots)) != hipSuccess ||
+            (e = hipMalloc(reinterpret_cast<void **>(&ctx->dPlans), sizeof(CvttBc7DevicePlan) * cvttmi_context::kPlanSlots)) != hipSuccess ||
             (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
             (e = hipEventCreate(&ctx->evStart)) != hipSuccess || (e = hipEventCreate(&ctx->evStop)) != hipSuccess)
         {
@@ -367,7 +381,7 @@ extern "C"
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
         hipStream_t stream = static_cast<hipStream_t>(hipStream);
 
-        const cvttmi_bc7_plan *dPlan = NULL;
+        const CvttBc7DevicePlan *dPlan = NULL;
         int rc = stagePlan(ctx, plan, stream, &dPlan);
         if (rc != CVTTMI_OK)
             return rc;
