@@ -905,6 +905,18 @@ __device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int ind
 
 } // namespace
 
+// Broadcast the seeds computed by sub-lane `srcSub` of every quad to the whole quad.
+__device__ __forceinline__ void quadBroadcast(Unfinished &dst, const Unfinished &src, int lane, int srcSub)
+{
+    const int from = (lane & ~3) | srcSub;
+#pragma unroll
+    for (int ch = 0; ch < 4; ch++)
+    {
+        dst.base[ch] = __shfl(src.base[ch], from);
+        dst.offset[ch] = __shfl(src.offset[ch], from);
+    }
+}
+
 template <bool FAST>
 __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
                                                         const CvttBc7Args A, const CvttDeviceTables *__restrict__ T,
@@ -957,8 +969,14 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     if (numRefine < 1)
         numRefine = 1;
 
+    // Running best.  The reference walks candidates in a fixed order (single-plane modes
+    // 0,1,2,3,6,7 by partition, then mode 4 / mode 5 by rotation and index selector) and
+    // commits on a strict '<', i.e. it keeps the FIRST candidate that reaches the minimum.
+    // We evaluate in a different order, so every candidate carries its position `seq` in the
+    // reference's order and the commit compares (error, seq) lexicographically.
     WorkState work;
     work.err = FLT_MAX;
+    int workSeq = -1; // nothing committed yet: a candidate must beat FLT_MAX strictly
     work.mode = 0;
     work.partOrIS = 0;
     work.rotation = 0;
@@ -967,70 +985,52 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
         work.ep[s][0] = work.ep[s][1] = 0;
     work.idxLo = work.idxHi = work.idx2Lo = work.idx2Hi = 0;
 
-    // Stage loop.  Stages 0-5: single-plane modes 0,1,2,3,6,7 (reference TrySinglePlane,
-    // BC67.cpp:1146-1660); stages 6-9: mode 4 rotations 0-3; stages 10-13: mode 5 rotations
-    // 0-3 (reference TryDualPlane, BC67.cpp:1678-1963).  The order is the reference's commit
-    // order, so a strict '<' against the running best reproduces its tie-breaking.  Each
-    // heavy routine below has exactly one call site.
-    int curRotation = 0;
-    float rw[4], rwSq[4], rrcpW[4];
-#pragma unroll
-    for (int ch = 0; ch < 4; ch++)
+    // ================================ dual-plane modes 4,5 ================================
+    // reference TryDualPlane, BC67.cpp:1678-1963.  The RGB seeds depend only on the rotation,
+    // so sub-lane r computes them for rotation r once (the reference recomputes them for each
+    // mode / index selector).
     {
-        rw[ch] = A.w[ch];
-        rwSq[ch] = A.wSq[ch];
-        rrcpW[ch] = A.rcpW[ch];
-    }
-
-    for (int stage = 0; stage < 14; stage++)
-    {
-        const bool dual = stage >= 6;
-        ModeDesc md;
-        int numSubsets, numPartitions, rotation = 0;
-        u64 enabled;
-        switch (stage)
+        Unfinished uRot;
         {
-        case 0: md = {0, 3, 4, 4, 5}; numSubsets = 3; numPartitions = 16; enabled = plan->mode0PartitionEnabled; break;
-        case 1: md = {1, 3, 2, 6, 7}; numSubsets = 2; numPartitions = 64; enabled = plan->mode1PartitionEnabled; break;
-        case 2: md = {2, 2, 1, 5, 5}; numSubsets = 3; numPartitions = 64; enabled = plan->mode2PartitionEnabled; break;
-        case 3: md = {3, 2, 4, 7, 0}; numSubsets = 2; numPartitions = 64; enabled = plan->mode3PartitionEnabled; break;
-        case 4: md = {6, 4, 4, 7, 0}; numSubsets = 1; numPartitions = 1; enabled = plan->mode6Enabled ? 1 : 0; break;
-        case 5: md = {7, 2, 4, 5, 6}; numSubsets = 2; numPartitions = 64; enabled = ~0ull; break; // dead mask in the reference (BC67.cpp:1592-1597)
-        default:
-            md = {stage < 10 ? 4 : 5, 2, 1, 0, 0};
-            rotation = (stage - 6) & 3;
-            numSubsets = 1;
-            numPartitions = (stage < 10) ? 2 : 1; // index selectors
-            enabled = ~0ull;
-            break;
-        }
-        const int mode = md.mode;
-        const bool isRGB = mode < 4;
-        // does this mode run for my group?  (wave-uniform skip when it runs for nobody)
-        const bool laneRuns = isRGB ? allowRGBModes : (mode == 7 ? allowMode7 : true);
-        if (__ballot(laneRuns) == 0)
-            continue;
-
-        int numSP0 = 0, numSP1 = 0;
-        if (dual)
-        {
-            if (mode == 4)
-            {
-                numSP0 = plan->mode4SP[rotation][0];
-                numSP1 = plan->mode4SP[rotation][1];
-            }
-            else
-                numSP0 = numSP1 = plan->mode5SP[rotation];
-            if (numSP0 == 0 && numSP1 == 0)
-                continue;
-        }
-
-        if (rotation != curRotation)
-        {
-            // undo the previous exchange, apply the new one (pixels and per-channel constants)
+            u32 rpix[16];
 #pragma unroll
             for (int px = 0; px < 16; px++)
-                pix[px] = rotatePixel(rotatePixel(pix[px], curRotation), rotation);
+                rpix[px] = rotatePixel(pix[px], c);
+            float lw[4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++)
+                lw[ch] = A.w[ch];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+                if (c == ch + 1)
+                {
+                    lw[ch] = A.w[3];
+                    lw[3] = A.w[ch];
+                }
+            pcaEndpoints<3>(rpix, 0xffffu, lw, -1, uRot);
+        }
+
+        int curRotation = 0;
+        for (int cfg = 0; cfg < 12; cfg++)
+        {
+            // cfg order = reference commit order: mode 4 (rot 0: is 0,1; rot 1: ...), then mode 5 rot 0..3
+            const int mode = cfg < 8 ? 4 : 5;
+            const int rotation = cfg < 8 ? (cfg >> 1) : (cfg - 8);
+            const int indexSelector = cfg < 8 ? (cfg & 1) : 0;
+            int numTweak = (mode == 4) ? plan->mode4SP[rotation][indexSelector] : plan->mode5SP[rotation];
+            if (numTweak <= 0)
+                continue;
+            if (numTweak > 4)
+                numTweak = 4;
+
+            if (rotation != curRotation)
+            {
+#pragma unroll
+                for (int px = 0; px < 16; px++)
+                    pix[px] = rotatePixel(rotatePixel(pix[px], curRotation), rotation);
+                curRotation = rotation;
+            }
+            float rw[4], rwSq[4], rrcpW[4];
 #pragma unroll
             for (int ch = 0; ch < 4; ch++)
             {
@@ -1049,146 +1049,215 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                     rwSq[3] = A.wSq[ch];
                     rrcpW[3] = A.rcpW[ch];
                 }
-            curRotation = rotation;
-        }
 
-        for (int partition = 0; partition < numPartitions; partition++)
-        {
-            if (((enabled >> partition) & 1ull) == 0)
-                continue;
+            Unfinished u;
+            quadBroadcast(u, uRot, lane, rotation);
+            ShapeBest b, bA;
+            evalDual<FAST>(pix, mode, indexSelector, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
 
-            float totalError = 0.0f;
-            u32 pe00 = 0, pe01 = 0, pe10 = 0, pe11 = 0, pe20 = 0, pe21 = 0;
-            u32 pIdxLo = 0, pIdxHi = 0, pIdx2Lo = 0, pIdx2Hi = 0;
-            bool skipPartition = false;
-
-            for (int s = 0; s < numSubsets; s++)
+            const float combined = b.err + bA.err; // reference BC67.cpp:1942
+            const int seq = 384 + cfg;
+            if (combined < work.err || (combined == work.err && seq < workSeq))
             {
-                u32 mask = 0xffffu;
-                int numTweak;
-                bool rgbListed = true, rgbaListed = true;
-                if (dual)
-                    numTweak = partition ? numSP1 : numSP0;
+                work.err = combined;
+                workSeq = seq;
+                work.mode = mode;
+                work.rotation = rotation;
+                work.partOrIS = indexSelector;
+                work.ep[0][0] = b.ep0 | bA.ep0;
+                work.ep[0][1] = b.ep1 | bA.ep1;
+                if (indexSelector)
+                {
+                    // index selector 1: the 2-bit set is the alpha plane (BC67.cpp:1953-1957)
+                    work.idxLo = bA.idxLo;
+                    work.idxHi = bA.idxHi;
+                    work.idx2Lo = b.idxLo;
+                    work.idx2Hi = b.idxHi;
+                }
                 else
                 {
-                    int shape = 0;
-                    if (numSubsets == 2)
-                        shape = T->shapes2[partition][s];
-                    else if (numSubsets == 3)
-                        shape = T->shapes3[partition][s];
-                    mask = T->shapeMask[shape];
-                    numTweak = isRGB ? plan->seedPointsForShapeRGB[shape] : plan->seedPointsForShapeRGBA[shape];
-                    rgbListed = ((dplan->rgbListed[shape >> 5] >> (shape & 31)) & 1u) != 0;
-                    if (!isRGB)
-                        rgbaListed = ((dplan->rgbaListed[shape >> 5] >> (shape & 31)) & 1u) != 0;
+                    work.idxLo = b.idxLo;
+                    work.idxHi = b.idxHi;
+                    work.idx2Lo = bA.idxLo;
+                    work.idx2Hi = bA.idxHi;
                 }
-                if (numTweak > 4)
-                    numTweak = 4;
-                if (numTweak <= 0)
-                {
-                    if (dual)
-                        skipPartition = true; // reference BC67.cpp:1729-1730
-                    else
-                        totalError = totalError + FLT_MAX; // shapeBestError stays at its reset value (BC67.cpp:1228-1242)
-                    continue;
-                }
+            }
+        }
+        if (curRotation != 0)
+        {
+#pragma unroll
+            for (int px = 0; px < 16; px++)
+                pix[px] = rotatePixel(pix[px], curRotation);
+        }
+    }
 
-                Unfinished u;
+    // =========================== single-plane modes 0,1,2,3,6,7 ===========================
+    // reference TrySinglePlane, BC67.cpp:1146-1660.  The (partition, subset) pairs of a mode
+    // form a flat list of shape evaluations; it is consumed in batches of four: sub-lane c
+    // runs the PCA seed search for item 4*batch + c (per-lane shape mask), then the four
+    // items are searched one after the other with the shape wave-uniform.
+    for (int stageIter = 0; stageIter < 6; stageIter++)
+    {
+        ModeDesc md;
+        int numSubsets, numPartitions, stage;
+        u64 enabled;
+        switch (stageIter)
+        {
+        case 0: stage = 4; md = {6, 4, 4, 7, 0}; numSubsets = 1; numPartitions = 1; enabled = plan->mode6Enabled ? 1 : 0; break;
+        case 1: stage = 5; md = {7, 2, 4, 5, 6}; numSubsets = 2; numPartitions = 64; enabled = ~0ull; break; // dead mask in the reference (BC67.cpp:1592-1597)
+        case 2: stage = 1; md = {1, 3, 2, 6, 7}; numSubsets = 2; numPartitions = 64; enabled = plan->mode1PartitionEnabled; break;
+        case 3: stage = 3; md = {3, 2, 4, 7, 0}; numSubsets = 2; numPartitions = 64; enabled = plan->mode3PartitionEnabled; break;
+        case 4: stage = 0; md = {0, 3, 4, 4, 5}; numSubsets = 3; numPartitions = 16; enabled = plan->mode0PartitionEnabled; break;
+        default: stage = 2; md = {2, 2, 1, 5, 5}; numSubsets = 3; numPartitions = 64; enabled = plan->mode2PartitionEnabled; break;
+        }
+        const int mode = md.mode;
+        const bool isRGB = mode < 4;
+        // does this mode run for my group?  (wave-uniform skip when it runs for nobody)
+        const bool laneRuns = isRGB ? allowRGBModes : (mode == 7 ? allowMode7 : true);
+        if (__ballot(laneRuns) == 0 || enabled == 0)
+            continue;
+
+        const int numItems = numPartitions * numSubsets;
+        float totalError = 0.0f;
+        u32 pe00 = 0, pe01 = 0, pe10 = 0, pe11 = 0, pe20 = 0, pe21 = 0;
+        u32 pIdxLo = 0, pIdxHi = 0;
+
+        for (int batch = 0; batch * 4 < numItems; batch++)
+        {
+            // ---- seeds for up to four items, one per sub-lane ----
+            Unfinished uMine;
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++)
+                uMine.base[ch] = uMine.offset[ch] = 0.0f;
+            {
+                const int item = batch * 4 + c;
+                int partition, sub;
+                if (numSubsets == 1) { partition = item; sub = 0; }
+                else if (numSubsets == 2) { partition = item >> 1; sub = item & 1; }
+                else { partition = item / 3; sub = item - partition * 3; }
+                const bool live = item < numItems && ((enabled >> partition) & 1ull) != 0;
+                int shape = 0;
+                if (live)
                 {
-                    const bool need3 = (dual || isRGB || anyWantsExpand) && rgbListed;
-                    const bool need4 = !dual && !isRGB && anyWantsPCA4 && rgbaListed;
-                    Unfinished u3, u4;
-#pragma unroll
-                    for (int ch = 0; ch < 4; ch++)
-                        u3.base[ch] = u3.offset[ch] = u4.base[ch] = u4.offset[ch] = 0.0f;
-                    if (need3)
-                        pcaEndpoints<3>(pix, mask, rw, -1, u3);
-                    if (need4)
-                        pcaEndpoints<4>(pix, mask, rw, -1, u4);
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++)
+                    if (numSubsets == 2)
+                        shape = T->shapes2[partition][sub];
+                    else if (numSubsets == 3)
+                        shape = T->shapes3[partition][sub];
+                }
+                const u32 mask = T->shapeMask[shape];
+                const int seeds = isRGB ? plan->seedPointsForShapeRGB[shape] : plan->seedPointsForShapeRGBA[shape];
+                const bool rgbListed = ((dplan->rgbListed[shape >> 5] >> (shape & 31)) & 1u) != 0;
+                const bool rgbaListed = isRGB ? true : (((dplan->rgbaListed[shape >> 5] >> (shape & 31)) & 1u) != 0);
+                const bool wanted = live && seeds != 0;
+                // which PCA does this lane need?  (BC67.cpp:1085-1144; unlisted shapes keep zero seeds)
+                const bool do4 = wanted && !isRGB && wantPCA4 && rgbaListed;
+                const bool do3 = wanted && rgbListed && (isRGB || (!wantPCA4 && rgbaListed));
+                if (__ballot(do3) != 0)
+                {
+                    Unfinished u3;
+                    pcaEndpoints<3>(pix, do3 ? mask : 0u, A.w, -1, u3);
+                    if (do3)
                     {
-                        u.base[ch] = u3.base[ch];
-                        u.offset[ch] = u3.offset[ch];
-                    }
-                    u.base[3] = 255.0f;
-                    u.offset[3] = 0.0f;
-                    if (!dual && !isRGB)
-                    {
-                        if (wantPCA4)
-                            u = u4; // zeros when the shape is not in rgbaShapeList
-                        else if (!rgbaListed)
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
                         {
-#pragma unroll
-                            for (int ch = 0; ch < 4; ch++)
-                                u.base[ch] = u.offset[ch] = 0.0f;
+                            uMine.base[ch] = u3.base[ch];
+                            uMine.offset[ch] = u3.offset[ch];
                         }
                     }
                 }
-
-                ShapeBest b, bA;
-                bA.err = 0.0f;
-                bA.ep0 = bA.ep1 = bA.idxLo = bA.idxHi = 0;
-#ifndef CVTT_EXP_NO_DUAL
-                if (dual)
-                    evalDual<FAST>(pix, mode, partition, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
-                else
-#endif
-#ifndef CVTT_EXP_NO_RGB
-                if (isRGB)
-                    evalShape<3, FAST>(pix, mask, md, u, numTweak, A, T, numRefine, lane, b);
-                else
-#endif
-                    evalShape<4, FAST>(pix, mask, md, u, numTweak, A, T, numRefine, lane, b);
-
-                totalError = totalError + b.err;
-                if (dual)
-                    totalError = b.err + bA.err; // combinedError, reference BC67.cpp:1942
-                if (s == 0) { pe00 = b.ep0 | bA.ep0; pe01 = b.ep1 | bA.ep1; }
-                else if (s == 1) { pe10 = b.ep0; pe11 = b.ep1; }
-                else { pe20 = b.ep0; pe21 = b.ep1; }
-                pIdxLo |= b.idxLo;
-                pIdxHi |= b.idxHi;
-                pIdx2Lo = bA.idxLo;
-                pIdx2Hi = bA.idxHi;
-            }
-            if (skipPartition)
-                continue;
-
-            bool better = laneRuns && (totalError < work.err);
-            if (mode == 7 && anyBlockHasAlpha)
-            {
-                // lanes without alpha may only take partitions enabled for RGB (BC67.cpp:1625-1635)
-                const bool rgbAllowed = ((mode7RGB >> partition) & 1ull) != 0;
-                if (!rgbAllowed)
-                    better = better && blockHasNonMaxAlpha;
-            }
-            if (better)
-            {
-                work.err = totalError;
-                work.mode = mode;
-                work.partOrIS = partition;
-                work.rotation = rotation;
-                work.ep[0][0] = pe00;
-                work.ep[0][1] = pe01;
-                work.ep[1][0] = pe10;
-                work.ep[1][1] = pe11;
-                work.ep[2][0] = pe20;
-                work.ep[2][1] = pe21;
-                if (dual && partition)
+                if (!isRGB && wanted && !wantPCA4 && rgbaListed)
                 {
-                    // index selector 1: the 2-bit set is the alpha plane (BC67.cpp:1953-1957)
-                    work.idxLo = pIdx2Lo;
-                    work.idxHi = pIdx2Hi;
-                    work.idx2Lo = pIdxLo;
-                    work.idx2Hi = pIdxHi;
+                    uMine.base[3] = 255.0f; // ExpandTo<4>(255), UnfinishedEndpoints.h:93-114
+                    uMine.offset[3] = 0.0f;
+                }
+                if (__ballot(do4) != 0)
+                {
+                    Unfinished u4;
+                    pcaEndpoints<4>(pix, do4 ? mask : 0u, A.w, -1, u4);
+                    if (do4)
+                        uMine = u4;
+                }
+            }
+
+            // ---- search the four items ----
+            for (int j = 0; j < 4; j++)
+            {
+                const int item = batch * 4 + j;
+                if (item >= numItems)
+                    break;
+                int partition, sub;
+                if (numSubsets == 1) { partition = item; sub = 0; }
+                else if (numSubsets == 2) { partition = item >> 1; sub = item & 1; }
+                else { partition = item / 3; sub = item - partition * 3; }
+                if (((enabled >> partition) & 1ull) == 0)
+                    continue;
+
+                int shape = 0;
+                if (numSubsets == 2)
+                    shape = T->shapes2[partition][sub];
+                else if (numSubsets == 3)
+                    shape = T->shapes3[partition][sub];
+                const u32 mask = T->shapeMask[shape];
+                int numTweak = isRGB ? plan->seedPointsForShapeRGB[shape] : plan->seedPointsForShapeRGBA[shape];
+                if (numTweak > 4)
+                    numTweak = 4;
+
+                if (sub == 0)
+                {
+                    totalError = 0.0f;
+                    pIdxLo = pIdxHi = 0;
+                }
+                ShapeBest b;
+                if (numTweak <= 0)
+                {
+                    b.err = FLT_MAX; // shapeBestError stays at its reset value (BC67.cpp:1228-1242)
+                    b.ep0 = b.ep1 = b.idxLo = b.idxHi = 0;
                 }
                 else
                 {
-                    work.idxLo = pIdxLo;
-                    work.idxHi = pIdxHi;
-                    work.idx2Lo = pIdx2Lo;
-                    work.idx2Hi = pIdx2Hi;
+                    Unfinished u;
+                    quadBroadcast(u, uMine, lane, j);
+#ifndef CVTT_EXP_NO_RGB
+                    if (isRGB)
+                        evalShape<3, FAST>(pix, mask, md, u, numTweak, A, T, numRefine, lane, b);
+                    else
+#endif
+                        evalShape<4, FAST>(pix, mask, md, u, numTweak, A, T, numRefine, lane, b);
+                }
+                totalError = totalError + b.err;
+                if (sub == 0) { pe00 = b.ep0; pe01 = b.ep1; }
+                else if (sub == 1) { pe10 = b.ep0; pe11 = b.ep1; }
+                else { pe20 = b.ep0; pe21 = b.ep1; }
+                pIdxLo |= b.idxLo;
+                pIdxHi |= b.idxHi;
+
+                if (sub == numSubsets - 1)
+                {
+                    const int seq = stage * 64 + partition;
+                    bool better = laneRuns && (totalError < work.err || (totalError == work.err && seq < workSeq));
+                    if (mode == 7 && anyBlockHasAlpha)
+                    {
+                        // lanes without alpha may only take partitions enabled for RGB (BC67.cpp:1625-1635)
+                        const bool rgbAllowed = ((mode7RGB >> partition) & 1ull) != 0;
+                        if (!rgbAllowed)
+                            better = better && blockHasNonMaxAlpha;
+                    }
+                    if (better)
+                    {
+                        work.err = totalError;
+                        workSeq = seq;
+                        work.mode = mode;
+                        work.partOrIS = partition;
+                        work.ep[0][0] = pe00;
+                        work.ep[0][1] = pe01;
+                        work.ep[1][0] = pe10;
+                        work.ep[1][1] = pe11;
+                        work.ep[2][0] = pe20;
+                        work.ep[2][1] = pe21;
+                        work.idxLo = pIdxLo;
+                        work.idxHi = pIdxHi;
+                    }
                 }
             }
         }
