@@ -148,6 +148,7 @@ _EXPORTS = (
     "cvttmi_default_options", "cvttmi_default_bc7_plan", "cvttmi_create", "cvttmi_destroy",
     "cvttmi_last_error", "cvttmi_set_rcp_table", "cvttmi_get_rcp_table",
     "cvttmi_encode_bc7_device", "cvttmi_encode_bc7", "cvttmi_timing_enable", "cvttmi_timing_read",
+    "cvttmi_set_exhaustive",
 )
 
 _lib = None
@@ -177,6 +178,7 @@ def load_library():
     lib.cvttmi_encode_bc7.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                       ctypes.c_void_p, ctypes.c_void_p]
     lib.cvttmi_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.cvttmi_set_exhaustive.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_timing_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
     _lib = lib
     return lib
@@ -223,6 +225,10 @@ class Context:
         lut = np.ascontiguousarray(lut, np.float32)
         assert lut.size == 17
         self._check(self._lib.cvttmi_set_rcp_table(self._h, lut.ctypes.data), "set_rcp_table")
+
+    def set_exhaustive(self, on=True):
+        """search every candidate like the reference (default: exact branch-and-bound pruning)"""
+        self._check(self._lib.cvttmi_set_exhaustive(self._h, 1 if on else 0), "set_exhaustive")
 
     # -- timing of the kernels launched by *_device calls (HIP events on the launch stream) --
     def timing_enable(self, on=True):

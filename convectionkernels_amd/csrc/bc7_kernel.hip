@@ -84,16 +84,22 @@ struct Unfinished
 };
 
 // ---- EndpointSelector<N,8> (reference EndpointSelector.h:33-149,
-// PackedCovarianceMatrix.h:29-59), one lane, pixels of `mask` in ascending order -----------
+// PackedCovarianceMatrix.h:29-59), one lane, pixels of `mask` in ascending order.  Split in
+// two so that the branch-and-bound test below can run between the passes. -----------------
 template <int N>
-__device__ __forceinline__ void pcaEndpoints(const u32 (&pix)[16], u32 mask, const float (&w)[4], int swapCh,
-                                             Unfinished &u)
+struct Moments
 {
-    // swapCh: channel exchanged with alpha (dual-plane rotation), -1 = none
     float centroid[N];
+    float cov[N * (N + 1) / 2]; // lower triangle, row-major: (row,col) at row*(row+1)/2+col
+};
+
+// passes 0 and 1: centroid and scatter matrix of the pre-weighted pixels
+template <int N>
+__device__ __forceinline__ void pcaMoments(const u32 (&pix)[16], u32 mask, const float (&w)[4], Moments<N> &m)
+{
 #pragma unroll
     for (int ch = 0; ch < N; ch++)
-        centroid[ch] = 0.0f;
+        m.centroid[ch] = 0.0f;
     float count = 0.0f;
 #pragma unroll
     for (int px = 0; px < 16; px++)
@@ -103,19 +109,18 @@ __device__ __forceinline__ void pcaEndpoints(const u32 (&pix)[16], u32 mask, con
             const u32 pk = fetchPixel(pix[px]);
 #pragma unroll
             for (int ch = 0; ch < N; ch++)
-                centroid[ch] = centroid[ch] + byteF(pk, ch) * w[ch];
+                m.centroid[ch] = m.centroid[ch] + byteF(pk, ch) * w[ch];
             count = count + 1.0f;
         }
     }
     const float denom = safeDenom(count);
 #pragma unroll
     for (int ch = 0; ch < N; ch++)
-        centroid[ch] = centroid[ch] / denom;
+        m.centroid[ch] = m.centroid[ch] / denom;
 
-    float cov[N * (N + 1) / 2];
 #pragma unroll
     for (int i = 0; i < N * (N + 1) / 2; i++)
-        cov[i] = 0.0f;
+        m.cov[i] = 0.0f;
 #pragma unroll
     for (int px = 0; px < 16; px++)
     {
@@ -125,19 +130,25 @@ __device__ __forceinline__ void pcaEndpoints(const u32 (&pix)[16], u32 mask, con
             float diff[N];
 #pragma unroll
             for (int ch = 0; ch < N; ch++)
-                diff[ch] = byteF(pk, ch) * w[ch] - centroid[ch];
+                diff[ch] = byteF(pk, ch) * w[ch] - m.centroid[ch];
             int index = 0;
 #pragma unroll
             for (int row = 0; row < N; row++)
 #pragma unroll
                 for (int col = 0; col <= row; col++)
                 {
-                    cov[index] = cov[index] + diff[row] * diff[col];
+                    m.cov[index] = m.cov[index] + diff[row] * diff[col];
                     index++;
                 }
         }
     }
+}
 
+// power iteration, pass 2 and GetEndpoints
+template <int N>
+__device__ __forceinline__ void pcaFinish(const u32 (&pix)[16], u32 mask, const float (&w)[4], const Moments<N> &m,
+                                          Unfinished &u)
+{
     float approx[N];
 #pragma unroll
     for (int ch = 0; ch < N; ch++)
@@ -154,7 +165,7 @@ __device__ __forceinline__ void pcaEndpoints(const u32 (&pix)[16], u32 mask, con
             {
                 const int hi = row > col ? row : col;
                 const int lo = row > col ? col : row;
-                sum = sum + approx[col] * cov[hi * (hi + 1) / 2 + lo];
+                sum = sum + approx[col] * m.cov[hi * (hi + 1) / 2 + lo];
             }
             product[row] = sum;
         }
@@ -187,7 +198,7 @@ __device__ __forceinline__ void pcaEndpoints(const u32 (&pix)[16], u32 mask, con
             float dist = 0.0f;
 #pragma unroll
             for (int ch = 0; ch < N; ch++)
-                dist = dist + direction[ch] * (byteF(pk, ch) * w[ch] - centroid[ch]);
+                dist = dist + direction[ch] * (byteF(pk, ch) * w[ch] - m.centroid[ch]);
             minDist = sseMin(minDist, dist);
             maxDist = sseMax(maxDist, dist);
         }
@@ -195,12 +206,63 @@ __device__ __forceinline__ void pcaEndpoints(const u32 (&pix)[16], u32 mask, con
 #pragma unroll
     for (int ch = 0; ch < N; ch++)
     {
-        const float mn = centroid[ch] + direction[ch] * minDist;
-        const float mx = centroid[ch] + direction[ch] * maxDist;
+        const float mn = m.centroid[ch] + direction[ch] * minDist;
+        const float mx = m.centroid[ch] + direction[ch] * maxDist;
         u.base[ch] = mn / w[ch];
         u.offset[ch] = (mx - mn) / w[ch];
     }
-    (void)swapCh;
+}
+
+template <int N>
+__device__ __forceinline__ void pcaEndpoints(const u32 (&pix)[16], u32 mask, const float (&w)[4], int, Unfinished &u)
+{
+    Moments<N> m;
+    pcaMoments<N>(pix, mask, w, m);
+    pcaFinish<N>(pix, mask, w, m, u);
+}
+
+// ---- exact branch-and-bound: a rigorous lower bound on the error of ANY trial of a shape --
+// Every reconstructed colour of a trial is floor(I + 0.5) per channel for a point I on the
+// segment between the two (quantised) endpoints (IndexSelector.h:90-100), so in the weighted
+// metric it lies within delta = 0.5*sqrt(sum w_ch^2) of some line L.  Hence for every pixel
+// the trial's error is >= max(0, d - delta)^2 >= d^2 - 2*delta*d, d = weighted distance to L,
+// and with D2 = sum d^2 >= R (R = total-least-squares residual of the shape = trace(S) -
+// lambda_max(S), S the scatter matrix that PCA pass 1 accumulates anyway) and sum d <=
+// sqrt(n*D2):   error >= R - 2*delta*sqrt(n*R)   whenever R >= n*delta^2.
+// lambda_max is over-estimated by trace(S^4)^(1/4), so R is under-estimated; the result is
+// scaled down by 1e-4 to absorb the float rounding of S, of this computation and of the
+// reference's own error sums.  A candidate whose bound exceeds the current best can never be
+// committed (the commit needs error <= best), so skipping it leaves the output bit-identical.
+template <int N>
+__device__ __forceinline__ float shapeErrorLowerBound(const Moments<N> &m, float n, float delta)
+{
+    float trace = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        trace += m.cov[i * (i + 1) / 2 + i];
+    // S2 = S*S (symmetric), trace(S^4) = ||S2||_F^2
+    float t4 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++)
+        {
+            float e = 0.0f;
+#pragma unroll
+            for (int k = 0; k < N; k++)
+            {
+                const int a0 = i > k ? i : k, a1 = i > k ? k : i;
+                const int b0 = j > k ? j : k, b1 = j > k ? k : j;
+                e += m.cov[a0 * (a0 + 1) / 2 + a1] * m.cov[b0 * (b0 + 1) / 2 + b1];
+            }
+            t4 += (i == j ? 1.0f : 2.0f) * e * e;
+        }
+    const float lambdaUp = __fsqrt_rn(__fsqrt_rn(t4)) * 1.0001f;
+    const float r = trace - lambdaUp;
+    float lb = 0.0f;
+    if (r > n * delta * delta)
+        lb = (r - 2.0f * delta * __fsqrt_rn(n * r)) * 0.9999f;
+    return lb > 0.0f ? lb : 0.0f; // NaN / inf inputs end up as "no bound"
 }
 
 // ---- BC7 endpoint quantisation (reference BC67.cpp:829-860); all values fit 16 bits ----
@@ -1122,13 +1184,16 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
         u32 pe00 = 0, pe01 = 0, pe10 = 0, pe11 = 0, pe20 = 0, pe21 = 0;
         u32 pIdxLo = 0, pIdxHi = 0;
 
+        int deadPartition = -1; // partition proven unable to win (skipped from here on)
+
         for (int batch = 0; batch * 4 < numItems; batch++)
         {
-            // ---- seeds for up to four items, one per sub-lane ----
-            Unfinished uMine;
-#pragma unroll
-            for (int ch = 0; ch < 4; ch++)
-                uMine.base[ch] = uMine.offset[ch] = 0.0f;
+            // ---- phase A: moments (and the error lower bound) of up to four items, one per sub-lane ----
+            Moments<3> m3;
+            Moments<4> m4;
+            u32 myMask = 0;
+            bool do3 = false, do4 = false, expandAlpha = false;
+            float lbMine = 0.0f;
             {
                 const int item = batch * 4 + c;
                 int partition, sub;
@@ -1144,19 +1209,95 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                     else if (numSubsets == 3)
                         shape = T->shapes3[partition][sub];
                 }
-                const u32 mask = T->shapeMask[shape];
+                myMask = T->shapeMask[shape];
                 const int seeds = isRGB ? plan->seedPointsForShapeRGB[shape] : plan->seedPointsForShapeRGBA[shape];
                 const bool rgbListed = ((dplan->rgbListed[shape >> 5] >> (shape & 31)) & 1u) != 0;
                 const bool rgbaListed = isRGB ? true : (((dplan->rgbaListed[shape >> 5] >> (shape & 31)) & 1u) != 0);
                 const bool wanted = live && seeds != 0;
                 // which PCA does this lane need?  (BC67.cpp:1085-1144; unlisted shapes keep zero seeds)
-                const bool do4 = wanted && !isRGB && wantPCA4 && rgbaListed;
-                const bool do3 = wanted && rgbListed && (isRGB || (!wantPCA4 && rgbaListed));
+                do4 = wanted && !isRGB && wantPCA4 && rgbaListed;
+                do3 = wanted && rgbListed && (isRGB || (!wantPCA4 && rgbaListed));
+                expandAlpha = !isRGB && wanted && !wantPCA4 && rgbaListed;
+                const float n = (float)__popc(myMask);
                 if (__ballot(do3) != 0)
                 {
+                    pcaMoments<3>(pix, do3 ? myMask : 0u, A.w, m3);
+                    if (do3 && A.prune)
+                        lbMine = shapeErrorLowerBound<3>(m3, n, isRGB ? A.delta3 : A.delta4);
+                }
+                if (__ballot(do4) != 0)
+                {
+                    pcaMoments<4>(pix, do4 ? myMask : 0u, A.w, m4);
+                    if (do4 && A.prune)
+                        lbMine = shapeErrorLowerBound<4>(m4, n, A.delta4);
+                }
+                if (isRGB && wanted && A.prune)
+                {
+                    // the RGB modes add the exact error of replacing alpha by 255 (BC67.cpp:1250-1264)
+                    u32 acc = 0;
+#pragma unroll
+                    for (int px = 0; px < 16; px++)
+                        if ((myMask >> px) & 1u)
+                        {
+                            const int d = 255 - byteI(pix[px], 3);
+                            acc = (u32)mad24(d, d, (int)acc);
+                        }
+                    const float st = (A.flags & CVTTMI_FLAG_UNIFORM) ? (float)(int)acc : (float)(int)acc * A.wSq[3];
+                    lbMine = lbMine + st;
+                }
+                if (live && seeds == 0)
+                    lbMine = FLT_MAX; // its error stays FLT_MAX (BC67.cpp:1228-1242)
+                if (!live)
+                    lbMine = 0.0f;
+            }
+
+            // ---- phase B: which items can still win?  bound = errors already known for the
+            // partition + lower bounds of its items in this batch; wave-uniform decisions ----
+            bool pruneItem[4];
+            float lbItem[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                lbItem[j] = __shfl(lbMine, (lane & ~3) | j);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                pruneItem[j] = false;
+                const int item = batch * 4 + j;
+                if (A.prune && item < numItems)
+                {
+                    int partition, sub;
+                    if (numSubsets == 1) { partition = item; sub = 0; }
+                    else if (numSubsets == 2) { partition = item >> 1; sub = item & 1; }
+                    else { partition = item / 3; sub = item - partition * 3; }
+                    // items of the same partition inside this batch: [jLo, jHi]
+                    int jLo = j - sub;
+                    int jHi = jLo + numSubsets - 1;
+                    float bound = (jLo < 0) ? totalError : 0.0f; // earlier subsets came with previous batches
+                    if (jLo < 0) jLo = 0;
+                    if (jHi > 3) jHi = 3;
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (i >= jLo && i <= jHi)
+                            bound = bound + lbItem[i];
+                    bound = bound * 0.999999f;
+                    const bool cannotWin = bound > work.err;
+                    pruneItem[j] = __ballot(valid && laneRuns && !cannotWin) == 0;
+                }
+            }
+
+            // ---- phase C: finish the seed search of the items that survive ----
+            Unfinished uMine;
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++)
+                uMine.base[ch] = uMine.offset[ch] = 0.0f;
+            {
+                const bool myPruned = (c == 0) ? pruneItem[0] : (c == 1) ? pruneItem[1] : (c == 2) ? pruneItem[2] : pruneItem[3];
+                const bool fin3 = do3 && !myPruned, fin4 = do4 && !myPruned;
+                if (__ballot(fin3) != 0)
+                {
                     Unfinished u3;
-                    pcaEndpoints<3>(pix, do3 ? mask : 0u, A.w, -1, u3);
-                    if (do3)
+                    pcaFinish<3>(pix, fin3 ? myMask : 0u, A.w, m3, u3);
+                    if (fin3)
                     {
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++)
@@ -1166,21 +1307,21 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                         }
                     }
                 }
-                if (!isRGB && wanted && !wantPCA4 && rgbaListed)
+                if (expandAlpha)
                 {
                     uMine.base[3] = 255.0f; // ExpandTo<4>(255), UnfinishedEndpoints.h:93-114
                     uMine.offset[3] = 0.0f;
                 }
-                if (__ballot(do4) != 0)
+                if (__ballot(fin4) != 0)
                 {
                     Unfinished u4;
-                    pcaEndpoints<4>(pix, do4 ? mask : 0u, A.w, -1, u4);
-                    if (do4)
+                    pcaFinish<4>(pix, fin4 ? myMask : 0u, A.w, m4, u4);
+                    if (fin4)
                         uMine = u4;
                 }
             }
 
-            // ---- search the four items ----
+            // ---- phase D: search the four items ----
             for (int j = 0; j < 4; j++)
             {
                 const int item = batch * 4 + j;
@@ -1191,6 +1332,11 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 else if (numSubsets == 2) { partition = item >> 1; sub = item & 1; }
                 else { partition = item / 3; sub = item - partition * 3; }
                 if (((enabled >> partition) & 1ull) == 0)
+                    continue;
+                const bool prunedNow = (j == 0) ? pruneItem[0] : (j == 1) ? pruneItem[1] : (j == 2) ? pruneItem[2] : pruneItem[3];
+                if (prunedNow)
+                    deadPartition = partition;
+                if (partition == deadPartition)
                     continue;
 
                 int shape = 0;
@@ -1258,6 +1404,14 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                         work.idxLo = pIdxLo;
                         work.idxHi = pIdxHi;
                     }
+                }
+                else if (A.prune)
+                {
+                    // the partition already costs more than the best: its remaining subsets
+                    // cannot bring it back (errors are >= 0)
+                    const bool cannotWin = totalError * 0.999999f > work.err;
+                    if (__ballot(valid && laneRuns && !cannotWin) == 0)
+                        deadPartition = partition;
                 }
             }
         }

@@ -43,6 +43,10 @@ struct CvttBc7Args
     uint32_t flags;
     int32_t refineRounds;
     uint32_t numBlocks;
+    // exact branch-and-bound (bc7_kernel.hip: shapeErrorLowerBound): 0 = exhaustive search
+    uint32_t prune;
+    float delta3;    // 0.5*sqrt(wSq[0]+wSq[1]+wSq[2]), rounded up
+    float delta4;    // 0.5*sqrt(wSq[0..3]), rounded up
 };
 
 #endif

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <xmmintrin.h>
+#include <math.h>
 
 #include <string>
 
@@ -44,6 +45,7 @@ struct cvttmi_context
     void *dOut;
     size_t dInBytes, dOutBytes;
     hipStream_t stream;
+    bool exhaustive; // search every candidate even when it provably cannot win
     // timing
     bool timing;
     hipEvent_t evStart, evStop;
@@ -279,6 +281,7 @@ extern "C"
         ctx->pinnedInBytes = ctx->pinnedOutBytes = ctx->dInBytes = ctx->dOutBytes = 0;
         ctx->stream = NULL;
         ctx->timing = false;
+        ctx->exhaustive = getenv("CVTTMI_EXHAUSTIVE") != NULL && atoi(getenv("CVTTMI_EXHAUSTIVE")) != 0;
         ctx->totalMs = 0.0;
         ctx->launches = 0;
         fillTables(ctx->hostTables);
@@ -344,6 +347,14 @@ extern "C"
         return CVTTMI_OK;
     }
 
+    int cvttmi_set_exhaustive(cvttmi_context *ctx, int exhaustive)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        ctx->exhaustive = exhaustive != 0;
+        return CVTTMI_OK;
+    }
+
     int cvttmi_timing_enable(cvttmi_context *ctx, int enable)
     {
         if (!ctx)
@@ -391,6 +402,13 @@ extern "C"
         args.flags = options->flags;
         args.refineRounds = options->refineRoundsBC7;
         args.numBlocks = static_cast<uint32_t>(numBlocks);
+        args.prune = ctx->exhaustive ? 0u : 1u;
+        {
+            const double s3 = (double)args.wSq[0] + (double)args.wSq[1] + (double)args.wSq[2];
+            const double s4 = s3 + (double)args.wSq[3];
+            args.delta3 = static_cast<float>(0.5 * sqrt(s3) * 1.000001);
+            args.delta4 = static_cast<float>(0.5 * sqrt(s4) * 1.000001);
+        }
 
         if (ctx->timing)
             hipEventRecord(ctx->evStart, stream);

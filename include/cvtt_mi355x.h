@@ -119,6 +119,13 @@ int cvttmi_encode_bc7_device(cvttmi_context *ctx, void *d_out, const void *d_blo
 int cvttmi_encode_bc7(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
                       const cvttmi_options *options, const cvttmi_bc7_plan *plan);
 
+/* Search strategy.  By default the kernels skip candidates (partitions / subsets) whose
+ * rigorous error lower bound already exceeds the best candidate found so far -- an exact
+ * branch-and-bound: the output is bit-identical to the exhaustive search the reference
+ * performs.  exhaustive != 0 evaluates every candidate like the reference does (same output,
+ * slower); the environment variable CVTTMI_EXHAUSTIVE=1 sets the default of new contexts. */
+int cvttmi_set_exhaustive(cvttmi_context *ctx, int exhaustive);
+
 /* Time (ms, HIP events on the launch stream) and launch count of the kernels of the most
  * recent *_device call sequence since cvttmi_timing_reset(); used by bench.py's roofline. */
 int cvttmi_timing_enable(cvttmi_context *ctx, int enable);
