@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--size", type=int, default=4096, help="image edge in pixels (default: BASELINE config 2)")
     ap.add_argument("--opaque", action="store_true", help="variant 2b: alpha forced to 255 (modes 0-3 run)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--exhaustive", action="store_true",
+                    help="evaluate every candidate like the reference (default: exact branch-and-bound, same output)")
     args = ap.parse_args()
 
     import torch
@@ -106,6 +108,7 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     ctx = api.Context(dev.index)
+    ctx.set_exhaustive(args.exhaustive)
     rcp = ctx.get_rcp_table()  # this box's host RCPPS: "bit-exact vs the CPU path on the same box"
     opt, plan = api.Options(), api.BC7EncodingPlan()
 
@@ -175,6 +178,8 @@ def main():
                             "%d blocks per GPU (BASELINE configs[1])" % (args.size, args.size, " alpha=255" if args.opaque else "", nblk),
                 "flags": "0x%x" % opt.flags, "refineRoundsBC7": opt.refineRoundsBC7,
                 "exchange": "all_gather of packed blocks (RCCL)" if world > 1 else "none",
+                "search": "exhaustive (every candidate evaluated, as the reference does)" if args.exhaustive else
+                          "exact branch-and-bound (candidates whose rigorous error lower bound exceeds the running best are skipped; output bit-identical)",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -183,6 +188,21 @@ def main():
                 "note": "VALU-bound search: %d algorithmic bytes per block; see DESIGN.md for the lane-op model" % ALGO_BYTES_PER_BLOCK,
             },
         }
+        if world == 1 and not args.exhaustive:
+            # the same workload with pruning off, for reference (not the headline value)
+            ctx.set_exhaustive(True)
+            ctx.encode_bc7(d_in, opt, plan, out=d_out)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            out_pruned = d_out.clone()
+            a.record()
+            ctx.encode_bc7(d_in, opt, plan, out=d_out)
+            b.record()
+            torch.cuda.synchronize()
+            result["exhaustive_search"] = {"value": nblk / a.elapsed_time(b) / 1e3, "unit": "Mblocks/s",
+                                           "kernel_ms": a.elapsed_time(b),
+                                           "identical_output": bool(torch.equal(out_pruned, d_out))}
+            ctx.set_exhaustive(False)
         if not args.no_cpu and world == 1:
             out_host = d_out.cpu().numpy()
             result["cpu_baseline"] = cpu_baseline(blocks, out_host, np.frombuffer(opt.tobytes(), np.uint8).copy(),

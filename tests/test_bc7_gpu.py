@@ -72,6 +72,25 @@ def test_vs_reference_on_this_box(gpu_ctx, ref_lib):
     assert _diff(out, exp).size == 0
 
 
+def test_pruned_equals_exhaustive(gpu_ctx):
+    """the branch-and-bound search (default) and the exhaustive search give identical blocks"""
+    import torch
+    api = _api()
+    blocks = np.concatenate([content.mixed_ldr_blocks(31337, 48), content.config_blocks(9, 128, 128),
+                             content.config_blocks(10, 128, 128, opaque=True)])
+    t = torch.from_numpy(blocks).cuda()
+    try:
+        for opt in (api.Options(), api.Options(flags=api.Flags.Better), api.Options(flags=api.Flags.Default | api.Flags.Uniform),
+                    api.Options(redWeight=3.0, greenWeight=0.25, blueWeight=1.5, alphaWeight=0.1)):
+            gpu_ctx.set_exhaustive(False)
+            a = gpu_ctx.encode_bc7(t, opt).cpu().numpy()
+            gpu_ctx.set_exhaustive(True)
+            b = gpu_ctx.encode_bc7(t, opt).cpu().numpy()
+            assert _diff(a, b).size == 0
+    finally:
+        gpu_ctx.set_exhaustive(False)
+
+
 def test_device_tensor_path_and_ragged_sizes(gpu_ctx, oracle_lib):
     import torch
     api = _api()

@@ -1,0 +1,68 @@
+"""world_size-2 gloo test of the N>1 path: block-row sharding never splits a group and the
+gathered output equals the single-process output.  The per-shard encoder here is the CPU
+oracle (test infrastructure) -- the GPU run uses the HIP path with the same sharding code."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from convectionkernels_amd import sharding, api
+from oracle import pyref
+import content
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+orc = pyref.OracleLib()
+rcp = np.array([1.0] + [1.0 / i for i in range(1, 17)], np.float32)
+opt = pyref.make_options()
+plan = np.frombuffer(api.BC7EncodingPlan().tobytes(), np.uint8).copy()
+def encode(t):
+    return torch.from_numpy(orc.encode_bc7(t.numpy(), opt, plan, rcp, 2))
+for rows, per_row in ((6, 8), (5, 16), (3, 24), (7, 8)):
+    blocks = content.mixed_ldr_blocks(5, rows * per_row // 8 + 1)[:rows * per_row]
+    full = sharding.encode_sharded(encode, torch.from_numpy(blocks), rows, per_row, 16)
+    if rank == 0:
+        np.save(os.path.join(os.environ["OUT_DIR"], "out_%%d_%%d.npy" %% (rows, per_row)), full.numpy())
+dist.destroy_process_group()
+''' % (ROOT, ROOT)
+
+
+def test_shard_ranges_are_group_aligned_and_cover():
+    from convectionkernels_amd import sharding
+    for rows, per_row in ((4096, 4096), (6, 8), (5, 16), (3, 12), (7, 4), (1, 8)):
+        for world in (1, 2, 3, 4, 8):
+            prev = 0
+            for r in range(world):
+                lo, hi = sharding.shard_block_rows(rows, per_row, r, world)
+                assert lo == prev and lo % 8 == 0 and hi >= lo
+                prev = hi
+            assert prev == rows * per_row
+    # 16384^2 over 8 GPUs: 512 block rows of 4096 blocks each per rank
+    assert sharding.shard_block_rows(4096, 4096, 3, 8) == (3 * 512 * 4096, 4 * 512 * 4096)
+
+
+def test_two_rank_gloo_matches_single_process(tmp_path, oracle_lib):
+    import content
+    from convectionkernels_amd import api
+    from oracle import pyref
+    env = dict(os.environ, OUT_DIR=str(tmp_path), MASTER_ADDR="127.0.0.1")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29731", str(script)], env=env,
+                          timeout=600)
+    rcp = np.array([1.0] + [1.0 / i for i in range(1, 17)], np.float32)
+    plan = np.frombuffer(api.BC7EncodingPlan().tobytes(), np.uint8).copy()
+    for rows, per_row in ((6, 8), (5, 16), (3, 24), (7, 8)):
+        blocks = content.mixed_ldr_blocks(5, rows * per_row // 8 + 1)[:rows * per_row]
+        n = blocks.shape[0] // 8 * 8
+        exp = oracle_lib.encode_bc7(blocks[:n], pyref.make_options(), plan, rcp, 4)
+        got = np.load(tmp_path / ("out_%d_%d.npy" % (rows, per_row)))
+        assert got.shape[0] == rows * per_row
+        assert (got[:n] == exp).all()

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 CSVs written by tools/profile_round.sh into one small JSON/markdown
+summary (the raw counter_collection CSVs have one row per counter per dispatch)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+out_dir = sys.argv[1]
+summary = {}
+
+
+def load(path):
+    rows = list(csv.DictReader(open(path)))
+    return [r for r in rows if "cvttmi" in r["Kernel_Name"]]
+
+
+for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
+    f = glob.glob(os.path.join(out_dir, sub, "*counter_collection.csv"))
+    if not f:
+        continue
+    rows = load(f[0])
+    if not rows:
+        continue
+    # first (and normally only un-warmed) dispatch of the encode kernel; with the exhaustive
+    # comparison launch in bench.py there can be several -- keep dispatches apart
+    by_disp = {}
+    for r in rows:
+        by_disp.setdefault(r["Dispatch_Id"], {"kernel": r["Kernel_Name"].split("(")[0], "vgpr": r["VGPR_Count"],
+                                              "sgpr": r["SGPR_Count"], "scratch": r["Scratch_Size"],
+                                              "grid": r["Grid_Size"], "wg": r["Workgroup_Size"],
+                                              "dur_us": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+                                              "counters": {}})
+        c = by_disp[r["Dispatch_Id"]]["counters"]
+        c[r["Counter_Name"]] = c.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    summary[sub] = list(by_disp.values())
+
+stats = glob.glob(os.path.join(out_dir, "trace", "*kernel_stats.csv"))
+if stats:
+    summary["kernel_stats"] = [r for r in csv.DictReader(open(stats[0]))]
+
+# derived numbers for the first dispatch
+try:
+    d = summary["pmc_sq"][0]
+    c = d["counters"]
+    xcd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0           # summed over the 8 XCDs
+    simd_cycles = xcd_cycles * 1024                    # 256 CUs x 4 SIMDs
+    d["derived"] = {
+        "clock_ghz": xcd_cycles / (d["dur_us"] * 1e3),
+        "valu_insts_per_wave": c["SQ_INSTS_VALU"] / (int(d["grid"]) / 64),
+        "valu_busy_frac(ACTIVE_INST_VALU*4/simd_cycles)": c["SQ_ACTIVE_INST_VALU"] * 4 / simd_cycles,
+        "avg_waves_per_simd(WAVE_CYCLES*4/simd_cycles)": c["SQ_WAVE_CYCLES"] * 4 / simd_cycles,
+        "cycles_per_valu_inst": c["SQ_ACTIVE_INST_VALU"] * 4 / c["SQ_INSTS_VALU"],
+    }
+except Exception as e:  # noqa
+    summary["derived_error"] = str(e)
+try:
+    fetch = summary["pmc_fetch"][0]["counters"]["FETCH_SIZE"]
+    write = summary["pmc_write"][0]["counters"]["WRITE_SIZE"]
+    # MI355X_MICROARCH.md: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the
+    # bytes of a wide coalesced stream -> doubled
+    summary["hbm_traffic_bytes_per_launch"] = {"fetch_kib_raw": fetch, "write_kib_raw": write,
+                                               "bytes_corrected": (2 * fetch + write) * 1024}
+except Exception as e:  # noqa
+    summary["traffic_error"] = str(e)
+json.dump(summary, open(os.path.join(out_dir, "summary.json"), "w"), indent=1)
+print(json.dumps(summary.get("pmc_sq", [{}])[0].get("derived", {}), indent=1))
+print(json.dumps(summary.get("hbm_traffic_bytes_per_launch", {})))
