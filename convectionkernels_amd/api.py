@@ -148,7 +148,7 @@ _EXPORTS = (
     "cvttmi_default_options", "cvttmi_default_bc7_plan", "cvttmi_create", "cvttmi_destroy",
     "cvttmi_last_error", "cvttmi_set_rcp_table", "cvttmi_get_rcp_table",
     "cvttmi_encode_bc7_device", "cvttmi_encode_bc7", "cvttmi_timing_enable", "cvttmi_timing_read",
-    "cvttmi_set_exhaustive",
+    "cvttmi_set_exhaustive", "cvttmi_encode_bc1_device", "cvttmi_encode_bc1",
 )
 
 _lib = None
@@ -177,6 +177,9 @@ def load_library():
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.cvttmi_encode_bc7.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                       ctypes.c_void_p, ctypes.c_void_p]
+    lib.cvttmi_encode_bc1_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                             ctypes.c_void_p, ctypes.c_void_p]
+    lib.cvttmi_encode_bc1.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.cvttmi_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_set_exhaustive.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_timing_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
@@ -272,6 +275,38 @@ class Context:
         return res
 
 
+    # -- generic helper for the formats without a plan argument --
+    def _encode_simple(self, host_fn, dev_fn, what, blocks, options, out, stream, in_bytes, out_bytes):
+        options = options if options is not None else Options()
+        if isinstance(blocks, np.ndarray):
+            b = np.ascontiguousarray(blocks)
+            n = b.nbytes // in_bytes
+            if b.nbytes % in_bytes or n % NumParallelBlocks:
+                raise CvttError("blocks must hold a multiple of 8 pixel blocks")
+            res = np.empty((n, out_bytes), np.uint8) if out is None else out
+            self._check(host_fn(self._h, res.ctypes.data, b.ctypes.data, n, ctypes.addressof(options)), what)
+            return res
+        import torch
+        if not (isinstance(blocks, torch.Tensor) and blocks.is_cuda):
+            raise CvttError("blocks must be a numpy array or a CUDA tensor")
+        b = blocks.contiguous()
+        nbytes = b.numel() * b.element_size()
+        n = nbytes // in_bytes
+        if nbytes % in_bytes or n % NumParallelBlocks:
+            raise CvttError("blocks must hold a multiple of 8 pixel blocks")
+        res = torch.empty((n, out_bytes), dtype=torch.uint8, device=b.device) if out is None else out
+        if stream is None:
+            stream = torch.cuda.current_stream(b.device).cuda_stream
+        self._check(dev_fn(self._h, res.data_ptr(), b.data_ptr(), n, ctypes.addressof(options), ctypes.c_void_p(stream)), what)
+        return res
+
+    # -- BC1 --
+    def encode_bc1(self, blocks, options=None, out=None, stream=None):
+        """Batched cvtt::Kernels::EncodeBC1: (N,16,4) uint8 -> (N,8) uint8."""
+        return self._encode_simple(self._lib.cvttmi_encode_bc1, self._lib.cvttmi_encode_bc1_device, "encode_bc1",
+                                   blocks, options, out, stream, 64, 8)
+
+
 _default_ctx = {}
 
 
@@ -286,3 +321,8 @@ def EncodeBC7(pBlocks, options=None, encodingPlan=None, device=0):
     """cvtt::Kernels::EncodeBC7 (reference ConvectionKernels_API.cpp:41-54): any multiple of
     NumParallelBlocks blocks; returns the packed 16-byte blocks."""
     return default_context(device).encode_bc7(pBlocks, options, encodingPlan)
+
+
+def EncodeBC1(pBlocks, options=None, device=0):
+    """cvtt::Kernels::EncodeBC1 (reference ConvectionKernels_API.cpp:86-99)."""
+    return default_context(device).encode_bc1(pBlocks, options)

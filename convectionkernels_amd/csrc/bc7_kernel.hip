@@ -33,238 +33,10 @@
 #define CVTT_BC7_WAVES 3
 #endif
 
+#include "cvtt_kernel_common.h"
+
 namespace
 {
-typedef uint32_t u32;
-typedef uint64_t u64;
-
-// ---- lane arithmetic helpers -------------------------------------------------------
-// MINPS/MAXPS operand order (reference ParallelMath.h:522-559): second operand wins on
-// NaN / equal.
-__device__ __forceinline__ float sseMin(float a, float b) { return a < b ? a : b; }
-__device__ __forceinline__ float sseMax(float a, float b) { return a > b ? a : b; }
-__device__ __forceinline__ float safeDenom(float v) { return v == 0.0f ? 1.0f : v; }
-
-// Clamp then CVTPS2DQ under round-to-nearest-even (reference ParallelMath.h:561-567,
-// 936-946).  fminf/fmaxf match MINPS/MAXPS here: a NaN input yields `hi`, and the sign of
-// a zero result is irrelevant once converted to an integer.  Result stays a float
-// (integral value) so callers can use it as both index and refiner weight.
-__device__ __forceinline__ float clampRound(float v, float hi)
-{
-    return rintf(fmaxf(fminf(v, hi), 0.0f));
-}
-
-__device__ __forceinline__ float byteF(u32 pk, int ch) { return (float)((pk >> (8 * ch)) & 0xffu); }
-__device__ __forceinline__ int byteI(u32 pk, int ch) { return (int)((pk >> (8 * ch)) & 0xffu); }
-
-// Fetch a packed pixel through an empty asm so the optimiser treats it as a fresh value:
-// without it LICM hoists all 64 byte->float conversions (and their weighted products) out of
-// the trial loops and keeps ~190 extra VGPRs alive for the whole kernel.
-__device__ __forceinline__ u32 fetchPixel(u32 pk)
-{
-    asm volatile("" : "+v"(pk));
-    return pk;
-}
-
-// Same trick for wave-uniform values (shape masks): keeps the 16 per-pixel bit tests as
-// s_bitcmp on one SGPR instead of 16 hoisted 64-bit lane masks.
-__device__ __forceinline__ u32 opaqueUniform(u32 v)
-{
-    asm volatile("" : "+s"(v));
-    return v;
-}
-
-// 24-bit integer multiply-add: full-rate v_mad_i32_i24 (operands here are < 2^16)
-__device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
-
-struct Unfinished
-{
-    float base[4];
-    float offset[4];
-};
-
-// ---- EndpointSelector<N,8> (reference EndpointSelector.h:33-149,
-// PackedCovarianceMatrix.h:29-59), one lane, pixels of `mask` in ascending order.  Split in
-// two so that the branch-and-bound test below can run between the passes. -----------------
-template <int N>
-struct Moments
-{
-    float centroid[N];
-    float cov[N * (N + 1) / 2]; // lower triangle, row-major: (row,col) at row*(row+1)/2+col
-};
-
-// passes 0 and 1: centroid and scatter matrix of the pre-weighted pixels
-template <int N>
-__device__ __forceinline__ void pcaMoments(const u32 (&pix)[16], u32 mask, const float (&w)[4], Moments<N> &m)
-{
-#pragma unroll
-    for (int ch = 0; ch < N; ch++)
-        m.centroid[ch] = 0.0f;
-    float count = 0.0f;
-#pragma unroll
-    for (int px = 0; px < 16; px++)
-    {
-        if ((mask >> px) & 1u)
-        {
-            const u32 pk = fetchPixel(pix[px]);
-#pragma unroll
-            for (int ch = 0; ch < N; ch++)
-                m.centroid[ch] = m.centroid[ch] + byteF(pk, ch) * w[ch];
-            count = count + 1.0f;
-        }
-    }
-    const float denom = safeDenom(count);
-#pragma unroll
-    for (int ch = 0; ch < N; ch++)
-        m.centroid[ch] = m.centroid[ch] / denom;
-
-#pragma unroll
-    for (int i = 0; i < N * (N + 1) / 2; i++)
-        m.cov[i] = 0.0f;
-#pragma unroll
-    for (int px = 0; px < 16; px++)
-    {
-        if ((mask >> px) & 1u)
-        {
-            const u32 pk = fetchPixel(pix[px]);
-            float diff[N];
-#pragma unroll
-            for (int ch = 0; ch < N; ch++)
-                diff[ch] = byteF(pk, ch) * w[ch] - m.centroid[ch];
-            int index = 0;
-#pragma unroll
-            for (int row = 0; row < N; row++)
-#pragma unroll
-                for (int col = 0; col <= row; col++)
-                {
-                    m.cov[index] = m.cov[index] + diff[row] * diff[col];
-                    index++;
-                }
-        }
-    }
-}
-
-// power iteration, pass 2 and GetEndpoints
-template <int N>
-__device__ __forceinline__ void pcaFinish(const u32 (&pix)[16], u32 mask, const float (&w)[4], const Moments<N> &m,
-                                          Unfinished &u)
-{
-    float approx[N];
-#pragma unroll
-    for (int ch = 0; ch < N; ch++)
-        approx[ch] = 1.0f;
-    for (int it = 0; it < 8; it++)
-    {
-        float product[N];
-#pragma unroll
-        for (int row = 0; row < N; row++)
-        {
-            float sum = 0.0f;
-#pragma unroll
-            for (int col = 0; col < N; col++)
-            {
-                const int hi = row > col ? row : col;
-                const int lo = row > col ? col : row;
-                sum = sum + approx[col] * m.cov[hi * (hi + 1) / 2 + lo];
-            }
-            product[row] = sum;
-        }
-        float largest = product[0];
-#pragma unroll
-        for (int ch = 1; ch < N; ch++)
-            largest = sseMax(largest, product[ch]);
-        largest = safeDenom(largest);
-#pragma unroll
-        for (int ch = 0; ch < N; ch++)
-            approx[ch] = product[ch] / largest;
-    }
-    float approxLen = 0.0f;
-#pragma unroll
-    for (int ch = 0; ch < N; ch++)
-        approxLen = approxLen + approx[ch] * approx[ch];
-    approxLen = safeDenom(__fsqrt_rn(approxLen));
-    float direction[N];
-#pragma unroll
-    for (int ch = 0; ch < N; ch++)
-        direction[ch] = approx[ch] / approxLen;
-
-    float minDist = FLT_MAX, maxDist = -FLT_MAX;
-#pragma unroll
-    for (int px = 0; px < 16; px++)
-    {
-        if ((mask >> px) & 1u)
-        {
-            const u32 pk = fetchPixel(pix[px]);
-            float dist = 0.0f;
-#pragma unroll
-            for (int ch = 0; ch < N; ch++)
-                dist = dist + direction[ch] * (byteF(pk, ch) * w[ch] - m.centroid[ch]);
-            minDist = sseMin(minDist, dist);
-            maxDist = sseMax(maxDist, dist);
-        }
-    }
-#pragma unroll
-    for (int ch = 0; ch < N; ch++)
-    {
-        const float mn = m.centroid[ch] + direction[ch] * minDist;
-        const float mx = m.centroid[ch] + direction[ch] * maxDist;
-        u.base[ch] = mn / w[ch];
-        u.offset[ch] = (mx - mn) / w[ch];
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void pcaEndpoints(const u32 (&pix)[16], u32 mask, const float (&w)[4], int, Unfinished &u)
-{
-    Moments<N> m;
-    pcaMoments<N>(pix, mask, w, m);
-    pcaFinish<N>(pix, mask, w, m, u);
-}
-
-// ---- exact branch-and-bound: a rigorous lower bound on the error of ANY trial of a shape --
-// Every reconstructed colour of a trial is floor(I + 0.5) per channel for a point I on the
-// segment between the two (quantised) endpoints (IndexSelector.h:90-100), so in the weighted
-// metric it lies within delta = 0.5*sqrt(sum w_ch^2) of some line L.  Hence for every pixel
-// the trial's error is >= max(0, d - delta)^2 >= d^2 - 2*delta*d, d = weighted distance to L,
-// and with D2 = sum d^2 >= R (R = total-least-squares residual of the shape = trace(S) -
-// lambda_max(S), S the scatter matrix that PCA pass 1 accumulates anyway) and sum d <=
-// sqrt(n*D2):   error >= R - 2*delta*sqrt(n*R)   whenever R >= n*delta^2.
-// lambda_max is over-estimated by trace(S^4)^(1/4), so R is under-estimated; the result is
-// scaled down by 1e-4 to absorb the float rounding of S, of this computation and of the
-// reference's own error sums.  A candidate whose bound exceeds the current best can never be
-// committed (the commit needs error <= best), so skipping it leaves the output bit-identical.
-template <int N>
-__device__ __forceinline__ float shapeErrorLowerBound(const Moments<N> &m, float n, float delta)
-{
-    float trace = 0.0f;
-#pragma unroll
-    for (int i = 0; i < N; i++)
-        trace += m.cov[i * (i + 1) / 2 + i];
-    // S2 = S*S (symmetric), trace(S^4) = ||S2||_F^2
-    float t4 = 0.0f;
-#pragma unroll
-    for (int i = 0; i < N; i++)
-#pragma unroll
-        for (int j = 0; j <= i; j++)
-        {
-            float e = 0.0f;
-#pragma unroll
-            for (int k = 0; k < N; k++)
-            {
-                const int a0 = i > k ? i : k, a1 = i > k ? k : i;
-                const int b0 = j > k ? j : k, b1 = j > k ? k : j;
-                e += m.cov[a0 * (a0 + 1) / 2 + a1] * m.cov[b0 * (b0 + 1) / 2 + b1];
-            }
-            t4 += (i == j ? 1.0f : 2.0f) * e * e;
-        }
-    const float lambdaUp = __fsqrt_rn(__fsqrt_rn(t4)) * 1.0001f;
-    const float r = trace - lambdaUp;
-    float lb = 0.0f;
-    if (r > n * delta * delta)
-        lb = (r - 2.0f * delta * __fsqrt_rn(n * r)) * 0.9999f;
-    return lb > 0.0f ? lb : 0.0f; // NaN / inf inputs end up as "no bound"
-}
-
 // ---- BC7 endpoint quantisation (reference BC67.cpp:829-860); all values fit 16 bits ----
 __device__ __forceinline__ int quantizeNoP(int v, int bits) { return ((v << bits) - v + (127 + (1 << (7 - bits)))) >> 8; }
 __device__ __forceinline__ int quantizeP(int v, int bits, int p)

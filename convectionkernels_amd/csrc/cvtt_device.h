@@ -21,6 +21,7 @@ struct CvttDeviceTables
     float tweakFactors[3][4][2];
     float rcpTable[17];        // host RCPPS(i), i = 1..16
     float rcpMaxIndex[5];      // 1.0f / ((1 << bits) - 1), bits = 0..4 (entry 0 unused)
+    float tweakFactors3[2][4][2]; // same for range = 3, 4 (BC1; range 3 has 3 seed points)
 };
 
 // The caller's plan plus two bitmaps derived on the host: which shapes the plan's
@@ -47,6 +48,19 @@ struct CvttBc7Args
     uint32_t prune;
     float delta3;    // 0.5*sqrt(wSq[0]+wSq[1]+wSq[2]), rounded up
     float delta4;    // 0.5*sqrt(wSq[0..3]), rounded up
+};
+
+// BC1 per-launch parameters.
+struct CvttBc1Args
+{
+    float w[4];
+    float wSq[4];
+    float rcpW[4];
+    uint32_t flags;
+    int32_t refineRounds; // Options::refineRoundsS3TC
+    int32_t seedPoints;   // Options::seedPoints
+    int32_t threshold;    // floor(threshold * 255 + 0.5) as a signed 16-bit lane value (S3TC.cpp:748)
+    uint32_t numBlocks;
 };
 
 #endif

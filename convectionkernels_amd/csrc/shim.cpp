@@ -22,6 +22,9 @@ extern "C" hipError_t cvttmi_launch_bc7(const void *d_blocks, void *d_out, const
                                         const CvttDeviceTables *d_tables, const CvttBc7DevicePlan *d_plan,
                                         hipStream_t stream);
 
+extern "C" hipError_t cvttmi_launch_bc1(const void *d_blocks, void *d_out, const CvttBc1Args *args,
+                                        const CvttDeviceTables *d_tables, hipStream_t stream);
+
 static_assert(sizeof(cvttmi_options) == 44, "cvtt::Options layout");
 static_assert(sizeof(cvttmi_bc7_plan) == 808, "cvtt::BC7EncodingPlan layout");
 
@@ -108,6 +111,9 @@ namespace
             const float v = static_cast<float>(i == 0 ? 1 : i);
             t.rcpTable[i] = _mm_cvtss_f32(_mm_rcp_ps(_mm_set1_ps(v)));
         }
+        for (int r = 0; r < 2; r++)
+            for (int tw = 0; tw < 4; tw++)
+                tweakFactors(tw, 3 + r, t.tweakFactors3[r][tw]); // range 3, tweak 3 divides by zero: never read
         t.rcpMaxIndex[0] = 0.0f;
         for (int bits = 1; bits <= 4; bits++)
         {
@@ -424,6 +430,76 @@ extern "C"
             ctx->totalMs += ms;
             ctx->launches += 1;
         }
+        return CVTTMI_OK;
+    }
+
+    int cvttmi_encode_bc1_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
+                                 const cvttmi_options *options, void *hipStream)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        if (!d_out || !d_blocks || !options || (numBlocks % 8) != 0 || numBlocks > 0xfffffff0u)
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        if (options->flags & CVTTMI_FLAG_S3TC_EXHAUSTIVE)
+            return fail(ctx, CVTTMI_E_UNSUPPORTED, "S3TC_Exhaustive is not implemented on the GPU path");
+        if (numBlocks == 0)
+            return CVTTMI_OK;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        hipStream_t stream = static_cast<hipStream_t>(hipStream);
+        CvttBc1Args args;
+        fillWeightArgs(options, args.w, args.wSq, args.rcpW);
+        args.flags = options->flags;
+        args.refineRounds = options->refineRoundsS3TC;
+        args.seedPoints = options->seedPoints;
+        // S3TC.cpp:748: MakeUInt15(static_cast<uint16_t>(floor(alphaThreshold * 255.0f + 0.5f)))
+        args.threshold = static_cast<int16_t>(static_cast<uint16_t>(static_cast<int32_t>(floor(options->threshold * 255.0f + 0.5f))));
+        args.numBlocks = static_cast<uint32_t>(numBlocks);
+        if (ctx->timing)
+            hipEventRecord(ctx->evStart, stream);
+        e = cvttmi_launch_bc1(d_blocks, d_out, &args, ctx->dTables, stream);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "bc1 kernel launch", e);
+        if (ctx->timing)
+        {
+            hipEventRecord(ctx->evStop, stream);
+            hipEventSynchronize(ctx->evStop);
+            float ms = 0.0f;
+            hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop);
+            ctx->totalMs += ms;
+            ctx->launches += 1;
+        }
+        return CVTTMI_OK;
+    }
+
+    int cvttmi_encode_bc1(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
+                          const cvttmi_options *options)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        if (!out || !blocks || !options || (numBlocks % 8) != 0)
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        if (numBlocks == 0)
+            return CVTTMI_OK;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        const size_t inBytes = numBlocks * 64, outBytes = numBlocks * 8;
+        int rc = ensureStaging(ctx, inBytes, outBytes);
+        if (rc != CVTTMI_OK)
+            return rc;
+        memcpy(ctx->pinnedIn, blocks, inBytes);
+        if ((e = hipMemcpyAsync(ctx->dIn, ctx->pinnedIn, inBytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "H2D", e);
+        rc = cvttmi_encode_bc1_device(ctx, ctx->dOut, ctx->dIn, numBlocks, options, ctx->stream);
+        if (rc != CVTTMI_OK)
+            return rc;
+        if ((e = hipMemcpyAsync(ctx->pinnedOut, ctx->dOut, outBytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "D2H", e);
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "kernel execution", e);
+        memcpy(out, ctx->pinnedOut, outBytes);
         return CVTTMI_OK;
     }
 

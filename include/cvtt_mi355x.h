@@ -114,10 +114,20 @@ int cvttmi_get_rcp_table(const cvttmi_context *ctx, float lut[17]);
 int cvttmi_encode_bc7_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
                              const cvttmi_options *options, const cvttmi_bc7_plan *plan, void *hipStream);
 
+/* replaces cvtt::Kernels::EncodeBC1 (ConvectionKernels_API.cpp:86-99 ->
+ * S3TCComputer::PackRGB with alphaTest = true, ConvectionKernels_S3TC.cpp:717-1052):
+ * numBlocks * 64 B of PixelBlockU8 in, numBlocks * 8 B out.  Uses options->threshold,
+ * seedPoints, refineRoundsS3TC, the S3TC_Paranoid / Uniform flags and the channel weights. */
+int cvttmi_encode_bc1_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
+                             const cvttmi_options *options, void *hipStream);
+
 /* ---- host-buffer convenience entry points: stage through pinned memory, launch, copy
  * back, synchronise.  Same semantics as the *_device calls. ---- */
 int cvttmi_encode_bc7(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
                       const cvttmi_options *options, const cvttmi_bc7_plan *plan);
+
+int cvttmi_encode_bc1(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
+                      const cvttmi_options *options);
 
 /* Search strategy.  By default the kernels skip candidates (partitions / subsets) whose
  * rigorous error lower bound already exceeds the best candidate found so far -- an exact

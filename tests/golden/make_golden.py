@@ -76,6 +76,27 @@ def main():
     arrays["names"] = np.array(names)
     np.savez_compressed(os.path.join(HERE, "bc7_mixed.npz"), **arrays)
 
+    # ---- BC1: mixed content + config 1 image x option variants ----
+    P = pyref
+    bc1_blocks = np.concatenate([content.mixed_ldr_blocks(777, 24), content.config_blocks(1, 64, 64)])
+    b1 = {"blocks": bc1_blocks, "rcp": rcp}
+    b1names = []
+    for name, o in {
+        "default": P.make_options(),
+        "plain": P.make_options(flags=P.FLAG_BC7_FAST_INDEXING),
+        "uniform": P.make_options(flags=P.FLAGS_DEFAULT | P.FLAG_UNIFORM),
+        "threshold09": P.make_options(threshold=0.9),
+        "threshold0": P.make_options(threshold=0.0),
+        "refine1_seeds2": P.make_options(refine_s3tc=1, seed_points=2),
+        "refine3": P.make_options(refine_s3tc=3),
+        "weights": P.make_options(weights=(0.5, 1.0, 0.25, 2.0)),
+    }.items():
+        b1["opt_" + name] = o
+        b1["out_" + name] = ref.encode_bc1(bc1_blocks, o)
+        b1names.append(name)
+    b1["names"] = np.array(b1names)
+    np.savez_compressed(os.path.join(HERE, "bc1_mixed.npz"), **b1)
+
     # ---- known answers (App. H) ----
     ka = content.known_answer_group_ldr()
     opt = pyref.make_options()
@@ -84,6 +105,8 @@ def main():
                         bc1=ref.encode_bc1(ka, opt),
                         etc2rgba=ref.encode_etc2(ka, opt, 1))
 
+    if "--skip-images" in sys.argv:
+        return
     # ---- whole-image hashes for the BASELINE.json configs ----
     hashes = {"rcp_hex": [int(x) for x in rcp.view(np.uint32)]}
     plan = ref.default_plan()
