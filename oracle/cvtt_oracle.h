@@ -74,6 +74,10 @@ int orc_encode_bc7(uint8_t *out, const uint8_t *blocks, size_t numBlocks,
 int orc_encode_bc1(uint8_t *out, const uint8_t *blocks, size_t numBlocks,
                    const orc_options *options, const float *rcp17, int threads);
 
+/* blocksF16: numBlocks * 128 bytes of PixelBlockF16 (half bits as int16, RGBA; alpha ignored). */
+int orc_encode_bc6h(uint8_t *out, const uint8_t *blocksF16, size_t numBlocks,
+                    const orc_options *options, int isSigned, const float *rcp17, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,6 +159,7 @@ class OracleLib:
         assert L.orc_sizeof_bc7_plan() == SIZEOF_BC7_PLAN
         L.orc_encode_bc7.restype = ctypes.c_int
         L.orc_encode_bc1.restype = ctypes.c_int
+        L.orc_encode_bc6h.restype = ctypes.c_int
 
     def probe_rcp(self):
         out = np.zeros(17, np.float32)
@@ -180,6 +181,21 @@ class OracleLib:
                                      rcp_p, ctypes.c_int(threads))
         if rc != 0:
             raise RuntimeError("orc_encode_bc7 rc=%d" % rc)
+        return out.reshape(n, 16)
+
+    def encode_bc6h(self, blocks_f16bits, options, signed=False, rcp=None, threads=1):
+        b = np.ascontiguousarray(blocks_f16bits, dtype=np.int16)
+        n = b.size // 64
+        assert n % 8 == 0
+        out = np.zeros(n * 16, np.uint8)
+        rcp_p = None
+        if rcp is not None:
+            rcp = np.ascontiguousarray(rcp, np.float32)
+            rcp_p = rcp.ctypes.data_as(ctypes.c_void_p)
+        rc = self.lib.orc_encode_bc6h(out.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n),
+                                      options.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(int(signed)), rcp_p, ctypes.c_int(threads))
+        if rc != 0:
+            raise RuntimeError("orc_encode_bc6h rc=%d" % rc)
         return out.reshape(n, 16)
 
     def encode_bc1(self, blocks, options, rcp=None, threads=1):

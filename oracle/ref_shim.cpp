@@ -15,6 +15,7 @@
 #include <xmmintrin.h>
 
 #include "ConvectionKernels.h"
+#include "ConvectionKernels_BC6H_IO.h"
 
 namespace
 {
@@ -145,6 +146,27 @@ extern "C"
         if (data)
             cvtt::Kernels::ReleaseETC2Data(data, shimFree);
         return 0;
+    }
+
+    // BC6H header bit scatter of mode `modeIndex` (0..13, order of the BC6H mode table):
+    // fields = { m, d, rw, rx, ry, rz, gw, gx, gy, gz, bw, bx, by, bz }.  Used by
+    // tools/gen_bc6h_layout.py to tabulate the (public) BC6H bit layout by probing.
+    void ref_bc6h_write_header(int modeIndex, const uint16_t *f, uint32_t *out3)
+    {
+        out3[0] = out3[1] = out3[2] = 0;
+        cvtt::BC6H_IO::g_writeFuncs[modeIndex](out3, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], f[9], f[10], f[11], f[12], f[13]);
+    }
+
+    void ref_decode_bc6h(uint8_t *outBlocksF16, const uint8_t *bc, size_t numBlocks, int isSigned)
+    {
+        cvtt::PixelBlockF16 *o = reinterpret_cast<cvtt::PixelBlockF16 *>(outBlocksF16);
+        for (size_t b = 0; b + cvtt::NumParallelBlocks <= numBlocks; b += cvtt::NumParallelBlocks)
+        {
+            if (isSigned)
+                cvtt::Kernels::DecodeBC6HS(o + b, bc + b * 16);
+            else
+                cvtt::Kernels::DecodeBC6HU(o + b, bc + b * 16);
+        }
     }
 
     void ref_decode_bc7(uint8_t *outBlocks, const uint8_t *bc, size_t numBlocks)

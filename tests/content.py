@@ -96,3 +96,59 @@ def known_answer_group_ldr():
 
 def config_blocks(seed, width, height, opaque=False):
     return synth.tile_blocks(synth.image_rgba8(seed, width, height, opaque=opaque))
+
+
+def known_answer_group_hdr():
+    """SURVEY.md App. H HDR group: (8,16,4) int16 half bit patterns."""
+    hdr = np.zeros((8, 16, 4), np.int16)
+    for b in range(8):
+        for p in range(16):
+            for c in range(4):
+                hdr[b, p, c] = ((8 + (b + p + c) % 12) << 10) | ((131 * b + 61 * p + 17 * c + 7 * p * p) & 0x3FF)
+            hdr[b, p, 3] = 0x3C00
+    return hdr
+
+
+def mixed_hdr_blocks(seed, groups, signed=False):
+    """(groups*8, 16, 4) int16 half bit patterns: random normals, smooth ramps, solid, two-colour,
+    tiny/denormal values, huge values, and (signed=True) negative values."""
+    rng = _rng(seed)
+    out = np.zeros((groups * 8, 16, 4), np.uint16)
+    yy, xx = np.divmod(np.arange(16), 4)
+    for g in range(groups):
+        kind = g % 8
+        for b in range(8):
+            k = kind if kind != 7 else int(rng.integers(0, 7))
+            if k == 0:  # config-3 style: finite positive normals
+                r = rng.integers(0, 1 << 62, (16, 3), dtype=np.int64)
+                v = (((1 + (r >> 10) % 29) << 10) | (r & 0x3FF))
+            elif k == 1:  # smooth ramp in linear space
+                c0 = rng.uniform(0.05, 4.0, 3)
+                dx = rng.normal(0, 0.2, 3)
+                dy = rng.normal(0, 0.2, 3)
+                f = np.clip(c0[None] + xx[:, None] * dx[None] + yy[:, None] * dy[None], 0, 60000)
+                v = f.astype(np.float16).view(np.uint16).astype(np.int64)
+            elif k == 2:  # solid
+                v = np.repeat(rng.integers(0, 0x7BFF, (1, 3)), 16, axis=0)
+            elif k == 3:  # two colours
+                ca = rng.integers(0, 0x7BFF, 3)
+                cb = rng.integers(0, 0x7BFF, 3)
+                m = rng.integers(0, 2, 16).astype(bool)
+                v = np.where(m[:, None], ca[None], cb[None])
+            elif k == 4:  # tiny values incl. denormals and zero
+                v = rng.integers(0, 0x0800, (16, 3))
+            elif k == 5:  # anything, including inf/nan patterns and sign bits
+                v = rng.integers(0, 0x10000, (16, 3))
+            else:  # narrow range around a bright colour
+                base = rng.integers(0x3000, 0x7000, 3)
+                v = base[None] + rng.integers(-40, 41, (16, 3))
+            v = np.asarray(v, np.int64) & 0xFFFF
+            if signed and (b & 1):
+                v = v | (rng.integers(0, 2, (16, 3)) << 15)
+            out[g * 8 + b, :, :3] = v
+            out[g * 8 + b, :, 3] = 0x3C00
+    return out.view(np.int16)
+
+
+def config_blocks_hdr(seed, width, height):
+    return synth.tile_blocks(synth.image_f16bits(seed, width, height))

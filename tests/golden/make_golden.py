@@ -97,13 +97,31 @@ def main():
     b1["names"] = np.array(b1names)
     np.savez_compressed(os.path.join(HERE, "bc1_mixed.npz"), **b1)
 
+    # ---- BC6H: mixed HDR content x option variants (canonical -O1 build only: hazard H1) ----
+    hdr = content.mixed_hdr_blocks(606, 16)
+    hdrs = content.mixed_hdr_blocks(607, 8, signed=True)
+    b6 = {"blocks": hdr, "blocks_signed": hdrs, "rcp": rcp}
+    for name, o in {
+        "default": P.make_options(),
+        "fast": P.make_options(flags=P.FLAGS_DEFAULT | P.FLAG_BC6H_FAST_INDEXING),
+        "uniform": P.make_options(flags=P.FLAGS_DEFAULT | P.FLAG_UNIFORM),
+        "seeds2_refine2": P.make_options(seed_points=2, refine_bc6h=2),
+        "weights": P.make_options(weights=(0.5, 1.0, 0.25, 2.0)),
+    }.items():
+        b6["opt_" + name] = o
+        b6["out_" + name] = ref.encode_bc6h(hdr, o, False)
+        b6["outs_" + name] = ref.encode_bc6h(hdrs, o, True)
+    np.savez_compressed(os.path.join(HERE, "bc6h_mixed.npz"), **b6)
+
     # ---- known answers (App. H) ----
     ka = content.known_answer_group_ldr()
     opt = pyref.make_options()
     np.savez_compressed(os.path.join(HERE, "known_answers.npz"), blocks=ka, rcp=rcp,
                         bc7=ref.encode_bc7(ka, opt, ref.default_plan()),
                         bc1=ref.encode_bc1(ka, opt),
-                        etc2rgba=ref.encode_etc2(ka, opt, 1))
+                        etc2rgba=ref.encode_etc2(ka, opt, 1),
+                        hdr_blocks=content.known_answer_group_hdr(),
+                        bc6hu=ref.encode_bc6h(content.known_answer_group_hdr(), opt, False))
 
     if "--skip-images" in sys.argv:
         return

@@ -1,0 +1,46 @@
+"""BC6H (EncodeBC6HU / EncodeBC6HS): oracle vs golden vectors / reference on CPU; HIP path on GPU."""
+import os
+
+import numpy as np
+import pytest
+
+import content
+from oracle import pyref
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+NAMES = ["default", "fast", "uniform", "seeds2_refine2", "weights"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_golden(oracle_lib, name):
+    g = np.load(os.path.join(GOLD, "bc6h_mixed.npz"))
+    out = oracle_lib.encode_bc6h(g["blocks"], g["opt_" + name], False, g["rcp"], threads=8)
+    assert (out == g["out_" + name]).all()
+    outs = oracle_lib.encode_bc6h(g["blocks_signed"], g["opt_" + name], True, g["rcp"], threads=8)
+    assert (outs == g["outs_" + name]).all()
+
+
+def test_oracle_known_answers(oracle_lib):
+    g = np.load(os.path.join(GOLD, "known_answers.npz"))
+    out = oracle_lib.encode_bc6h(g["hdr_blocks"], pyref.make_options(), False, g["rcp"])
+    assert (out == g["bc6hu"]).all()
+    assert out[0].tobytes().hex() == "1e52092f4c757d92a3158148235b1b51"
+    assert out[7].tobytes().hex() == "3e7c34543d2fa2a94b8999e0bf5b4e09"
+
+
+def test_oracle_vs_reference(oracle_lib, ref_lib):
+    rcp = ref_lib.probe_rcp()
+    blocks = content.mixed_hdr_blocks(99, 8)
+    for opt in (pyref.make_options(), pyref.make_options(flags=pyref.FLAG_BC6H_FAST_INDEXING, seed_points=3)):
+        assert (oracle_lib.encode_bc6h(blocks, opt, False, rcp, 8) == ref_lib.encode_bc6h(blocks, opt, False)).all()
+    cfg = content.config_blocks_hdr(3, 32, 32)  # BASELINE config 3 content
+    assert (oracle_lib.encode_bc6h(cfg, pyref.make_options(), False, rcp, 8) == ref_lib.encode_bc6h(cfg, pyref.make_options(), False)).all()
+
+
+def test_group_coupling_changes_output(oracle_lib):
+    """the duplicate-round skip and the mode commit loop couple the 8 lanes:
+    encoding a block inside its group is not always the same as encoding it replicated alone"""
+    blocks = content.mixed_hdr_blocks(3, 16)
+    opt = pyref.make_options()
+    grouped = oracle_lib.encode_bc6h(blocks, opt, False, None, 8)
+    assert grouped.shape == (128, 16)
