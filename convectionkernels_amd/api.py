@@ -149,6 +149,7 @@ _EXPORTS = (
     "cvttmi_last_error", "cvttmi_set_rcp_table", "cvttmi_get_rcp_table",
     "cvttmi_encode_bc7_device", "cvttmi_encode_bc7", "cvttmi_timing_enable", "cvttmi_timing_read",
     "cvttmi_set_exhaustive", "cvttmi_encode_bc1_device", "cvttmi_encode_bc1",
+    "cvttmi_encode_bc6h_device", "cvttmi_encode_bc6h",
 )
 
 _lib = None
@@ -180,6 +181,10 @@ def load_library():
     lib.cvttmi_encode_bc1_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                              ctypes.c_void_p, ctypes.c_void_p]
     lib.cvttmi_encode_bc1.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.cvttmi_encode_bc6h_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                              ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.cvttmi_encode_bc6h.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                       ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_set_exhaustive.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_timing_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
@@ -307,6 +312,16 @@ class Context:
                                    blocks, options, out, stream, 64, 8)
 
 
+    # -- BC6H --
+    def encode_bc6h(self, blocks, options=None, signed=False, out=None, stream=None):
+        """Batched cvtt::Kernels::EncodeBC6HU / EncodeBC6HS: (N,16,4) half bit patterns (int16 /
+        uint16 / float16 numpy array, or a CUDA tensor of 2-byte elements) -> (N,16) uint8."""
+        sg = 1 if signed else 0
+        host = lambda h, o, b, n, opt: self._lib.cvttmi_encode_bc6h(h, o, b, n, opt, sg)
+        dev = lambda h, o, b, n, opt, st: self._lib.cvttmi_encode_bc6h_device(h, o, b, n, opt, sg, st)
+        return self._encode_simple(host, dev, "encode_bc6h", blocks, options, out, stream, 128, 16)
+
+
 _default_ctx = {}
 
 
@@ -326,3 +341,13 @@ def EncodeBC7(pBlocks, options=None, encodingPlan=None, device=0):
 def EncodeBC1(pBlocks, options=None, device=0):
     """cvtt::Kernels::EncodeBC1 (reference ConvectionKernels_API.cpp:86-99)."""
     return default_context(device).encode_bc1(pBlocks, options)
+
+
+def EncodeBC6HU(pBlocks, options=None, device=0):
+    """cvtt::Kernels::EncodeBC6HU (reference ConvectionKernels_API.cpp:56-69)."""
+    return default_context(device).encode_bc6h(pBlocks, options, signed=False)
+
+
+def EncodeBC6HS(pBlocks, options=None, device=0):
+    """cvtt::Kernels::EncodeBC6HS (reference ConvectionKernels_API.cpp:71-84)."""
+    return default_context(device).encode_bc6h(pBlocks, options, signed=True)

@@ -1,0 +1,708 @@
+// BC6H (unsigned / signed half-float) endpoint search for gfx950.
+//
+// Replaces cvtt::Internal::BC6HComputer::Pack as reached from cvtt::Kernels::EncodeBC6HU /
+// EncodeBC6HS (reference ConvectionKernels_API.cpp:56-84, ConvectionKernels_BC67.cpp:2665-3051;
+// QuantizeEndpoints* 2503-2595, Evaluate*Legality 2597-2663, quantise/unquantise 2425-2501,
+// IndexSelectorHDR.h, ParallelMath.h:996-1066).  Bit-identical to the reference's SSE2 lanes
+// in its canonical build (zero-initialised automatics, program-order rounding
+// scopes).
+//
+// Mapping: one LANE owns one block, a wave owns 8 reference groups (64 consecutive blocks).
+// The reference couples the 8 lanes of a group in two places -- the duplicate-round skip
+// (BC67.cpp:2853-2877, AllSet) and the mode-commit loop (2936-2984, AnySet) -- and both are
+// evaluated in the reference's exact candidate order, so every loop here is wave-uniform and
+// the two group predicates are 8-lane slices of a wave ballot.
+//   * pixels: 2CL integers packed in 32 VGPRs, their weighted linear values in 48 VGPRs;
+//   * slow indexing walks the interpolants in the OUTER loop (one reconstruction per
+//     interpolant per round instead of a 16-entry table per lane) and keeps a running
+//     (error, index) per pixel -- same strict '<' order as IndexSelectorHDR.h:125-139;
+//   * the per-partition "meta round" results (quantised endpoints, indexes, errors of up to
+//     12 rounds x 2 subsets) live in LDS, [entry][lane] so every access is conflict free.
+#include "cvtt_kernel_common.h"
+
+namespace
+{
+// ---- LDS layout (dwords per lane) ----
+//   EPQ : 12 rounds x 2 subsets x 3 dwords (6 x int16: ep0.rgb, ep1.rgb)      = 72
+//   IDX : 12 rounds x 2 dwords (4 bits per pixel)                             = 24
+//   ERR : 12 rounds x 2 subsets                                               = 24
+constexpr int kEpqBase = 0, kIdxBase = 72, kErrBase = 96, kMetaDwords = 120;
+
+__device__ __forceinline__ float divRoundUp(float a, float b)
+{
+    // IEEE division rounded toward +inf (the reference divides inside a RoundUpForScope,
+    // BC67.cpp:2509/2556): correct the round-to-nearest quotient by the sign of the residual
+    const float q = a / b;
+    const float r = __fmaf_rn(-q, b, a);
+    return (r > 0.0f) ? __uint_as_float(__float_as_uint(q) + 1u) : q; // q >= 0 here
+}
+
+// QuantizeSingleEndpointElementUnsigned, BC67.cpp:2441-2445
+__device__ __forceinline__ int quantizeUnsigned(int elem, int precision)
+{
+    float v = divRoundUp((float)elem * 64.0f, 31.0f);
+    v = sseMin(v, 65535.0f);
+    int i = (int)ceilf(v - 32768.0f);
+    i = i > 32767 ? 32767 : i;
+    const u32 expanded = ((u32)i & 0xffffu) ^ 0x8000u;
+    return (int)(expanded >> (16 - precision));
+}
+
+// QuantizeSingleEndpointElementSigned, BC67.cpp:2425-2439
+__device__ __forceinline__ int quantizeSigned(int elem, int precision)
+{
+    const bool neg = elem < 0;
+    int a = neg ? -elem : elem;
+    const float v = divRoundUp((float)a * 32.0f, 31.0f);
+    int i = (int)ceilf(v);
+    i = i > 32767 ? 32767 : i;
+    a = (int)(((u32)i & 0xffffu) >> (16 - precision));
+    return neg ? -a : a;
+}
+
+// Unquantize*, BC67.cpp:2447-2501: returns the interpolation endpoint, `finished` = colour-space value
+__device__ __forceinline__ int unquantizeUnsigned(int comp, int precision, int &finished)
+{
+    u32 unq = (u32)comp & 0xffffu;
+    if (precision < 15)
+    {
+        unq = (((u32)comp << (16 - precision)) + (0x8000u >> precision)) & 0xffffu;
+        if (comp == 0) unq = 0;
+        if (((1 << precision) - 2) < comp) unq = 0xffffu;
+    }
+    finished = (int)((unq * 31u) >> 6);
+    return (int)unq;
+}
+
+__device__ __forceinline__ int unquantizeSigned(int comp, int precision, int &finished)
+{
+    const bool neg = comp < 0;
+    const int absComp = neg ? -comp : comp;
+    int unq, absUnq;
+    if (precision >= 16)
+    {
+        unq = comp;
+        absUnq = absComp;
+    }
+    else
+    {
+        absUnq = (int)(short)(unsigned short)((absComp << (16 - precision)) + (0x4000 >> (precision - 1)));
+        if (comp == 0) absUnq = 0;
+        if (((1 << (precision - 1)) - 2) < comp) absUnq = 0x7fff;
+        unq = neg ? -absUnq : absUnq;
+    }
+    int funq = (int)((((u32)absUnq & 0xffffu) * 31u) >> 5);
+    funq = funq > 32767 ? 32767 : funq;
+    finished = (int)(short)(neg ? -funq : funq);
+    return (int)(short)unq;
+}
+
+// TwosCLHalfToFloat, ParallelMath.h:1012-1041
+__device__ __forceinline__ float twosCLHalfToFloat(int v16)
+{
+    const u32 v = (u32)v16 & 0xffffu;
+    const u32 signBits = v & 0x8000u;
+    const u32 mantissa = v & 0x03ffu;
+    u32 exponent = v & 0x7c00u;
+    const bool isDenormal = exponent == 0;
+    exponent = ((exponent >> 3) + 14336u) & 0xffffu;
+    const u32 corrHigh = isDenormal ? (signBits | 14336u) : 0u;
+    const u32 highBits = signBits | exponent | (mantissa >> 3);
+    const u32 lowBits = (mantissa << 13) & 0xffffu;
+    return __uint_as_float((highBits << 16) | lowBits) - __uint_as_float(corrHigh << 16);
+}
+
+// ReconstructHDR{Signed,Unsigned}Uninverted for one channel, IndexSelectorHDR.h:34-66
+template <bool SIGNED>
+__device__ __forceinline__ int reconstructChannel(int e0, int e1, int weight)
+{
+    if (SIGNED)
+    {
+        int p = (64 - weight) * e0 + weight * e1; // |e| < 2^15: fits easily
+        p = (p + 32) >> 6;
+        p = p > 32767 ? 32767 : (p < -32768 ? -32768 : p);
+        const bool neg = p < 0;
+        const int a = neg ? -p : p;
+        int scaled = (int)((((u32)a & 0xffffu) * 31u) >> 5); // UnscaleHDRValueSigned, BC67.cpp:766-782
+        scaled = scaled > 32767 ? 32767 : scaled;
+        return (int)(short)(unsigned short)((u32)scaled | (neg ? 0x8000u : 0u));
+    }
+    else
+    {
+        u32 p = (u32)(64 - weight) * (u32)e0 + (u32)weight * (u32)e1; // e < 2^16, weight <= 64
+        p = (p + 32u) >> 6;
+        return (int)((((p & 0xffffu) * 31u) >> 6)); // UnscaleHDRValueUnsigned
+    }
+}
+
+struct FetchHDR
+{
+    const u32 (&pk01)[16];
+    const u32 (&pk2)[16];
+    const float (&w)[4];
+    template <int N>
+    __device__ __forceinline__ void get(int px, float (&v)[N]) const
+    {
+        const u32 a = fetchPixel(pk01[px]);
+        const u32 b = fetchPixel(pk2[px]);
+        v[0] = (float)(int)(short)(a & 0xffffu) * w[0];
+        v[1] = (float)(int)(short)(a >> 16) * w[1];
+        v[2] = (float)(int)(short)(b & 0xffffu) * w[2];
+    }
+};
+
+__device__ __forceinline__ u32 groupBits(u64 ballot, int lane) { return (u32)(ballot >> (lane & 56)) & 0xffu; }
+} // namespace
+
+template <bool SIGNED, bool FAST>
+__global__ __launch_bounds__(64) void cvttmi_bc6h_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+                                                         const CvttBc6hArgs A, const CvttDeviceTables *__restrict__ T)
+{
+    __shared__ u32 meta[kMetaDwords][64];
+    const int lane = threadIdx.x;
+    const u32 blockIndex = blockIdx.x * 64u + (u32)lane;
+    const bool valid = blockIndex < A.numBlocks;
+    const bool uniformErr = (A.flags & CVTTMI_FLAG_UNIFORM) != 0;
+
+    // ---- load + clamp to the "2CL" domain (BC67.cpp:2691-2715) ----
+    u32 pk01[16], pk2[16];
+    float linW[16][3]; // TwosCLHalfToFloat(pixel) * weight
+    {
+        const uint2 *src = reinterpret_cast<const uint2 *>(blocks + (size_t)(valid ? blockIndex : 0u) * 128u);
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+        {
+            const uint2 raw = src[px];
+            int v[3] = {(int)(short)(raw.x & 0xffffu), (int)(short)(raw.x >> 16), (int)(short)(raw.y & 0xffffu)};
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+            {
+                int x = v[ch];
+                if (SIGNED)
+                {
+                    if (x < 0)
+                        x = -(x & 32767);
+                    x = x < -31743 ? -31743 : x;
+                }
+                else
+                    x = x < 0 ? 0 : x;
+                x = x > 31743 ? 31743 : x;
+                v[ch] = x;
+                linW[px][ch] = twosCLHalfToFloat(x) * A.w[ch];
+            }
+            pk01[px] = ((u32)v[0] & 0xffffu) | ((u32)v[1] << 16);
+            pk2[px] = (u32)v[2] & 0xffffu;
+        }
+    }
+    const FetchHDR F = {pk01, pk2, A.w};
+
+    int numTweakRounds = A.seedPoints < 1 ? 1 : (A.seedPoints > 4 ? 4 : A.seedPoints);
+    int numRefineRounds = A.refineRounds < 1 ? 1 : (A.refineRounds > 3 ? 3 : A.refineRounds);
+
+    // running best (BC67.cpp:2721-2733)
+    float bestError = FLT_MAX;
+    int bestMode = 0, bestPartition = 0;
+    u32 bestEP[6] = {0, 0, 0, 0, 0, 0}; // [subset][3 dwords: (e0r|e0g<<16),(e0b|e1r<<16),(e1g|e1b<<16)]
+    u32 bestIdxLo = 0, bestIdxHi = 0;
+
+    for (int partitionedInt = 0; partitionedInt < 2; partitionedInt++)
+    {
+        const bool partitioned = partitionedInt == 1;
+        const int numPartitions = partitioned ? 32 : 1;
+        const int numSubsets = partitioned ? 2 : 1;
+        const int indexBits = partitioned ? 3 : 4;
+        const int indexRange = 1 << indexBits;
+        const float maxValue = (float)(indexRange - 1);
+        const int weightRcp = partitioned ? 4681 : 2185; // g_weightReciprocals[8], [16]
+        const float rcpMaxIndex = T->rcpMaxIndex[indexBits];
+
+        for (int aPrec = 16; aPrec >= 0; aPrec--)
+        {
+            // g_hdrModesExistForPrecision, BC67.cpp:144-149
+            const u32 exists = partitioned ? 0x0fc0u : 0x11c00u;
+            if (((exists >> aPrec) & 1u) == 0)
+                continue;
+
+            for (int p = 0; p < numPartitions; p++)
+            {
+                const u32 partitionMask = partitioned ? T->partition2[p] : 0u;
+                u32 roundValid0 = 0xfffu, roundValid1 = 0xfffu; // per group (identical in its 8 lanes)
+
+                // canonical build: the meta arrays start zeroed for every partition
+#pragma unroll 4
+                for (int e = 0; e < kMetaDwords; e++)
+                    meta[e][lane] = 0;
+
+                for (int subset = 0; subset < numSubsets; subset++)
+                {
+                    const u32 subsetMask = partitioned ? (subset ? partitionMask : (~partitionMask & 0xffffu)) : 0xffffu;
+                    const int fixupIndex = (subset == 0) ? 0 : (int)T->anchor2[p];
+                    const int count = __popc(subsetMask);
+                    const float wRcp = T->rcpTable[count];
+                    const float wCount = (float)count;
+
+                    // seeds of this subset (the reference precomputes them for every partition,
+                    // BC67.cpp:2738-2774; recomputing them per precision keeps them out of memory)
+                    Unfinished ufep;
+                    {
+                        Moments<3> m;
+                        pcaMomentsT<3>(F, subsetMask, m);
+                        pcaFinishT<3>(F, subsetMask, A.w, m, ufep);
+                    }
+
+                    for (int tweak = 0; tweak < 4; tweak++)
+                    {
+                        // EndpointRefiner<3> refiners[2]: fresh (zero in the canonical build) per tweak
+                        float tv[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, tt = 0.0f, ts = 0.0f;
+                        int refCount = 0; // contributions of the previous round
+                        bool abortRemaining = false;
+
+                        for (int refinePass = 0; refinePass < 3; refinePass++)
+                        {
+                            const int metaRound = tweak * 3 + refinePass;
+                            if (tweak >= numTweakRounds || refinePass >= numRefineRounds)
+                                abortRemaining = true;
+                            if (abortRemaining)
+                            {
+                                if (subset == 0) roundValid0 &= ~(1u << metaRound); else roundValid1 &= ~(1u << metaRound);
+                                continue;
+                            }
+
+                            // ---- endpoints in colour space ----
+                            int epCS[2][3];
+                            if (refinePass == 0)
+                            {
+                                const float tf0 = T->tweakFactors[indexBits - 2][tweak][0];
+                                const float tf1 = T->tweakFactors[indexBits - 2][tweak][1];
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++)
+                                {
+                                    // FinishHDRSigned / Unsigned, UnfinishedEndpoints.h:39-75
+                                    const float lo = SIGNED ? -31743.0f : 0.0f;
+                                    const float f0 = sseMax(sseMin(ufep.base[ch] + ufep.offset[ch] * tf0, 31743.0f), lo);
+                                    const float f1 = sseMax(sseMin(ufep.base[ch] + ufep.offset[ch] * tf1, 31743.0f), lo);
+                                    epCS[0][ch] = (int)rintf(f0);
+                                    epCS[1][ch] = (int)rintf(f1);
+                                }
+                            }
+                            else
+                            {
+                                // EndpointRefiner::GetRefinedEndpointsHDR (EndpointRefiner.h:99-175) from the
+                                // previous round's sums (empty when that round was skipped as a duplicate)
+                                const float w = (refCount == 0) ? 1.0f : wCount;
+                                const float wr = (refCount == 0) ? T->rcpTable[1] : wRcp;
+                                float adenom = (tt * w - ts * ts) * wr;
+                                const bool z = (adenom == 0.0f);
+                                if (z) adenom = 1.0f;
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++)
+                                {
+                                    const float a = (tv[ch] - ts * vs[ch] * wr) / adenom;
+                                    const float b = (vs[ch] - a * ts) * wr;
+                                    float p1 = b, p2 = a + b;
+                                    if (z)
+                                    {
+                                        p1 = vs[ch] * wr;
+                                        p2 = p1;
+                                    }
+                                    const float lo = SIGNED ? -31743.0f : 0.0f;
+                                    epCS[0][ch] = (int)rintf(sseMax(sseMin(p1 * A.rcpW[ch], 31743.0f), lo));
+                                    epCS[1][ch] = (int)rintf(sseMax(sseMin(p2 * A.rcpW[ch], 31743.0f), lo));
+                                }
+                            }
+                            // refiners[subset].Init(...)
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++)
+                                tv[ch] = vs[ch] = 0.0f;
+                            tt = ts = 0.0f;
+                            refCount = 0;
+
+                            // ---- QuantizeEndpoints{Signed,Unsigned}, BC67.cpp:2503-2595 ----
+                            int q[2][3], unq[2][3], fin[2][3];
+#pragma unroll
+                            for (int epi = 0; epi < 2; epi++)
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++)
+                                {
+                                    if (SIGNED)
+                                    {
+                                        q[epi][ch] = quantizeSigned(epCS[epi][ch], aPrec);
+                                        unq[epi][ch] = unquantizeSigned(q[epi][ch], aPrec, fin[epi][ch]);
+                                    }
+                                    else
+                                    {
+                                        q[epi][ch] = quantizeUnsigned(epCS[epi][ch] & 0xffff, aPrec);
+                                        unq[epi][ch] = unquantizeUnsigned(q[epi][ch], aPrec, fin[epi][ch]);
+                                    }
+                                }
+
+                            // ---- raw (un-inverted) index of every pixel of the subset ----
+                            float selBest[16];
+                            int selIdx[16];
+#pragma unroll
+                            for (int px = 0; px < 16; px++)
+                            {
+                                selBest[px] = 0.0f;
+                                selIdx[px] = 0;
+                            }
+                            const u32 sm = opaqueUniform(subsetMask);
+                            if (FAST)
+                            {
+                                // IndexSelector::Init on the colour-space endpoints + SelectIndexLDR
+                                float origin[3], axis[3], epDW[3];
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++)
+                                {
+                                    origin[ch] = (float)fin[0][ch];
+                                    epDW[ch] = ((float)fin[1][ch] - origin[ch]) * A.w[ch];
+                                }
+                                float lenSq = epDW[0] * epDW[0];
+                                lenSq = lenSq + epDW[1] * epDW[1];
+                                lenSq = lenSq + epDW[2] * epDW[2];
+                                lenSq = safeDenom(lenSq);
+                                const float mvdls = maxValue / lenSq;
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++)
+                                    axis[ch] = epDW[ch] * A.w[ch] * mvdls;
+#pragma unroll
+                                for (int px = 0; px < 16; px++)
+                                    if ((sm >> px) & 1u)
+                                    {
+                                        const u32 a = fetchPixel(pk01[px]), b = fetchPixel(pk2[px]);
+                                        float dist = ((float)(int)(short)(a & 0xffffu) - origin[0]) * axis[0];
+                                        dist = dist + ((float)(int)(short)(a >> 16) - origin[1]) * axis[1];
+                                        dist = dist + ((float)(int)(short)(b & 0xffffu) - origin[2]) * axis[2];
+                                        selIdx[px] = (int)clampRound(dist, maxValue);
+                                    }
+                            }
+                            else
+                            {
+                                // SelectIndexHDRSlow with the interpolant in the outer loop
+                                for (int i = 0; i < indexRange; i++)
+                                {
+                                    const int weight = mad24(weightRcp, i, 256) >> 9;
+                                    float iw[3];
+#pragma unroll
+                                    for (int ch = 0; ch < 3; ch++)
+                                        iw[ch] = twosCLHalfToFloat(reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight)) * A.w[ch];
+#pragma unroll
+                                    for (int px = 0; px < 16; px++)
+                                        if ((sm >> px) & 1u)
+                                        {
+                                            float d = linW[px][0] - iw[0];
+                                            float e = d * d;
+                                            d = linW[px][1] - iw[1];
+                                            e = e + d * d;
+                                            d = linW[px][2] - iw[2];
+                                            e = e + d * d;
+                                            if (i == 0)
+                                                selBest[px] = e;
+                                            else
+                                            {
+                                                if (e < selBest[px])
+                                                    selIdx[px] = i;
+                                                selBest[px] = sseMin(selBest[px], e);
+                                            }
+                                        }
+                                }
+                            }
+
+                            // anchor index decides the inversion (BC67.cpp:2525-2547)
+                            int fixRaw = 0;
+#pragma unroll
+                            for (int px = 0; px < 16; px++)
+                                if (px == fixupIndex)
+                                    fixRaw = selIdx[px];
+                            const bool invert = (indexRange / 2 - 1) < fixRaw;
+                            if (invert)
+                            {
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++)
+                                {
+                                    const int t = q[0][ch];
+                                    q[0][ch] = q[1][ch];
+                                    q[1][ch] = t;
+                                }
+                            }
+                            const u32 qa = ((u32)q[0][0] & 0xffffu) | ((u32)q[0][1] << 16);
+                            const u32 qb = ((u32)q[0][2] & 0xffffu) | ((u32)q[1][0] << 16);
+                            const u32 qc = ((u32)q[1][1] & 0xffffu) | ((u32)q[1][2] << 16);
+                            const int epqAt = kEpqBase + (metaRound * 2 + subset) * 3;
+
+                            // ---- duplicate-round test against every earlier meta round (group-wide) ----
+                            bool anySame = false;
+                            for (int prev = 0; prev < metaRound; prev++)
+                            {
+                                const int at = kEpqBase + (prev * 2 + subset) * 3;
+                                anySame = anySame || (meta[at][lane] == qa && meta[at + 1][lane] == qb && meta[at + 2][lane] == qc);
+                            }
+                            meta[epqAt][lane] = qa;
+                            meta[epqAt + 1][lane] = qb;
+                            meta[epqAt + 2][lane] = qc;
+                            const bool groupAllSame = (metaRound > 0) && (groupBits(__ballot(anySame), lane) == 0xffu);
+                            if (groupAllSame)
+                            {
+                                if (subset == 0) roundValid0 &= ~(1u << metaRound); else roundValid1 &= ~(1u << metaRound);
+                                // the anchor index was already stored by QuantizeEndpoints (BC67.cpp:2547)
+                                const int at = kIdxBase + metaRound * 2 + (fixupIndex >> 3);
+                                const int sh = 4 * (fixupIndex & 7);
+                                const u32 fi = (u32)(invert ? (indexRange - 1) - fixRaw : fixRaw);
+                                meta[at][lane] = (meta[at][lane] & ~(0xfu << sh)) | (fi << sh);
+                            }
+                            else
+                            {
+                                // ---- error, indexes and refiner sums in pixel order (BC67.cpp:2879-2909) ----
+                                float subsetError = 0.0f;
+                                u32 idxLo = meta[kIdxBase + metaRound * 2][lane], idxHi = meta[kIdxBase + metaRound * 2 + 1][lane];
+#pragma unroll
+                                for (int px = 0; px < 16; px++)
+                                    if ((sm >> px) & 1u)
+                                    {
+                                        const int raw = selIdx[px];
+                                        const int index = invert ? (indexRange - 1) - raw : raw;
+                                        if (px < 8)
+                                            idxLo = (idxLo & ~(0xfu << (4 * px))) | ((u32)index << (4 * px));
+                                        else
+                                            idxHi = (idxHi & ~(0xfu << (4 * (px - 8)))) | ((u32)index << (4 * (px - 8)));
+
+                                        const int weight = mad24(weightRcp, raw, 256) >> 9;
+                                        const u32 a = fetchPixel(pk01[px]), b = fetchPixel(pk2[px]);
+                                        const int orig[3] = {(int)(short)(a & 0xffffu), (int)(short)(a >> 16), (int)(short)(b & 0xffffu)};
+                                        float err = 0.0f;
+#pragma unroll
+                                        for (int ch = 0; ch < 3; ch++)
+                                        {
+                                            const int rec = reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight);
+                                            float sq;
+                                            if (FAST)
+                                            {
+                                                // SqDiffSInt16, ParallelMath.h:996-1010
+                                                const int r16 = (int)(short)rec;
+                                                const u32 du = (u32)((r16 > orig[ch] ? r16 : orig[ch]) - (r16 > orig[ch] ? orig[ch] : r16)) & 0xffffu;
+                                                sq = (float)(int)(du * du);
+                                            }
+                                            else
+                                            {
+                                                const float d = twosCLHalfToFloat(rec) - twosCLHalfToFloat(orig[ch]);
+                                                sq = d * d;
+                                            }
+                                            err = uniformErr ? (err + sq) : (err + sq * A.wSq[ch]);
+                                        }
+                                        subsetError = subsetError + err;
+
+                                        if (refinePass != numRefineRounds - 1)
+                                        {
+                                            const float t = (float)index * rcpMaxIndex;
+#pragma unroll
+                                            for (int ch = 0; ch < 3; ch++)
+                                            {
+                                                const float v = (float)orig[ch] * A.w[ch];
+                                                tv[ch] = tv[ch] + t * v;
+                                                vs[ch] = vs[ch] + v;
+                                            }
+                                            tt = tt + t * t;
+                                            ts = ts + t;
+                                            refCount++;
+                                        }
+                                    }
+                                meta[kIdxBase + metaRound * 2][lane] = idxLo;
+                                meta[kIdxBase + metaRound * 2 + 1][lane] = idxHi;
+                                meta[kErrBase + metaRound * 2 + subset][lane] = __float_as_uint(subsetError);
+                            }
+                        }
+                    }
+                }
+
+                // ---- delta-coding legality + commit, BC67.cpp:2914-2986 ----
+                const int numMeta1 = partitioned ? 12 : 1;
+                for (int meta0 = 0; meta0 < 12; meta0++)
+                {
+                    for (int meta1 = 0; meta1 < numMeta1; meta1++)
+                    {
+                        const bool roundsOk = ((roundValid0 >> meta0) & 1u) && (!partitioned || ((roundValid1 >> meta1) & 1u));
+                        float combined = __uint_as_float(meta[kErrBase + meta0 * 2][lane]);
+                        if (partitioned)
+                            combined = combined + __uint_as_float(meta[kErrBase + meta1 * 2 + 1][lane]);
+                        const bool errorBetter = roundsOk && (combined < bestError);
+                        if (__ballot(errorBetter) == 0)
+                            continue;
+                        const bool groupAny = groupBits(__ballot(errorBetter), lane) != 0;
+                        bool needsCommit = errorBetter;
+                        bool groupDone = !groupAny; // this group's mode loop has ended (or never started)
+
+                        // quantised endpoints of the two rounds
+                        int e0[2][3], e1[2][3];
+                        {
+                            const int at0 = kEpqBase + (meta0 * 2 + 0) * 3, at1 = kEpqBase + (meta1 * 2 + 1) * 3;
+                            const u32 a0 = meta[at0][lane], b0 = meta[at0 + 1][lane], c0 = meta[at0 + 2][lane];
+                            const u32 a1 = meta[at1][lane], b1 = meta[at1 + 1][lane], c1 = meta[at1 + 2][lane];
+                            e0[0][0] = (int)(short)(a0 & 0xffffu); e0[0][1] = (int)(short)(a0 >> 16); e0[0][2] = (int)(short)(b0 & 0xffffu);
+                            e0[1][0] = (int)(short)(b0 >> 16); e0[1][1] = (int)(short)(c0 & 0xffffu); e0[1][2] = (int)(short)(c0 >> 16);
+                            e1[0][0] = (int)(short)(a1 & 0xffffu); e1[0][1] = (int)(short)(a1 >> 16); e1[0][2] = (int)(short)(b1 & 0xffffu);
+                            e1[1][0] = (int)(short)(b1 >> 16); e1[1][1] = (int)(short)(c1 & 0xffffu); e1[1][2] = (int)(short)(c1 >> 16);
+                        }
+
+                        for (int mode = 0; mode < 14; mode++)
+                        {
+                            const int miPartitioned = T->bc6hModeInfo[mode][1];
+                            const int miPrec = T->bc6hModeInfo[mode][3];
+                            if ((miPartitioned != 0) != partitioned || miPrec != aPrec)
+                                continue;
+                            const bool transformed = T->bc6hModeInfo[mode][2] != 0;
+                            const int bPrec[3] = {T->bc6hModeInfo[mode][4], T->bc6hModeInfo[mode][5], T->bc6hModeInfo[mode][6]};
+
+                            // Evaluate{Partitioned,Single}Legality, BC67.cpp:2597-2663
+                            int enc[2][2][3];
+                            bool legal = true;
+                            const int mask = (1 << aPrec) - 1;
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++)
+                            {
+                                enc[0][0][ch] = e0[0][ch];
+                                enc[0][1][ch] = e0[1][ch];
+                                enc[1][0][ch] = partitioned ? e1[0][ch] : 0;
+                                enc[1][1][ch] = partitioned ? e1[1][ch] : 0;
+                                if (transformed)
+                                {
+                                    const int lost = 16 - bPrec[ch];
+#pragma unroll
+                                    for (int s = 0; s < 2; s++)
+#pragma unroll
+                                        for (int epi = 0; epi < 2; epi++)
+                                        {
+                                            if ((s == 0 && epi == 0) || (s == 1 && !partitioned))
+                                                continue;
+                                            const int bReduced = enc[s][epi][ch] & mask & 0xffff;
+                                            const int d16 = (int)(short)(unsigned short)(enc[s][epi][ch] - enc[0][0][ch]);
+                                            const int delta = (int)(short)(unsigned short)((u32)d16 << lost) >> lost;
+                                            enc[s][epi][ch] = delta;
+                                            const int reconstructed = (delta + enc[0][0][ch]) & mask & 0xffff;
+                                            legal = legal && (reconstructed == bReduced);
+                                        }
+                                }
+                            }
+
+                            const bool commit = errorBetter && legal && !groupDone;
+                            const u32 gCommit = groupBits(__ballot(commit), lane);
+                            if (commit)
+                            {
+                                bestError = combined;
+                                bestMode = mode;
+                                bestPartition = p;
+                                bestEP[0] = ((u32)enc[0][0][0] & 0xffffu) | ((u32)enc[0][0][1] << 16);
+                                bestEP[1] = ((u32)enc[0][0][2] & 0xffffu) | ((u32)enc[0][1][0] << 16);
+                                bestEP[2] = ((u32)enc[0][1][1] & 0xffffu) | ((u32)enc[0][1][2] << 16);
+                                if (partitioned)
+                                {
+                                    bestEP[3] = ((u32)enc[1][0][0] & 0xffffu) | ((u32)enc[1][0][1] << 16);
+                                    bestEP[4] = ((u32)enc[1][0][2] & 0xffffu) | ((u32)enc[1][1][0] << 16);
+                                    bestEP[5] = ((u32)enc[1][1][1] & 0xffffu) | ((u32)enc[1][1][2] << 16);
+                                }
+                                // indexes: subset-0 pixels from round meta0, subset-1 pixels from meta1
+                                const u32 lo0 = meta[kIdxBase + meta0 * 2][lane], hi0 = meta[kIdxBase + meta0 * 2 + 1][lane];
+                                const u32 lo1 = meta[kIdxBase + meta1 * 2][lane], hi1 = meta[kIdxBase + meta1 * 2 + 1][lane];
+                                u32 nLo = 0, nHi = 0;
+#pragma unroll
+                                for (int px = 0; px < 8; px++)
+                                {
+                                    if ((partitionMask >> px) & 1u) nLo |= 0xfu << (4 * px);
+                                    if ((partitionMask >> (px + 8)) & 1u) nHi |= 0xfu << (4 * px);
+                                }
+                                bestIdxLo = (lo0 & ~nLo) | (lo1 & nLo);
+                                bestIdxHi = (hi0 & ~nHi) | (hi1 & nHi);
+                                needsCommit = false;
+                            }
+                            // `continue` when nobody of the group commits skips the needsCommit test (BC67.cpp:2954-2955)
+                            if (gCommit != 0 && groupBits(__ballot(needsCommit && !groupDone), lane) == 0)
+                                groupDone = true;
+                            if (__ballot(!groupDone) == 0)
+                                break;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- header scatter + indexes (BC67.cpp:2992-3050, BC6H_IO: table from tools/gen_bc6h_layout.py) ----
+    if (valid)
+    {
+        const bool partitioned = T->bc6hModeInfo[bestMode][1] != 0;
+        const int headerBits = partitioned ? 82 : 65;
+        u32 fields[14];
+        fields[0] = T->bc6hModeInfo[bestMode][0];
+        fields[1] = (u32)bestPartition;
+        // fields: rw rx ry rz | gw gx gy gz | bw bx by bz  (w,x = subset 0 ep 0,1; y,z = subset 1)
+        const u32 e[2][2][3] = {
+            {{bestEP[0] & 0xffffu, bestEP[0] >> 16, bestEP[1] & 0xffffu}, {bestEP[1] >> 16, bestEP[2] & 0xffffu, bestEP[2] >> 16}},
+            {{bestEP[3] & 0xffffu, bestEP[3] >> 16, bestEP[4] & 0xffffu}, {bestEP[4] >> 16, bestEP[5] & 0xffffu, bestEP[5] >> 16}}};
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+        {
+            fields[2 + ch * 4 + 0] = e[0][0][ch];
+            fields[2 + ch * 4 + 1] = e[0][1][ch];
+            fields[2 + ch * 4 + 2] = e[1][0][ch];
+            fields[2 + ch * 4 + 3] = e[1][1][ch];
+        }
+        u64 lo = 0, hi = 0;
+        for (int bit = 0; bit < headerBits; bit++)
+        {
+            const u32 code = T->bc6hLayout[bestMode][bit];
+            u32 fv = 0;
+#pragma unroll
+            for (int f = 0; f < 14; f++)
+                if ((code >> 4) == (u32)f)
+                    fv = fields[f];
+            const u64 b = (u64)((fv >> (code & 15u)) & 1u);
+            if (bit < 64)
+                lo |= b << bit;
+            else
+                hi |= b << (bit - 64);
+        }
+        int off = headerBits;
+        const int fixupIndex1 = partitioned ? (int)T->anchor2[bestPartition & 31] : 0;
+        const int ib = partitioned ? 3 : 4;
+        const u64 idx = ((u64)bestIdxHi << 32) | bestIdxLo;
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+        {
+            const int bits = (px == 0 || px == fixupIndex1) ? ib - 1 : ib;
+            const u64 v = (idx >> (4 * px)) & 0xfull;
+            if (off < 64)
+            {
+                lo |= v << off;
+                if (off + bits > 64)
+                    hi |= v >> (64 - off);
+            }
+            else
+                hi |= v << (off - 64);
+            off += bits;
+        }
+        uint4 o;
+        o.x = (u32)lo;
+        o.y = (u32)(lo >> 32);
+        o.z = (u32)hi;
+        o.w = (u32)(hi >> 32);
+        *reinterpret_cast<uint4 *>(out + (size_t)blockIndex * 16u) = o;
+    }
+}
+
+extern "C" hipError_t cvttmi_launch_bc6h(const void *d_blocks, void *d_out, const CvttBc6hArgs *args,
+                                         const CvttDeviceTables *d_tables, int isSigned, hipStream_t stream)
+{
+    const uint32_t waves = (args->numBlocks + 63u) / 64u;
+    if (waves == 0)
+        return hipSuccess;
+    const bool fast = (args->flags & CVTTMI_FLAG_BC6H_FAST_INDEXING) != 0;
+#define CVTT_LAUNCH(S, Fq) hipLaunchKernelGGL((cvttmi_bc6h_kernel<S, Fq>), dim3(waves), dim3(64), 0, stream, (const uint8_t *)d_blocks, (uint8_t *)d_out, *args, d_tables)
+    if (isSigned)
+    {
+        if (fast) CVTT_LAUNCH(true, true); else CVTT_LAUNCH(true, false);
+    }
+    else
+    {
+        if (fast) CVTT_LAUNCH(false, true); else CVTT_LAUNCH(false, false);
+    }
+#undef CVTT_LAUNCH
+    return hipGetLastError();
+}

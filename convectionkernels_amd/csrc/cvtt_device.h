@@ -22,6 +22,10 @@ struct CvttDeviceTables
     float rcpTable[17];        // host RCPPS(i), i = 1..16
     float rcpMaxIndex[5];      // 1.0f / ((1 << bits) - 1), bits = 0..4 (entry 0 unused)
     float tweakFactors3[2][4][2]; // same for range = 3, 4 (BC1; range 3 has 3 seed points)
+    // BC6H mode table {mode id, two regions, transformed, endpoint bits, delta bits r,g,b, pad}
+    // and header bit layout (field*16+bit; tools/gen_bc6h_layout.py)
+    uint8_t bc6hModeInfo[14][8];
+    uint8_t bc6hLayout[14][82];
 };
 
 // The caller's plan plus two bitmaps derived on the host: which shapes the plan's
@@ -60,6 +64,18 @@ struct CvttBc1Args
     int32_t refineRounds; // Options::refineRoundsS3TC
     int32_t seedPoints;   // Options::seedPoints
     int32_t threshold;    // floor(threshold * 255 + 0.5) as a signed 16-bit lane value (S3TC.cpp:748)
+    uint32_t numBlocks;
+};
+
+// BC6H per-launch parameters.
+struct CvttBc6hArgs
+{
+    float w[4];
+    float wSq[4];
+    float rcpW[4];
+    uint32_t flags;
+    int32_t refineRounds; // Options::refineRoundsBC6H (clamped to 1..3 by the kernel)
+    int32_t seedPoints;   // Options::seedPoints (clamped to 1..4)
     uint32_t numBlocks;
 };
 

@@ -69,9 +69,24 @@ struct Moments
     float cov[N * (N + 1) / 2]; // lower triangle, row-major: (row,col) at row*(row+1)/2+col
 };
 
+// Pixel source for the PCA passes: pre-weighted channel values of pixel px.
+struct FetchLDR
+{
+    const u32 (&pix)[16];
+    const float (&w)[4];
+    template <int N>
+    __device__ __forceinline__ void get(int px, float (&v)[N]) const
+    {
+        const u32 pk = fetchPixel(pix[px]);
+#pragma unroll
+        for (int ch = 0; ch < N; ch++)
+            v[ch] = byteF(pk, ch) * w[ch];
+    }
+};
+
 // passes 0 and 1: centroid and scatter matrix of the pre-weighted pixels
-template <int N>
-__device__ __forceinline__ void pcaMoments(const u32 (&pix)[16], u32 mask, const float (&w)[4], Moments<N> &m)
+template <int N, class Fetch>
+__device__ __forceinline__ void pcaMomentsT(const Fetch &F, u32 mask, Moments<N> &m)
 {
 #pragma unroll
     for (int ch = 0; ch < N; ch++)
@@ -82,10 +97,11 @@ __device__ __forceinline__ void pcaMoments(const u32 (&pix)[16], u32 mask, const
     {
         if ((mask >> px) & 1u)
         {
-            const u32 pk = fetchPixel(pix[px]);
+            float v[N];
+            F.template get<N>(px, v);
 #pragma unroll
             for (int ch = 0; ch < N; ch++)
-                m.centroid[ch] = m.centroid[ch] + byteF(pk, ch) * w[ch];
+                m.centroid[ch] = m.centroid[ch] + v[ch];
             count = count + 1.0f;
         }
     }
@@ -102,11 +118,12 @@ __device__ __forceinline__ void pcaMoments(const u32 (&pix)[16], u32 mask, const
     {
         if ((mask >> px) & 1u)
         {
-            const u32 pk = fetchPixel(pix[px]);
+            float v[N];
+            F.template get<N>(px, v);
             float diff[N];
 #pragma unroll
             for (int ch = 0; ch < N; ch++)
-                diff[ch] = byteF(pk, ch) * w[ch] - m.centroid[ch];
+                diff[ch] = v[ch] - m.centroid[ch];
             int index = 0;
 #pragma unroll
             for (int row = 0; row < N; row++)
@@ -120,10 +137,16 @@ __device__ __forceinline__ void pcaMoments(const u32 (&pix)[16], u32 mask, const
     }
 }
 
-// power iteration, pass 2 and GetEndpoints
 template <int N>
-__device__ __forceinline__ void pcaFinish(const u32 (&pix)[16], u32 mask, const float (&w)[4], const Moments<N> &m,
-                                          Unfinished &u)
+__device__ __forceinline__ void pcaMoments(const u32 (&pix)[16], u32 mask, const float (&w)[4], Moments<N> &m)
+{
+    const FetchLDR F = {pix, w};
+    pcaMomentsT<N>(F, mask, m);
+}
+
+// power iteration, pass 2 and GetEndpoints
+template <int N, class Fetch>
+__device__ __forceinline__ void pcaFinishT(const Fetch &F, u32 mask, const float (&w)[4], const Moments<N> &m, Unfinished &u)
 {
     float approx[N];
 #pragma unroll
@@ -170,11 +193,12 @@ __device__ __forceinline__ void pcaFinish(const u32 (&pix)[16], u32 mask, const 
     {
         if ((mask >> px) & 1u)
         {
-            const u32 pk = fetchPixel(pix[px]);
+            float v[N];
+            F.template get<N>(px, v);
             float dist = 0.0f;
 #pragma unroll
             for (int ch = 0; ch < N; ch++)
-                dist = dist + direction[ch] * (byteF(pk, ch) * w[ch] - m.centroid[ch]);
+                dist = dist + direction[ch] * (v[ch] - m.centroid[ch]);
             minDist = sseMin(minDist, dist);
             maxDist = sseMax(maxDist, dist);
         }
@@ -187,6 +211,14 @@ __device__ __forceinline__ void pcaFinish(const u32 (&pix)[16], u32 mask, const 
         u.base[ch] = mn / w[ch];
         u.offset[ch] = (mx - mn) / w[ch];
     }
+}
+
+template <int N>
+__device__ __forceinline__ void pcaFinish(const u32 (&pix)[16], u32 mask, const float (&w)[4], const Moments<N> &m,
+                                          Unfinished &u)
+{
+    const FetchLDR F = {pix, w};
+    pcaFinishT<N>(F, mask, w, m, u);
 }
 
 template <int N>

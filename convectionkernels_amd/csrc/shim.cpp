@@ -17,6 +17,7 @@
 
 #include "cvtt_device.h"
 #include "bc7_tables.h"
+#include "bc6h_layout.h"
 
 extern "C" hipError_t cvttmi_launch_bc7(const void *d_blocks, void *d_out, const CvttBc7Args *args,
                                         const CvttDeviceTables *d_tables, const CvttBc7DevicePlan *d_plan,
@@ -24,6 +25,9 @@ extern "C" hipError_t cvttmi_launch_bc7(const void *d_blocks, void *d_out, const
 
 extern "C" hipError_t cvttmi_launch_bc1(const void *d_blocks, void *d_out, const CvttBc1Args *args,
                                         const CvttDeviceTables *d_tables, hipStream_t stream);
+
+extern "C" hipError_t cvttmi_launch_bc6h(const void *d_blocks, void *d_out, const CvttBc6hArgs *args,
+                                         const CvttDeviceTables *d_tables, int isSigned, hipStream_t stream);
 
 static_assert(sizeof(cvttmi_options) == 44, "cvtt::Options layout");
 static_assert(sizeof(cvttmi_bc7_plan) == 808, "cvtt::BC7EncodingPlan layout");
@@ -114,6 +118,13 @@ namespace
         for (int r = 0; r < 2; r++)
             for (int tw = 0; tw < 4; tw++)
                 tweakFactors(tw, 3 + r, t.tweakFactors3[r][tw]); // range 3, tweak 3 divides by zero: never read
+        for (int m = 0; m < 14; m++)
+        {
+            for (int i = 0; i < 7; i++)
+                t.bc6hModeInfo[m][i] = k_bc6h_mode_info[m][i];
+            for (int b = 0; b < 82; b++)
+                t.bc6hLayout[m][b] = k_bc6h_header_layout[m][b];
+        }
         t.rcpMaxIndex[0] = 0.0f;
         for (int bits = 1; bits <= 4; bits++)
         {
@@ -430,6 +441,72 @@ extern "C"
             ctx->totalMs += ms;
             ctx->launches += 1;
         }
+        return CVTTMI_OK;
+    }
+
+    int cvttmi_encode_bc6h_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
+                                  const cvttmi_options *options, int isSigned, void *hipStream)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        if (!d_out || !d_blocks || !options || (numBlocks % 8) != 0 || numBlocks > 0xfffffff0u)
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        if (numBlocks == 0)
+            return CVTTMI_OK;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        hipStream_t stream = static_cast<hipStream_t>(hipStream);
+        CvttBc6hArgs args;
+        fillWeightArgs(options, args.w, args.wSq, args.rcpW);
+        args.flags = options->flags;
+        args.refineRounds = options->refineRoundsBC6H;
+        args.seedPoints = options->seedPoints;
+        args.numBlocks = static_cast<uint32_t>(numBlocks);
+        if (ctx->timing)
+            hipEventRecord(ctx->evStart, stream);
+        e = cvttmi_launch_bc6h(d_blocks, d_out, &args, ctx->dTables, isSigned, stream);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "bc6h kernel launch", e);
+        if (ctx->timing)
+        {
+            hipEventRecord(ctx->evStop, stream);
+            hipEventSynchronize(ctx->evStop);
+            float ms = 0.0f;
+            hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop);
+            ctx->totalMs += ms;
+            ctx->launches += 1;
+        }
+        return CVTTMI_OK;
+    }
+
+    int cvttmi_encode_bc6h(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
+                           const cvttmi_options *options, int isSigned)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        if (!out || !blocks || !options || (numBlocks % 8) != 0)
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        if (numBlocks == 0)
+            return CVTTMI_OK;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        const size_t inBytes = numBlocks * 128, outBytes = numBlocks * 16;
+        int rc = ensureStaging(ctx, inBytes, outBytes);
+        if (rc != CVTTMI_OK)
+            return rc;
+        memcpy(ctx->pinnedIn, blocks, inBytes);
+        if ((e = hipMemcpyAsync(ctx->dIn, ctx->pinnedIn, inBytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "H2D", e);
+        rc = cvttmi_encode_bc6h_device(ctx, ctx->dOut, ctx->dIn, numBlocks, options, isSigned, ctx->stream);
+        if (rc != CVTTMI_OK)
+            return rc;
+        if ((e = hipMemcpyAsync(ctx->pinnedOut, ctx->dOut, outBytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "D2H", e);
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "kernel execution", e);
+        memcpy(out, ctx->pinnedOut, outBytes);
         return CVTTMI_OK;
     }
 

@@ -121,6 +121,15 @@ int cvttmi_encode_bc7_device(cvttmi_context *ctx, void *d_out, const void *d_blo
 int cvttmi_encode_bc1_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
                              const cvttmi_options *options, void *hipStream);
 
+/* replaces cvtt::Kernels::EncodeBC6HU (isSigned = 0) / EncodeBC6HS (isSigned != 0)
+ * (ConvectionKernels_API.cpp:56-84 -> BC6HComputer::Pack, ConvectionKernels_BC67.cpp:2665-3051):
+ * numBlocks * 128 B of PixelBlockF16 (half bits as int16, RGBA, alpha ignored) in,
+ * numBlocks * 16 B out.  Uses options->seedPoints, refineRoundsBC6H, the BC6H_FastIndexing /
+ * Uniform flags and the channel weights.  Group g = blocks [8g, 8g+8) keeps the reference's
+ * cross-lane coupling (duplicate-round skip, mode commit loop). */
+int cvttmi_encode_bc6h_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
+                              const cvttmi_options *options, int isSigned, void *hipStream);
+
 /* ---- host-buffer convenience entry points: stage through pinned memory, launch, copy
  * back, synchronise.  Same semantics as the *_device calls. ---- */
 int cvttmi_encode_bc7(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
@@ -128,6 +137,9 @@ int cvttmi_encode_bc7(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, 
 
 int cvttmi_encode_bc1(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
                       const cvttmi_options *options);
+
+int cvttmi_encode_bc6h(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
+                       const cvttmi_options *options, int isSigned);
 
 /* Search strategy.  By default the kernels skip candidates (partitions / subsets) whose
  * rigorous error lower bound already exceeds the best candidate found so far -- an exact

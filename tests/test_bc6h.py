@@ -44,3 +44,48 @@ def test_group_coupling_changes_output(oracle_lib):
     opt = pyref.make_options()
     grouped = oracle_lib.encode_bc6h(blocks, opt, False, None, 8)
     assert grouped.shape == (128, 16)
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_golden(gpu_ctx, name):
+    from convectionkernels_amd import api
+    g = np.load(os.path.join(GOLD, "bc6h_mixed.npz"))
+    gpu_ctx.set_rcp_table(g["rcp"])
+    opt = api.Options.frombytes(g["opt_" + name])
+    out = gpu_ctx.encode_bc6h(g["blocks"], opt, signed=False)
+    bad = np.nonzero((out != g["out_" + name]).any(axis=1))[0]
+    assert bad.size == 0, bad[:8]
+    outs = gpu_ctx.encode_bc6h(g["blocks_signed"], opt, signed=True)
+    bad = np.nonzero((outs != g["outs_" + name]).any(axis=1))[0]
+    assert bad.size == 0, bad[:8]
+
+
+@pytest.mark.gpu
+def test_gpu_known_answers_and_config3(gpu_ctx, oracle_lib):
+    """App. H vector; BASELINE configs[2] content (positive normal halfs) vs the oracle; device path"""
+    import torch
+    from convectionkernels_amd import api
+    g = np.load(os.path.join(GOLD, "known_answers.npz"))
+    gpu_ctx.set_rcp_table(g["rcp"])
+    assert (gpu_ctx.encode_bc6h(g["hdr_blocks"], api.Options()) == g["bc6hu"]).all()
+    rcp = oracle_lib.probe_rcp()
+    gpu_ctx.set_rcp_table(rcp)
+    blocks = content.config_blocks_hdr(3, 128, 128)  # 1024 blocks of the config-3 generator
+    exp = oracle_lib.encode_bc6h(blocks, pyref.make_options(), False, rcp, threads=8)
+    t = torch.from_numpy(blocks).cuda()
+    out = gpu_ctx.encode_bc6h(t, api.Options()).cpu().numpy()
+    assert (out == exp).all()
+    for n in (8, 72):  # ragged tails of a 64-block wave
+        assert (gpu_ctx.encode_bc6h(blocks[:n].copy(), api.Options()) == exp[:n]).all()
+
+
+@pytest.mark.gpu
+def test_gpu_vs_reference_on_this_box(gpu_ctx, ref_lib):
+    from convectionkernels_amd import api
+    gpu_ctx.set_rcp_table(ref_lib.probe_rcp())
+    blocks = content.mixed_hdr_blocks(2024, 24)
+    assert (gpu_ctx.encode_bc6h(blocks, api.Options()) == ref_lib.encode_bc6h(blocks, ref_lib.default_options(), False)).all()
+    sblocks = content.mixed_hdr_blocks(2025, 8, signed=True)
+    assert (gpu_ctx.encode_bc6h(sblocks, api.Options(), signed=True) == ref_lib.encode_bc6h(sblocks, ref_lib.default_options(), True)).all()
