@@ -19,14 +19,21 @@
 //   * the per-partition "meta round" results (quantised endpoints, indexes, errors of up to
 //     12 rounds x 2 subsets) live in LDS, [entry][lane] so every access is conflict free.
 #include "cvtt_kernel_common.h"
+#include <hip/hip_fp16.h>
 
 namespace
 {
-// ---- LDS layout (dwords per lane) ----
-//   EPQ : 12 rounds x 2 subsets x 3 dwords (6 x int16: ep0.rgb, ep1.rgb)      = 72
-//   IDX : 12 rounds x 2 dwords (4 bits per pixel)                             = 24
-//   ERR : 12 rounds x 2 subsets                                               = 24
-constexpr int kEpqBase = 0, kIdxBase = 72, kErrBase = 96, kMetaDwords = 120;
+// ---- per-partition "meta round" state, dwords per lane ----
+//   EPQ : 12 rounds x 2 subsets x 3 dwords (6 x int16: ep0.rgb, ep1.rgb) = 72   -> HBM/L2 scratch
+//   IDX : 12 rounds x 2 dwords (4 bits per pixel)                        = 24   -> LDS
+//   ERR : 12 rounds x 2 subsets                                          = 24   -> LDS
+// Keeping the endpoint history out of LDS leaves 12 KB of LDS per wave, so the CU can hold
+// 2-3 waves per SIMD; the scratch is [wave][entry][lane], i.e. one coalesced 256-byte line
+// per access, and stays L2 resident.
+constexpr int kIdxBase = 0, kErrBase = 24, kMetaDwords = 48, kEpqDwords = 72;
+#ifndef CVTT_BC6H_WAVES
+#define CVTT_BC6H_WAVES 3
+#endif
 
 __device__ __forceinline__ float divRoundUp(float a, float b)
 {
@@ -97,8 +104,9 @@ __device__ __forceinline__ int unquantizeSigned(int comp, int precision, int &fi
     return (int)(short)unq;
 }
 
-// TwosCLHalfToFloat, ParallelMath.h:1012-1041
-__device__ __forceinline__ float twosCLHalfToFloat(int v16)
+// TwosCLHalfToFloat, ParallelMath.h:1012-1041 -- literal bit manipulation (needed for the
+// signed format, whose negative 2CL pixel values are not valid half patterns)
+__device__ __forceinline__ float twosCLHalfToFloatBits(int v16)
 {
     const u32 v = (u32)v16 & 0xffffu;
     const u32 signBits = v & 0x8000u;
@@ -110,6 +118,18 @@ __device__ __forceinline__ float twosCLHalfToFloat(int v16)
     const u32 highBits = signBits | exponent | (mantissa >> 3);
     const u32 lowBits = (mantissa << 13) & 0xffffu;
     return __uint_as_float((highBits << 16) | lowBits) - __uint_as_float(corrHigh << 16);
+}
+
+// For every finite non-negative half pattern (all the unsigned format ever sees: inputs are
+// clamped to [0, 0x7BFF], reconstructions to <= 31743) the function above equals the hardware
+// conversion, except that it halves denormals (exponent field 0) -- checked exhaustively.
+template <bool SIGNED>
+__device__ __forceinline__ float twosCLHalfToFloat(int v16)
+{
+    if (SIGNED)
+        return twosCLHalfToFloatBits(v16);
+    const float f = __half2float(__ushort_as_half((unsigned short)v16));
+    return (v16 & 0x7c00) ? f : f * 0.5f;
 }
 
 // ReconstructHDR{Signed,Unsigned}Uninverted for one channel, IndexSelectorHDR.h:34-66
@@ -155,11 +175,13 @@ __device__ __forceinline__ u32 groupBits(u64 ballot, int lane) { return (u32)(ba
 } // namespace
 
 template <bool SIGNED, bool FAST>
-__global__ __launch_bounds__(64) void cvttmi_bc6h_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
-                                                         const CvttBc6hArgs A, const CvttDeviceTables *__restrict__ T)
+__global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+                                                         const CvttBc6hArgs A, const CvttDeviceTables *__restrict__ T,
+                                                         u32 *__restrict__ scratch)
 {
     __shared__ u32 meta[kMetaDwords][64];
     const int lane = threadIdx.x;
+    u32 *const epq = scratch + (size_t)blockIdx.x * (kEpqDwords * 64) + lane; // entry e at epq[e * 64]
     const u32 blockIndex = blockIdx.x * 64u + (u32)lane;
     const bool valid = blockIndex < A.numBlocks;
     const bool uniformErr = (A.flags & CVTTMI_FLAG_UNIFORM) != 0;
@@ -188,7 +210,7 @@ __global__ __launch_bounds__(64) void cvttmi_bc6h_kernel(const uint8_t *__restri
                     x = x < 0 ? 0 : x;
                 x = x > 31743 ? 31743 : x;
                 v[ch] = x;
-                linW[px][ch] = twosCLHalfToFloat(x) * A.w[ch];
+                linW[px][ch] = twosCLHalfToFloat<SIGNED>(x) * A.w[ch];
             }
             pk01[px] = ((u32)v[0] & 0xffffu) | ((u32)v[1] << 16);
             pk2[px] = (u32)v[2] & 0xffffu;
@@ -232,6 +254,9 @@ __global__ __launch_bounds__(64) void cvttmi_bc6h_kernel(const uint8_t *__restri
 #pragma unroll 4
                 for (int e = 0; e < kMetaDwords; e++)
                     meta[e][lane] = 0;
+#pragma unroll 4
+                for (int e = 0; e < kEpqDwords; e++)
+                    epq[e * 64] = 0;
 
                 for (int subset = 0; subset < numSubsets; subset++)
                 {
@@ -384,7 +409,7 @@ __global__ __launch_bounds__(64) void cvttmi_bc6h_kernel(const uint8_t *__restri
                                     float iw[3];
 #pragma unroll
                                     for (int ch = 0; ch < 3; ch++)
-                                        iw[ch] = twosCLHalfToFloat(reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight)) * A.w[ch];
+                                        iw[ch] = twosCLHalfToFloat<SIGNED>(reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight)) * A.w[ch];
 #pragma unroll
                                     for (int px = 0; px < 16; px++)
                                         if ((sm >> px) & 1u)
@@ -427,18 +452,18 @@ __global__ __launch_bounds__(64) void cvttmi_bc6h_kernel(const uint8_t *__restri
                             const u32 qa = ((u32)q[0][0] & 0xffffu) | ((u32)q[0][1] << 16);
                             const u32 qb = ((u32)q[0][2] & 0xffffu) | ((u32)q[1][0] << 16);
                             const u32 qc = ((u32)q[1][1] & 0xffffu) | ((u32)q[1][2] << 16);
-                            const int epqAt = kEpqBase + (metaRound * 2 + subset) * 3;
+                            const int epqAt = (metaRound * 2 + subset) * 3;
 
                             // ---- duplicate-round test against every earlier meta round (group-wide) ----
                             bool anySame = false;
                             for (int prev = 0; prev < metaRound; prev++)
                             {
-                                const int at = kEpqBase + (prev * 2 + subset) * 3;
-                                anySame = anySame || (meta[at][lane] == qa && meta[at + 1][lane] == qb && meta[at + 2][lane] == qc);
+                                const int at = (prev * 2 + subset) * 3;
+                                anySame = anySame || (epq[at * 64] == qa && epq[(at + 1) * 64] == qb && epq[(at + 2) * 64] == qc);
                             }
-                            meta[epqAt][lane] = qa;
-                            meta[epqAt + 1][lane] = qb;
-                            meta[epqAt + 2][lane] = qc;
+                            epq[epqAt * 64] = qa;
+                            epq[(epqAt + 1) * 64] = qb;
+                            epq[(epqAt + 2) * 64] = qc;
                             const bool groupAllSame = (metaRound > 0) && (groupBits(__ballot(anySame), lane) == 0xffu);
                             if (groupAllSame)
                             {
@@ -483,7 +508,7 @@ __global__ __launch_bounds__(64) void cvttmi_bc6h_kernel(const uint8_t *__restri
                                             }
                                             else
                                             {
-                                                const float d = twosCLHalfToFloat(rec) - twosCLHalfToFloat(orig[ch]);
+                                                const float d = twosCLHalfToFloat<SIGNED>(rec) - twosCLHalfToFloat<SIGNED>(orig[ch]);
                                                 sq = d * d;
                                             }
                                             err = uniformErr ? (err + sq) : (err + sq * A.wSq[ch]);
@@ -533,9 +558,9 @@ __global__ __launch_bounds__(64) void cvttmi_bc6h_kernel(const uint8_t *__restri
                         // quantised endpoints of the two rounds
                         int e0[2][3], e1[2][3];
                         {
-                            const int at0 = kEpqBase + (meta0 * 2 + 0) * 3, at1 = kEpqBase + (meta1 * 2 + 1) * 3;
-                            const u32 a0 = meta[at0][lane], b0 = meta[at0 + 1][lane], c0 = meta[at0 + 2][lane];
-                            const u32 a1 = meta[at1][lane], b1 = meta[at1 + 1][lane], c1 = meta[at1 + 2][lane];
+                            const int at0 = (meta0 * 2 + 0) * 3, at1 = (meta1 * 2 + 1) * 3;
+                            const u32 a0 = epq[at0 * 64], b0 = epq[(at0 + 1) * 64], c0 = epq[(at0 + 2) * 64];
+                            const u32 a1 = epq[at1 * 64], b1 = epq[(at1 + 1) * 64], c1 = epq[(at1 + 2) * 64];
                             e0[0][0] = (int)(short)(a0 & 0xffffu); e0[0][1] = (int)(short)(a0 >> 16); e0[0][2] = (int)(short)(b0 & 0xffffu);
                             e0[1][0] = (int)(short)(b0 >> 16); e0[1][1] = (int)(short)(c0 & 0xffffu); e0[1][2] = (int)(short)(c0 >> 16);
                             e1[0][0] = (int)(short)(a1 & 0xffffu); e1[0][1] = (int)(short)(a1 >> 16); e1[0][2] = (int)(short)(b1 & 0xffffu);
@@ -687,14 +712,19 @@ __global__ __launch_bounds__(64) void cvttmi_bc6h_kernel(const uint8_t *__restri
     }
 }
 
+extern "C" size_t cvttmi_bc6h_scratch_bytes(uint32_t numBlocks)
+{
+    return (size_t)((numBlocks + 63u) / 64u) * kEpqDwords * 64 * sizeof(u32);
+}
+
 extern "C" hipError_t cvttmi_launch_bc6h(const void *d_blocks, void *d_out, const CvttBc6hArgs *args,
-                                         const CvttDeviceTables *d_tables, int isSigned, hipStream_t stream)
+                                         const CvttDeviceTables *d_tables, int isSigned, void *d_scratch, hipStream_t stream)
 {
     const uint32_t waves = (args->numBlocks + 63u) / 64u;
     if (waves == 0)
         return hipSuccess;
     const bool fast = (args->flags & CVTTMI_FLAG_BC6H_FAST_INDEXING) != 0;
-#define CVTT_LAUNCH(S, Fq) hipLaunchKernelGGL((cvttmi_bc6h_kernel<S, Fq>), dim3(waves), dim3(64), 0, stream, (const uint8_t *)d_blocks, (uint8_t *)d_out, *args, d_tables)
+#define CVTT_LAUNCH(S, Fq) hipLaunchKernelGGL((cvttmi_bc6h_kernel<S, Fq>), dim3(waves), dim3(64), 0, stream, (const uint8_t *)d_blocks, (uint8_t *)d_out, *args, d_tables, (u32 *)d_scratch)
     if (isSigned)
     {
         if (fast) CVTT_LAUNCH(true, true); else CVTT_LAUNCH(true, false);

@@ -27,7 +27,8 @@ extern "C" hipError_t cvttmi_launch_bc1(const void *d_blocks, void *d_out, const
                                         const CvttDeviceTables *d_tables, hipStream_t stream);
 
 extern "C" hipError_t cvttmi_launch_bc6h(const void *d_blocks, void *d_out, const CvttBc6hArgs *args,
-                                         const CvttDeviceTables *d_tables, int isSigned, hipStream_t stream);
+                                         const CvttDeviceTables *d_tables, int isSigned, void *d_scratch, hipStream_t stream);
+extern "C" size_t cvttmi_bc6h_scratch_bytes(uint32_t numBlocks);
 
 static_assert(sizeof(cvttmi_options) == 44, "cvtt::Options layout");
 static_assert(sizeof(cvttmi_bc7_plan) == 808, "cvtt::BC7EncodingPlan layout");
@@ -52,6 +53,8 @@ struct cvttmi_context
     void *dOut;
     size_t dInBytes, dOutBytes;
     hipStream_t stream;
+    void *dScratch;       // kernel work space (BC6H endpoint history), grown on demand
+    size_t dScratchBytes;
     bool exhaustive; // search every candidate even when it provably cannot win
     // timing
     bool timing;
@@ -297,6 +300,8 @@ extern "C"
         ctx->pinnedIn = ctx->pinnedOut = ctx->dIn = ctx->dOut = NULL;
         ctx->pinnedInBytes = ctx->pinnedOutBytes = ctx->dInBytes = ctx->dOutBytes = 0;
         ctx->stream = NULL;
+        ctx->dScratch = NULL;
+        ctx->dScratchBytes = 0;
         ctx->timing = false;
         ctx->exhaustive = getenv("CVTTMI_EXHAUSTIVE") != NULL && atoi(getenv("CVTTMI_EXHAUSTIVE")) != 0;
         ctx->totalMs = 0.0;
@@ -332,6 +337,7 @@ extern "C"
         if (ctx->pinnedOut) hipHostFree(ctx->pinnedOut);
         if (ctx->dIn) hipFree(ctx->dIn);
         if (ctx->dOut) hipFree(ctx->dOut);
+        if (ctx->dScratch) hipFree(ctx->dScratch);
         if (ctx->stream) hipStreamDestroy(ctx->stream);
         hipEventDestroy(ctx->evStart);
         hipEventDestroy(ctx->evStop);
@@ -462,12 +468,34 @@ extern "C"
         args.flags = options->flags;
         args.refineRounds = options->refineRoundsBC6H;
         args.seedPoints = options->seedPoints;
-        args.numBlocks = static_cast<uint32_t>(numBlocks);
+        // the endpoint-history scratch is sized for one launch; large batches go in chunks of
+        // 2^18 blocks (75 MB of scratch) on the same stream
+        const size_t kChunk = 1u << 18;
+        const size_t need = cvttmi_bc6h_scratch_bytes(static_cast<uint32_t>(numBlocks < kChunk ? numBlocks : kChunk));
+        if (ctx->dScratchBytes < need)
+        {
+            if (ctx->dScratch)
+            {
+                hipDeviceSynchronize();
+                hipFree(ctx->dScratch);
+                ctx->dScratch = NULL;
+                ctx->dScratchBytes = 0;
+            }
+            if ((e = hipMalloc(&ctx->dScratch, need)) != hipSuccess)
+                return fail(ctx, CVTTMI_E_HIP, "hipMalloc(scratch)", e);
+            ctx->dScratchBytes = need;
+        }
         if (ctx->timing)
             hipEventRecord(ctx->evStart, stream);
-        e = cvttmi_launch_bc6h(d_blocks, d_out, &args, ctx->dTables, isSigned, stream);
-        if (e != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "bc6h kernel launch", e);
+        for (size_t first = 0; first < numBlocks; first += kChunk)
+        {
+            const size_t n = (numBlocks - first) < kChunk ? (numBlocks - first) : kChunk;
+            args.numBlocks = static_cast<uint32_t>(n);
+            e = cvttmi_launch_bc6h(static_cast<const uint8_t *>(d_blocks) + first * 128, static_cast<uint8_t *>(d_out) + first * 16,
+                                   &args, ctx->dTables, isSigned, ctx->dScratch, stream);
+            if (e != hipSuccess)
+                return fail(ctx, CVTTMI_E_HIP, "bc6h kernel launch", e);
+        }
         if (ctx->timing)
         {
             hipEventRecord(ctx->evStop, stream);

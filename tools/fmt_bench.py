@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Kernel timing of one format on synthetic BASELINE-style input (developer tool, GPU box).
+   python tools/fmt_bench.py bc7|bc7o|bc1|bc6hu|bc6hs [size] [reps]"""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from convectionkernels_amd import api, synth
+
+fmt = sys.argv[1]
+size = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+ctx = api.Context(0)
+if fmt in ("bc7", "bc7o", "bc1"):
+    b = synth.tile_blocks(synth.image_rgba8(2, size, size, opaque=(fmt == "bc7o")))
+else:
+    b = synth.tile_blocks(synth.image_f16bits(3, size, size))
+t = torch.from_numpy(b).cuda()
+enc = {"bc7": ctx.encode_bc7, "bc7o": ctx.encode_bc7, "bc1": ctx.encode_bc1,
+       "bc6hu": lambda x, out=None: ctx.encode_bc6h(x, signed=False, out=out),
+       "bc6hs": lambda x, out=None: ctx.encode_bc6h(x, signed=True, out=out)}[fmt]
+o = enc(t); torch.cuda.synchronize()
+ms = []
+for _ in range(reps):
+    a = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    a.record(); enc(t, out=o); e.record(); torch.cuda.synchronize(); ms.append(a.elapsed_time(e))
+print(json.dumps({"fmt": fmt, "size": size, "blocks": int(b.shape[0]), "ms": min(ms), "mblocks_s": b.shape[0] / min(ms) / 1e3}))
