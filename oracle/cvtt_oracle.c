@@ -1408,3 +1408,4 @@ int orc_encode_bc7(uint8_t *out, const uint8_t *blocks, size_t numBlocks, const 
 
 #include "cvtt_oracle_bc1.inc"
 #include "cvtt_oracle_bc6h.inc"
+#include "cvtt_oracle_etc2.inc"

@@ -78,6 +78,10 @@ int orc_encode_bc1(uint8_t *out, const uint8_t *blocks, size_t numBlocks,
 int orc_encode_bc6h(uint8_t *out, const uint8_t *blocksF16, size_t numBlocks,
                     const orc_options *options, int isSigned, const float *rcp17, int threads);
 
+/* mode 0: ETC2 RGB (8 B/block), 1: ETC2 RGBA = [EAC alpha | colour] (16 B/block), 2: EAC alpha (8 B/block) */
+int orc_encode_etc2(uint8_t *out, const uint8_t *blocks, size_t numBlocks,
+                    const orc_options *options, int mode, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -160,6 +160,7 @@ class OracleLib:
         L.orc_encode_bc7.restype = ctypes.c_int
         L.orc_encode_bc1.restype = ctypes.c_int
         L.orc_encode_bc6h.restype = ctypes.c_int
+        L.orc_encode_etc2.restype = ctypes.c_int
 
     def probe_rcp(self):
         out = np.zeros(17, np.float32)
@@ -197,6 +198,19 @@ class OracleLib:
         if rc != 0:
             raise RuntimeError("orc_encode_bc6h rc=%d" % rc)
         return out.reshape(n, 16)
+
+    def encode_etc2(self, blocks, options, mode, threads=1):
+        """mode 0: RGB (8 B), 1: RGBA (16 B), 2: EAC alpha (8 B)."""
+        blocks, pb = _u8(blocks)
+        n = blocks.size // 64
+        assert n % 8 == 0
+        per = 16 if mode == 1 else 8
+        out = np.zeros(n * per, np.uint8)
+        rc = self.lib.orc_encode_etc2(out.ctypes.data_as(ctypes.c_void_p), pb, ctypes.c_size_t(n),
+                                      options.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(mode), ctypes.c_int(threads))
+        if rc != 0:
+            raise RuntimeError("orc_encode_etc2 rc=%d" % rc)
+        return out.reshape(n, per)
 
     def encode_bc1(self, blocks, options, rcp=None, threads=1):
         blocks, pb = _u8(blocks)

@@ -113,6 +113,19 @@ def main():
         b6["outs_" + name] = ref.encode_bc6h(hdrs, o, True)
     np.savez_compressed(os.path.join(HERE, "bc6h_mixed.npz"), **b6)
 
+    # ---- ETC2 (canonical -O1 build): mixed content + config-4 image x option variants x modes ----
+    etc_blocks = np.concatenate([content.mixed_ldr_blocks(404, 24), content.config_blocks(4, 64, 64)])
+    e2 = {"blocks": etc_blocks}
+    for name, o in {
+        "default": P.make_options(),
+        "uniform": P.make_options(flags=P.FLAGS_DEFAULT | P.FLAG_UNIFORM),
+        "weights": P.make_options(weights=(0.5, 1.0, 0.25, 2.0)),
+    }.items():
+        e2["opt_" + name] = o
+        for mode, tag in ((0, "rgb"), (1, "rgba"), (2, "alpha")):
+            e2["out_%s_%s" % (tag, name)] = ref.encode_etc2(etc_blocks, o, mode)
+    np.savez_compressed(os.path.join(HERE, "etc2_mixed.npz"), **e2)
+
     # ---- known answers (App. H) ----
     ka = content.known_answer_group_ldr()
     opt = pyref.make_options()

@@ -1,0 +1,49 @@
+"""ETC2 RGB / RGBA / EAC alpha: oracle vs golden vectors / reference on CPU; HIP path on GPU."""
+import os
+
+import numpy as np
+import pytest
+
+import content
+from oracle import pyref
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+NAMES = ["default", "uniform", "weights"]
+MODES = [(0, "rgb"), (1, "rgba"), (2, "alpha")]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_golden(oracle_lib, name):
+    g = np.load(os.path.join(GOLD, "etc2_mixed.npz"))
+    for mode, tag in MODES:
+        out = oracle_lib.encode_etc2(g["blocks"], g["opt_" + name], mode, threads=8)
+        bad = np.nonzero((out != g["out_%s_%s" % (tag, name)]).any(axis=1))[0]
+        assert bad.size == 0, (tag, bad[:8])
+
+
+def test_oracle_known_answers(oracle_lib):
+    g = np.load(os.path.join(GOLD, "known_answers.npz"))
+    out = oracle_lib.encode_etc2(g["blocks"], pyref.make_options(), 1)
+    assert (out == g["etc2rgba"]).all()
+    assert out[0].tobytes().hex() == "93bac95c23f747d33107ad56df223d0a"
+    assert out[7].tobytes().hex() == "ff1092492492492425f963c745d519f7"
+
+
+def test_oracle_vs_reference(oracle_lib, ref_lib):
+    blocks = np.concatenate([content.mixed_ldr_blocks(5150, 24), content.config_blocks(4, 32, 32)])
+    for opt in (pyref.make_options(), pyref.make_options(flags=pyref.FLAG_UNIFORM)):
+        for mode, _ in MODES:
+            assert (oracle_lib.encode_etc2(blocks, opt, mode, 8) == ref_lib.encode_etc2(blocks, opt, mode)).all()
+
+
+def test_oracle_rejects_fake_bt709(oracle_lib):
+    with pytest.raises(RuntimeError):
+        oracle_lib.encode_etc2(np.zeros((8, 16, 4), np.uint8), pyref.make_options(flags=0x400), 0)
+
+
+def test_t_mode_group_coupling(oracle_lib):
+    """hazard H2: a block's T-mode candidates depend on the unique-colour count of its group
+    (SURVEY App. B); encoding must therefore take whole groups"""
+    blocks = content.mixed_ldr_blocks(8, 12)
+    out = oracle_lib.encode_etc2(blocks, pyref.make_options(), 0, 4)
+    assert out.shape == (96, 8)
