@@ -150,6 +150,8 @@ _EXPORTS = (
     "cvttmi_encode_bc7_device", "cvttmi_encode_bc7", "cvttmi_timing_enable", "cvttmi_timing_read",
     "cvttmi_set_exhaustive", "cvttmi_encode_bc1_device", "cvttmi_encode_bc1",
     "cvttmi_encode_bc6h_device", "cvttmi_encode_bc6h",
+    "cvttmi_encode_etc2_device", "cvttmi_encode_etc2_rgba_device", "cvttmi_encode_etc2_alpha_device",
+    "cvttmi_encode_etc2", "cvttmi_encode_etc2_rgba", "cvttmi_encode_etc2_alpha",
 )
 
 _lib = None
@@ -185,6 +187,10 @@ def load_library():
                                               ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     lib.cvttmi_encode_bc6h.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                        ctypes.c_void_p, ctypes.c_int]
+    for n in ("cvttmi_encode_etc2", "cvttmi_encode_etc2_rgba", "cvttmi_encode_etc2_alpha"):
+        getattr(lib, n).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        getattr(lib, n + "_device").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                                 ctypes.c_void_p, ctypes.c_void_p]
     lib.cvttmi_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_set_exhaustive.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_timing_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
@@ -322,6 +328,23 @@ class Context:
         return self._encode_simple(host, dev, "encode_bc6h", blocks, options, out, stream, 128, 16)
 
 
+    # -- ETC2 --
+    def encode_etc2(self, blocks, options=None, out=None, stream=None):
+        """Batched cvtt::Kernels::EncodeETC2 (RGB): (N,16,4) uint8 -> (N,8) uint8."""
+        return self._encode_simple(self._lib.cvttmi_encode_etc2, self._lib.cvttmi_encode_etc2_device, "encode_etc2",
+                                   blocks, options, out, stream, 64, 8)
+
+    def encode_etc2_rgba(self, blocks, options=None, out=None, stream=None):
+        """Batched cvtt::Kernels::EncodeETC2RGBA: (N,16,4) uint8 -> (N,16) uint8 = [EAC alpha | colour]."""
+        return self._encode_simple(self._lib.cvttmi_encode_etc2_rgba, self._lib.cvttmi_encode_etc2_rgba_device,
+                                   "encode_etc2_rgba", blocks, options, out, stream, 64, 16)
+
+    def encode_etc2_alpha(self, blocks, options=None, out=None, stream=None):
+        """Batched cvtt::Kernels::EncodeETC2Alpha (EAC 8-bit): (N,16,4) uint8 -> (N,8) uint8."""
+        return self._encode_simple(self._lib.cvttmi_encode_etc2_alpha, self._lib.cvttmi_encode_etc2_alpha_device,
+                                   "encode_etc2_alpha", blocks, options, out, stream, 64, 8)
+
+
 _default_ctx = {}
 
 
@@ -351,3 +374,19 @@ def EncodeBC6HU(pBlocks, options=None, device=0):
 def EncodeBC6HS(pBlocks, options=None, device=0):
     """cvtt::Kernels::EncodeBC6HS (reference ConvectionKernels_API.cpp:71-84)."""
     return default_context(device).encode_bc6h(pBlocks, options, signed=True)
+
+
+def EncodeETC2(pBlocks, options=None, compressionData=None, device=0):
+    """cvtt::Kernels::EncodeETC2 (reference ConvectionKernels_API.cpp:216-229); the reference's
+    ETC2CompressionData scratch argument is accepted and ignored (scratch lives in LDS)."""
+    return default_context(device).encode_etc2(pBlocks, options)
+
+
+def EncodeETC2RGBA(pBlocks, options=None, compressionData=None, device=0):
+    """cvtt::Kernels::EncodeETC2RGBA (reference ConvectionKernels_API.cpp:270-286)."""
+    return default_context(device).encode_etc2_rgba(pBlocks, options)
+
+
+def EncodeETC2Alpha(pBlocks, options=None, device=0):
+    """cvtt::Kernels::EncodeETC2Alpha (reference ConvectionKernels_API.cpp:246-256)."""
+    return default_context(device).encode_etc2_alpha(pBlocks, options)

@@ -26,6 +26,14 @@ struct CvttDeviceTables
     // and header bit layout (field*16+bit; tools/gen_bc6h_layout.py)
     uint8_t bc6hModeInfo[14][8];
     uint8_t bc6hLayout[14][82];
+    // ETC1 / ETC2 / EAC tables (tools/gen_etc_tables.py)
+    int16_t etc1Modifiers[8][4];   // {-large, -small, +small, +large}
+    int16_t thDistance[8];
+    uint8_t eacPositive[16][4];
+    uint8_t eacRounding[16][13];
+    uint8_t clusterCount[8];
+    uint16_t clusterStart[8];
+    int16_t clusterOffsets[632];
 };
 
 // The caller's plan plus two bitmaps derived on the host: which shapes the plan's
@@ -77,6 +85,19 @@ struct CvttBc6hArgs
     int32_t refineRounds; // Options::refineRoundsBC6H (clamped to 1..3 by the kernel)
     int32_t seedPoints;   // Options::seedPoints (clamped to 1..4)
     uint32_t numBlocks;
+};
+
+// ETC2 / EAC per-launch parameters.
+struct CvttEtcArgs
+{
+    float rw, gw, bw;   // Options weights, used directly (reference ETC.cpp:73-80, 2150-2152)
+    float axis0[3];     // chroma-plane axes of ETC2CompressionDataInternal (reference ETC.cpp:3117-3145)
+    float axis1[3];
+    uint32_t flags;
+    uint32_t numBlocks;
+    uint32_t outStride; // bytes between consecutive output blocks (8, or 16 for RGBA)
+    uint32_t outOffset; // byte offset of this kernel's 8 bytes inside the output block
+    uint64_t debug;     // developer builds (-DCVTT_ETC_DEBUG): device pointer for per-stage errors, else 0
 };
 
 #endif

@@ -1,0 +1,1147 @@
+// ETC2 RGB / RGBA (EAC alpha) encoders for gfx950.
+//
+// Replaces cvtt::Internal::ETCComputer::CompressETC2Block (punchthroughAlpha = false) and
+// CompressETC2AlphaBlock as reached from cvtt::Kernels::EncodeETC2 / EncodeETC2RGBA /
+// EncodeETC2Alpha (reference ConvectionKernels_API.cpp:216-229, 246-256, 270-286;
+// ConvectionKernels_ETC.cpp: EncodePlanar 1274-1662, sector split 1723-1848, EncodeTMode 396-647,
+// EncodeHMode 649-885, CompressETC1BlockInternal 2624-2882 (differential only), TestHalfBlock
+// 94-149, FindBestDifferentialCombination 219-362, emitters 2414-2622, alpha 1902-2085,
+// 2366-2411).  Bit-identical to the reference's SSE2 lanes in its canonical build (SURVEY App. C,
+// hazard H2: the T-mode candidate slot just past a lane's unique colours reads as zero).
+//
+// Colour kernel mapping: one WORKGROUP (8 waves) = one reference group of 8 blocks, one WAVE =
+// one block, one LANE = one candidate (a T-mode line colour, an H-mode colour pair, an ETC1
+// half-block base colour, a planar coefficient combination).  Every candidate is evaluated over
+// its pixels sequentially in registers (the reference's float sums are order dependent); the
+// wave then reduces (error, candidate id) with ties going to the lowest id, which is the first
+// candidate the reference's strict '<' would have kept.  Pixels, candidate lists and the
+// differential attempt lists live in LDS; the only cross-block exchange is the group maximum of
+// the T-mode unique-colour counts (one __syncthreads per T-mode call).
+// Alpha kernel: integer-only and lane independent, one lane per block.
+#include "cvtt_kernel_common.h"
+
+namespace
+{
+#define WAVE_SYNC()                                          \
+    do                                                       \
+    {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+    } while (0)
+
+constexpr int kMaxAttempts = 624; // 57 + 7 * 81 (reference ETC.h:38)
+
+struct EtcWaveShared
+{
+    int pix[16][4];   // r, g, b, unused
+    float pw[16][4];  // pre-weighted pixels (ExtractBlocks, ETC.cpp:2128-2155)
+    float isoErr[16]; // T mode: error of the isolated colour per pixel
+    unsigned short tColors[8][36];
+    int tCount[8];
+    union
+    {
+        struct
+        {
+            float err[36][16];       // H mode: min error of colour ci +/- modifier per pixel
+            unsigned short color[2][36];
+            unsigned short sign[36];
+        } h;
+        struct
+        {
+            float err[2][kMaxAttempts];  // ETC1 differential attempts per half block
+            u32 packed[2][kMaxAttempts]; // selectors | colour << 16
+        } a;
+    } u;
+    unsigned short dColors[16][82];      // de-duplicated base colours per (sector, table)
+    int dCount[16];
+    int planarRange[3][3][2];
+};
+
+__device__ __forceinline__ int udivSmall(int n, int d)
+{
+    // exact n / d for 0 <= n < 2^16, 0 < d < 2^12 (integer divisions of ETC.cpp:446, 546, 717)
+    int q = (int)((float)n * __frcp_rn((float)d));
+    const int r = n - q * d;
+    if (r < 0) q--;
+    if (r >= d) q++;
+    return q;
+}
+
+__device__ __forceinline__ u32 bswap32(u32 v) { return __builtin_bswap32(v); }
+
+// wave-wide argmin of (err, id); ties -> lowest id.  All lanes receive the winner.
+__device__ __forceinline__ void waveArgmin(float &err, int &id)
+{
+#pragma unroll
+    for (int step = 1; step < 64; step <<= 1)
+    {
+        const float oe = __shfl_xor(err, step);
+        const int oi = __shfl_xor(id, step);
+        const bool take = (oe < err) || (oe == err && oi < id);
+        err = take ? oe : err;
+        id = take ? oi : id;
+    }
+}
+
+struct EtcErr
+{
+    bool uniform;
+    float rw, gw, bw;
+    // ComputeErrorUniform / ComputeErrorWeighted, ETC.cpp:59-80
+    __device__ __forceinline__ float operator()(int r, int g, int b, const int *px, const float *pw) const
+    {
+        if (uniform)
+        {
+            const float d0 = (float)(r - px[0]), d1 = (float)(g - px[1]), d2 = (float)(b - px[2]);
+            float e = d0 * d0;
+            e = e + d1 * d1;
+            e = e + d2 * d2;
+            return e;
+        }
+        const float dr = (float)r * rw - pw[0];
+        const float dg = (float)g * gw - pw[1];
+        const float db = (float)b * bw - pw[2];
+        return dr * dr + dg * dg + db * db;
+    }
+};
+
+__device__ __forceinline__ int planarDecode(int coeff, int ch)
+{
+    return (ch == 1) ? (((coeff << 1) | (coeff >> 6)) & 0xffff) : (((coeff << 2) | (coeff >> 4)) & 0xffff);
+}
+
+// EmitTModeBlock, ETC.cpp:2414-2460
+__device__ __forceinline__ void emitT(u32 &hi, u32 &lo, const int (&lineColor)[3], const int (&iso)[3], u32 packedSelectors, int table)
+{
+    hi = 0;
+    lo = 0;
+    const int rh = (iso[0] >> 2) & 3, rl = iso[0] & 3;
+    if (rh + rl < 4) hi |= 1u << (58 - 32); else hi |= 7u << (61 - 32);
+    hi |= (u32)rh << (59 - 32);
+    hi |= (u32)rl << (56 - 32);
+    hi |= (u32)iso[1] << (52 - 32);
+    hi |= (u32)iso[2] << (48 - 32);
+    hi |= (u32)lineColor[0] << (44 - 32);
+    hi |= (u32)lineColor[1] << (40 - 32);
+    hi |= (u32)lineColor[2] << (36 - 32);
+    hi |= (u32)((table >> 1) & 3) << (34 - 32);
+    hi |= 1u << (33 - 32);
+    hi |= (u32)(table & 1);
+#pragma unroll
+    for (int px = 0; px < 16; px++)
+    {
+        const int src = ((px & 3) << 2) | (px >> 2); // selectorOrder
+        const u32 sel = (packedSelectors >> (2 * src)) & 3u;
+        lo |= (sel & 1u) << px;
+        lo |= ((sel >> 1) & 1u) << (16 + px);
+    }
+}
+} // namespace
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+                                                               const CvttEtcArgs A, const CvttDeviceTables *__restrict__ T)
+{
+    __shared__ EtcWaveShared shared[8];
+    __shared__ int groupTCount[8][8];
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const u32 blockIndex = blockIdx.x * 8u + (u32)wave;
+    EtcWaveShared &S = shared[wave];
+    const EtcErr E = {(A.flags & CVTTMI_FLAG_UNIFORM) != 0, A.rw, A.gw, A.bw};
+
+    // ---- load: pixel px by lane px ----
+    if (lane < 16)
+    {
+        const u32 pk = reinterpret_cast<const u32 *>(blocks + (size_t)blockIndex * 64u)[lane];
+        const int r = (int)(pk & 0xffu), g = (int)((pk >> 8) & 0xffu), b = (int)((pk >> 16) & 0xffu);
+        S.pix[lane][0] = r;
+        S.pix[lane][1] = g;
+        S.pix[lane][2] = b;
+        S.pw[lane][0] = E.uniform ? (float)r : (float)r * A.rw;
+        S.pw[lane][1] = E.uniform ? (float)g : (float)g * A.gw;
+        S.pw[lane][2] = E.uniform ? (float)b : (float)b * A.bw;
+    }
+    WAVE_SYNC();
+
+    float bestError = FLT_MAX;
+    u32 outHi = 0, outLo = 0;
+#ifdef CVTT_ETC_DEBUG
+    float *dbg = reinterpret_cast<float *>(A.debug) + (size_t)blockIndex * 8;
+#define DBG_TAP(i) do { if (lane == 0 && A.debug) dbg[i] = bestError; } while (0)
+#else
+#define DBG_TAP(i) do {} while (0)
+#endif
+
+    // =================================== planar ===================================
+    {
+        // closed-form least squares per channel (lanes 0..2), ETC.cpp:1291-1413
+        const int ch = lane < 3 ? lane : 0;
+        float fhh = 0.f, fho = 0.f, fhv = 0.f, foo = 0.f, fov = 0.f, fvv = 0.f;
+        float fh = 0.0f, fv = 0.0f, fo = 0.0f;
+        for (int px = 0; px < 16; px++)
+        {
+            const float x = (float)(px & 3), y = (float)(px >> 2);
+            const float c = (float)S.pix[px][ch];
+            fhh += x * x; fhv += x * y; fho += x; fh = fh - c * x;
+            fhv += y * x; fvv += y * y; fov += y; fv = fv - c * y;
+            fho += x; fov += y; foo += 1.0f; fo = fo - c;
+            fh = fh - c * x; fv = fv - c * y; fo = fo - c;
+        }
+        const float d = 2.0f * fhh, e = fho, f = fhv, gD = fh;
+        const float i = fhv, j = fov, k = 2.0f * fvv, lD = fv;
+        const float m = fho, n = 2.0f * foo, p = fov, qD = fo;
+        const float r0to1 = -i / d, r0to2 = -m / d;
+        const float j1 = j + r0to1 * e, k1 = k + r0to1 * f, l1D = lD + gD * r0to1;
+        const float n1 = n + r0to2 * e, p1 = p + r0to2 * f, q1D = qD + gD * r0to2;
+        const float r1to2 = -p1 / k1;
+        const float n2 = n1 + r1to2 * j1, q2D = q1D + l1D * r1to2;
+        const float oc = -q2D / n2;
+        const float r2to1 = -j1 / n2;
+        const float l2D = l1D + q2D * r2to1;
+        const float elim2 = -f / k1, elim1 = -e / n2;
+        const float g2D = gD + l2D * elim2 + q2D * elim1;
+        float hc = -g2D / d, vc = -l2D / k1;
+        hc = hc * 4.0f + oc;
+        vc = vc * 4.0f + oc;
+        if (lane < 3)
+        {
+            const float fcoeffs[3] = {oc, hc, vc};
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+            {
+                float coeff = sseMax(0.0f, fcoeffs[c]);
+                coeff = (ch == 1) ? sseMin(127.0f, coeff * (127.0f / 255.0f)) : sseMin(63.0f, coeff * (63.0f / 255.0f));
+                S.planarRange[ch][c][0] = (int)floorf(coeff); // RoundDownForScope
+                S.planarRange[ch][c][1] = (int)ceilf(coeff);  // RoundUpForScope
+            }
+        }
+        WAVE_SYNC();
+
+        // the 8 floor/ceil combinations per channel: lanes 0..23 (ETC.cpp:1507-1552)
+        const int pch = (lane >> 3) < 3 ? (lane >> 3) : 0;
+        const int combo = lane & 7;
+        const int cO = S.planarRange[pch][0][(combo >> 2) & 1];
+        const int cH = S.planarRange[pch][1][(combo >> 1) & 1];
+        const int cV = S.planarRange[pch][2][combo & 1];
+        float error = 0.0f;
+        {
+            const int dO = planarDecode(cO, pch), dH = planarDecode(cH, pch), dV = planarDecode(cV, pch);
+            const int hMinusO = (int)(short)(dH - dO), vMinusO = (int)(short)(dV - dO);
+            const int addend = (int)(short)((dO << 2) + 2);
+            for (int px = 0; px < 16; px++)
+            {
+                const int x = px & 3, y = px >> 2;
+                int dec = (int)(short)(x * hMinusO + y * vMinusO + addend) >> 2;
+                dec = dec < 0 ? 0 : (dec > 255 ? 255 : dec);
+                const float deltaF = (float)(S.pix[px][pch] - dec);
+                error = error + deltaF * deltaF;
+            }
+        }
+        // argmin over the 8 lanes of a channel, ties -> lowest combination
+        float cErr = lane < 24 ? error : FLT_MAX;
+        int cId = combo;
+#pragma unroll
+        for (int step = 1; step < 8; step <<= 1)
+        {
+            const float oe = __shfl_xor(cErr, step);
+            const int oi = __shfl_xor(cId, step);
+            const bool take = (oe < cErr) || (oe == cErr && oi < cId);
+            cErr = take ? oe : cErr;
+            cId = take ? oi : cId;
+        }
+        float chErr[3];
+        int coeffs[3][3];
+#pragma unroll
+        for (int c3 = 0; c3 < 3; c3++)
+        {
+            const float eBest = __shfl(cErr, c3 * 8);
+            const int win = __shfl(cId, c3 * 8);
+            // bestChannelError starts at FLT_MAX and is replaced on a strict '<'
+            chErr[c3] = eBest < FLT_MAX ? eBest : FLT_MAX;
+            coeffs[c3][0] = S.planarRange[c3][0][(win >> 2) & 1];
+            coeffs[c3][1] = S.planarRange[c3][1][(win >> 1) & 1];
+            coeffs[c3][2] = S.planarRange[c3][2][win & 1];
+            if (!E.uniform)
+            {
+                const float w = c3 == 0 ? A.rw : (c3 == 1 ? A.gw : A.bw);
+                chErr[c3] = chErr[c3] * (w * w);
+            }
+        }
+        float totalError = 0.0f;
+        totalError = totalError + chErr[0];
+        totalError = totalError + chErr[1];
+        totalError = totalError + chErr[2];
+        if (totalError < bestError)
+        {
+            bestError = totalError;
+            const int ro = coeffs[0][0], rh = coeffs[0][1], rv = coeffs[0][2];
+            const int go = coeffs[1][0], gh = coeffs[1][1], gv = coeffs[1][2];
+            const int bo = coeffs[2][0], bh = coeffs[2][1], bv = coeffs[2][2];
+            const int go1 = go >> 6, go2 = go & 63;
+            const int bo1 = bo >> 5, bo2 = (bo >> 3) & 3, bo3 = bo & 7;
+            const int rh1 = rh >> 1, rh2 = rh & 1;
+            const int fakeR = ro >> 2, fakeDR = go1 | ((ro & 3) << 1);
+            const int fakeG = go2 >> 2, fakeDG = ((go2 & 3) << 1) | bo1;
+            const int fakeB = bo2, fakeDB = bo3 >> 1;
+            u32 hi = 0, lo = 0;
+            if ((fakeDR & 4) != 0 && fakeR + fakeDR < 8) hi |= 1u << (63 - 32);
+            if ((fakeDG & 4) != 0 && fakeG + fakeDG < 8) hi |= 1u << (55 - 32);
+            if (fakeB + fakeDB < 4) hi |= 1u << (42 - 32); else hi |= 7u << (45 - 32);
+            hi |= (u32)ro << (57 - 32);
+            hi |= (u32)go1 << (56 - 32);
+            hi |= (u32)go2 << (49 - 32);
+            hi |= (u32)bo1 << (48 - 32);
+            hi |= (u32)bo2 << (43 - 32);
+            hi |= (u32)bo3 << (39 - 32);
+            hi |= (u32)rh1 << (34 - 32);
+            hi |= 1u << (33 - 32);
+            hi |= (u32)rh2;
+            lo |= (u32)gh << 25;
+            lo |= (u32)bh << 19;
+            lo |= (u32)rv << 13;
+            lo |= (u32)gv << 6;
+            lo |= (u32)bv;
+            outHi = hi;
+            outLo = lo;
+        }
+    }
+
+    DBG_TAP(0);
+    // ============ sector split along the chroma principal axis (ETC.cpp:1723-1848) ============
+    u32 isolatedMask = 0; // bit px: pixel is "isolated" / sector 1
+    {
+        float cdx[16], cdy[16];
+        if (E.uniform)
+        {
+            int cenX = 0, cenY = 0;
+            int ccx[16], ccy[16];
+#pragma unroll
+            for (int px = 0; px < 16; px++)
+            {
+                ccx[px] = (int)(short)(S.pix[px][0] - S.pix[px][2]);
+                ccy[px] = (int)(short)(S.pix[px][0] - (S.pix[px][1] << 1) + S.pix[px][2]);
+                cenX = (int)(short)(cenX + ccx[px]);
+                cenY = (int)(short)(cenY + ccy[px]);
+            }
+#pragma unroll
+            for (int px = 0; px < 16; px++)
+            {
+                cdx[px] = (float)(int)(short)((int)(short)(ccx[px] << 4) - cenX);
+                cdy[px] = (float)(int)(short)((int)(short)(ccy[px] << 4) - cenY) * 0.57735026918962576450914878050196f;
+            }
+        }
+        else
+        {
+            float ccx[16], ccy[16], cenX = 0.0f, cenY = 0.0f;
+#pragma unroll
+            for (int px = 0; px < 16; px++)
+            {
+                const float p0 = S.pw[px][0], p1 = S.pw[px][1], p2 = S.pw[px][2];
+                ccx[px] = p0 * A.axis0[0] + p1 * A.axis0[1] + p2 * A.axis0[2];
+                ccy[px] = p0 * A.axis1[0] + p1 * A.axis1[1] + p2 * A.axis1[2];
+            }
+#pragma unroll
+            for (int px = 0; px < 16; px++)
+            {
+                cenX = cenX + ccx[px];
+                cenY = cenY + ccy[px];
+            }
+#pragma unroll
+            for (int px = 0; px < 16; px++)
+            {
+                cdx[px] = ccx[px] * 16.0f - cenX;
+                cdy[px] = ccy[px] * 16.0f - cenY;
+            }
+        }
+        float covXX = 0.0f, covYY = 0.0f, covXY = 0.0f;
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+        {
+            covXX = covXX + cdx[px] * cdx[px];
+            covYY = covYY + cdy[px] * cdy[px];
+            covXY = covXY + cdx[px] * cdy[px];
+        }
+        const float halfTrace = (covXX + covYY) * 0.5f;
+        const float det = covXX * covYY - covXY * covXY;
+        const float mm = __fsqrt_rn(sseMax(0.0f, halfTrace * halfTrace - det));
+        const float ev = halfTrace + mm;
+        float dx = (covYY - ev + covXY);
+        const float dy = -(covXX - ev + covXY);
+        if (dx == 0.0f && dy == 0.0f)
+            dx = 1.0f;
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+            if ((cdx[px] * dx + cdy[px] * dy) < 0.0f)
+                isolatedMask |= 1u << px;
+    }
+
+    // =================================== T mode x2 ===================================
+    for (int call = 0; call < 2; call++)
+    {
+        const u32 iso = call == 0 ? isolatedMask : (~isolatedMask & 0xffffu);
+        int isolatedTotal[3] = {0, 0, 0}, lineTotal[3] = {0, 0, 0};
+        const int numIsolated = __popc(iso);
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+            {
+                const int v = S.pix[px][ch];
+                lineTotal[ch] += v;
+                if ((iso >> px) & 1u)
+                    isolatedTotal[ch] += v;
+            }
+        const int numLine = 16 - numIsolated;
+        int isoQ[3], isoColor[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+        {
+            lineTotal[ch] -= isolatedTotal[ch];
+            const int numerator = isolatedTotal[ch] + isolatedTotal[ch] + ((numIsolated << 4) | numIsolated);
+            isoQ[ch] = numIsolated == 0 ? 0 : udivSmall(numerator, numIsolated * 34);
+            isoColor[ch] = isoQ[ch] | (isoQ[ch] << 4);
+        }
+        {
+            const int px = lane & 15;
+            S.isoErr[px] = E(isoColor[0], isoColor[1], isoColor[2], S.pix[px], S.pw[px]);
+        }
+        // unique line colours: lane = table (ETC.cpp:494-560)
+        if (lane < 8)
+        {
+            const int modifier = T->thDistance[lane];
+            const int modifierOffset = modifier + modifier;
+            const int lineDivisor = numLine * 34;
+            const int lineAddend = (numLine << 4) | numLine;
+            int n = 0, last = -1;
+            for (int k = -numLine; k <= numLine; k++)
+            {
+                const int modifierAddend = (int)(short)(k * modifierOffset);
+                int packed = 0;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    int numerator = (int)(short)((int)(short)(lineTotal[ch] + lineTotal[ch] + lineAddend) + modifierAddend);
+                    numerator = numerator < 0 ? 0 : numerator;
+                    const int divided = lineDivisor == 0 ? 0 : udivSmall(numerator, lineDivisor);
+                    packed |= (divided < 15 ? divided : 15) << (ch * 5);
+                }
+                if (n == 0 || packed != last)
+                {
+                    S.tColors[lane][n++] = (unsigned short)packed;
+                    last = packed;
+                }
+            }
+            S.tCount[lane] = n;
+            groupTCount[wave][lane] = n;
+        }
+        __syncthreads();
+        int gmax[8], prefix[9];
+        prefix[0] = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+        {
+            int mx = 0;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; w8++)
+                mx = groupTCount[w8][t] > mx ? groupTCount[w8][t] : mx;
+            gmax[t] = mx;
+            prefix[t + 1] = prefix[t] + mx;
+        }
+        __syncthreads();
+
+        float candErr = FLT_MAX;
+        int candId = 0x7fffffff;
+        u32 candSel = 0;
+        for (int base = 0; base < prefix[8]; base += 64)
+        {
+            const int id = base + lane;
+            if (id < prefix[8])
+            {
+                int table = 0;
+#pragma unroll
+                for (int t = 1; t < 8; t++)
+                    if (id >= prefix[t])
+                        table = t;
+                const int ci = id - prefix[table];
+                const int n = S.tCount[table];
+                // own colours, then (hazard H2) one zero slot, then copies of colour 0
+                const int packed = ci < n ? S.tColors[table][ci] : (ci == n ? 0 : S.tColors[table][0]);
+                const int modifier = T->thDistance[table];
+                int lc[3][3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    const int q = (packed >> (ch * 5)) & 15;
+                    const int u = (q << 4) | q;
+                    lc[0][ch] = u + modifier < 255 ? u + modifier : 255;
+                    lc[1][ch] = u;
+                    lc[2][ch] = u - modifier > 0 ? u - modifier : 0;
+                }
+                u32 selectors = 0;
+                float error = 0.0f;
+                for (int px = 0; px < 16; px++)
+                {
+                    float pixelError = S.isoErr[px];
+                    u32 sel = 0;
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+                    {
+                        const float e = E(lc[i][0], lc[i][1], lc[i][2], S.pix[px], S.pw[px]);
+                        if (e < pixelError)
+                            sel = (u32)(i + 1);
+                        pixelError = sseMin(e, pixelError);
+                    }
+                    error = error + pixelError;
+                    selectors |= sel << (px * 2);
+                }
+                if (error < candErr) // ids ascend per lane, strict '<' keeps the first
+                {
+                    candErr = error;
+                    candId = id;
+                    candSel = selectors;
+                }
+            }
+        }
+        float wErr = candErr;
+        int wId = candId;
+        waveArgmin(wErr, wId);
+        if (wErr < bestError)
+        {
+            bestError = wErr;
+            const int src = wId & 63; // candidate id -> owning lane
+            const u32 selectors = __shfl(candSel, src);
+            int table = 0;
+#pragma unroll
+            for (int t = 1; t < 8; t++)
+                if (wId >= prefix[t])
+                    table = t;
+            const int ci = wId - prefix[table];
+            const int n = S.tCount[table];
+            const int packed = ci < n ? S.tColors[table][ci] : (ci == n ? 0 : S.tColors[table][0]);
+            const int lineColor[3] = {packed & 15, (packed >> 5) & 15, (packed >> 10) & 15};
+            emitT(outHi, outLo, lineColor, isoQ, selectors, table);
+        }
+        DBG_TAP(1 + call);
+        WAVE_SYNC();
+    }
+
+    // =================================== H mode ===================================
+    // groupings = the flipped sector assignment (ETC.cpp:1855-1860)
+    {
+        const u32 grp = ~isolatedMask & 0xffffu;
+        int counts[2], totals[2][3] = {{0, 0, 0}, {0, 0, 0}};
+        counts[1] = __popc(grp);
+        counts[0] = 16 - counts[1];
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+            {
+                const int v = S.pix[px][ch];
+                totals[0][ch] += v;
+                if ((grp >> px) & 1u)
+                    totals[1][ch] += v;
+            }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+            totals[0][ch] -= totals[1][ch];
+
+        float hBestErr = FLT_MAX; // best H candidate so far (only committed if it beats bestError)
+        int hBestId = 0x7fffffff;
+        u32 hBestBits = 0;        // sectorBits | signBits << 16
+        int hBestC0 = 0, hBestC1 = 0;
+
+        for (int table = 0; table < 8; table++)
+        {
+            const int modifier = T->thDistance[table];
+            // unique colours per sector: lane = sector (ETC.cpp:691-737)
+            if (lane < 2)
+            {
+                const int cnt = lane == 0 ? counts[0] : counts[1];
+                const int t0 = lane == 0 ? totals[0][0] : totals[1][0];
+                const int t1 = lane == 0 ? totals[0][1] : totals[1][1];
+                const int t2 = lane == 0 ? totals[0][2] : totals[1][2];
+                int n = 0, last = -1;
+                for (int k = -cnt; k <= cnt; k++)
+                {
+                    int q[3];
+                    const int tt[3] = {t0, t1, t2};
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                    {
+                        if (cnt == 0)
+                            q[ch] = 0;
+                        else
+                        {
+                            int v = (int)(short)(tt[ch] * 2 + cnt * 17 + modifier * 2 * k);
+                            v = v < 0 ? 0 : v;
+                            v = udivSmall(v, cnt * 34);
+                            q[ch] = v < 15 ? v : 15;
+                        }
+                    }
+                    const int packed = (q[0] << 10) | (q[1] << 5) | q[2];
+                    if (n == 0 || packed != last)
+                    {
+                        S.u.h.color[lane][n++] = (unsigned short)packed;
+                        last = packed;
+                    }
+                }
+                S.dCount[lane] = n;
+            }
+            WAVE_SYNC();
+            const int n0 = S.dCount[0], n1 = S.dCount[1];
+            // per-colour error rows: lane = colour (ETC.cpp:752-787)
+            if (lane < n0 + n1)
+            {
+                const int packed = lane < n0 ? S.u.h.color[0][lane] : S.u.h.color[1][lane - n0];
+                int c0[3], c1[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    const int q = (packed >> ((2 - ch) * 5)) & 15;
+                    const int u = (q << 4) | q;
+                    c0[ch] = u + modifier < 255 ? u + modifier : 255;
+                    c1[ch] = u - modifier > 0 ? u - modifier : 0;
+                }
+                u32 signBits = 0;
+                for (int px = 0; px < 16; px++)
+                {
+                    const float e0 = E(c0[0], c0[1], c0[2], S.pix[px], S.pw[px]);
+                    const float e1 = E(c1[0], c1[1], c1[2], S.pix[px], S.pw[px]);
+                    if (e1 < e0)
+                        signBits |= 1u << px;
+                    S.u.h.err[lane][px] = sseMin(e0, e1);
+                }
+                S.u.h.sign[lane] = (unsigned short)signBits;
+            }
+            WAVE_SYNC();
+            // colour pairs in the reference's odometer order (ETC.cpp:797-812): step s = 1..n0*n1 visits
+            // (s % n0, min(n1 - 1, s / n0)); the last step wraps to (0, n1 - 1), which is a repeat
+            // unless n1 == 1, where it is the only visit of (0, 0)
+            const int numPairs = n0 * n1;
+            for (int base = 1; base <= numPairs; base += 64)
+            {
+                const int k = base + lane;
+                if (k <= numPairs)
+                {
+                    const int i0 = k % n0;
+                    const int i1 = (k / n0) < n1 - 1 ? (k / n0) : n1 - 1;
+                    const int ci0 = i0, ci1 = n0 + i1;
+                    const u32 s0 = S.u.h.sign[ci0], s1 = S.u.h.sign[ci1];
+                    float totalError = 0.0f;
+                    u32 sectorBits = 0, signBits = 0;
+                    for (int px = 0; px < 16; px++)
+                    {
+                        const float e0 = S.u.h.err[ci0][px], e1 = S.u.h.err[ci1][px];
+                        totalError = totalError + sseMin(e0, e1);
+                        const bool oneBetter = e1 < e0;
+                        if (oneBetter)
+                            sectorBits |= 1u << px;
+                        signBits |= (1u << px) & (oneBetter ? s1 : s0);
+                    }
+                    if (totalError < hBestErr)
+                    {
+                        hBestErr = totalError;
+                        hBestId = table * 1024 + k;
+                        hBestBits = sectorBits | (signBits << 16);
+                        hBestC0 = S.u.h.color[0][i0];
+                        hBestC1 = S.u.h.color[1][i1];
+                    }
+                }
+            }
+            WAVE_SYNC();
+        }
+        float wErr = hBestErr;
+        int wId = hBestId;
+        waveArgmin(wErr, wId);
+        if (wErr < bestError)
+        {
+            bestError = wErr;
+            // the winner's data sits in the lane that evaluated it
+            const bool mine = (hBestId == wId) && (hBestErr == wErr);
+            const u64 who = __ballot(mine);
+            const int src = __ffsll((long long)who) - 1;
+            const u32 bits = __shfl(hBestBits, src);
+            const int bc0 = __shfl(hBestC0, src), bc1 = __shfl(hBestC1, src);
+            const int table = wId >> 10;
+            u32 sectorBits = bits & 0xffffu;
+            const u32 signBits = bits >> 16;
+            // EmitHModeBlock, ETC.cpp:2462-2563
+            if (bc0 == bc1)
+            {
+                const int lineColor[3] = {(bc0 >> 10) & 0x1f, (bc0 >> 5) & 0x1f, bc0 & 0x1f};
+                u32 packedSelectors = 0x55555555u;
+#pragma unroll
+                for (int px = 0; px < 16; px++)
+                    packedSelectors |= ((signBits >> px) & 1u) << ((px * 2) + 1);
+                emitT(outHi, outLo, lineColor, lineColor, packedSelectors, table);
+            }
+            else
+            {
+                int colors[2][3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    colors[0][ch] = (bc0 >> ((2 - ch) * 5)) & 15;
+                    colors[1][ch] = (bc1 >> ((2 - ch) * 5)) & 15;
+                }
+                if (((table & 1) == 1) != (bc0 > bc1))
+                {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                    {
+                        const int t = colors[0][ch];
+                        colors[0][ch] = colors[1][ch];
+                        colors[1][ch] = t;
+                    }
+                    sectorBits ^= 0xffffu;
+                }
+                const int r1 = colors[0][0], g1a = colors[0][1] >> 1, g1b = colors[0][1] & 1, b1a = colors[0][2] >> 3, b1b = colors[0][2] & 7;
+                const int r2 = colors[1][0], g2 = colors[1][1], b2 = colors[1][2];
+                u32 hi = 0, lo = 0;
+                if ((g1a & 4) != 0 && r1 + g1a < 8) hi |= 1u << (63 - 32);
+                const int fakeDG = b1b >> 1, fakeG = b1a | (g1b << 1);
+                if (fakeG + fakeDG < 4) hi |= 1u << (50 - 32); else hi |= 7u << (53 - 32);
+                hi |= (u32)r1 << (59 - 32);
+                hi |= (u32)g1a << (56 - 32);
+                hi |= (u32)g1b << (52 - 32);
+                hi |= (u32)b1a << (51 - 32);
+                hi |= (u32)b1b << (47 - 32);
+                hi |= (u32)r2 << (43 - 32);
+                hi |= (u32)g2 << (39 - 32);
+                hi |= (u32)b2 << (35 - 32);
+                hi |= (u32)((table >> 2) & 1) << (34 - 32);
+                hi |= 1u << (33 - 32);
+                hi |= (u32)((table >> 1) & 1);
+#pragma unroll
+                for (int px = 0; px < 16; px++)
+                {
+                    const int src2 = ((px & 3) << 2) | (px >> 2);
+                    lo |= ((signBits >> src2) & 1u) << px;
+                    lo |= ((sectorBits >> src2) & 1u) << (16 + px);
+                }
+                outHi = hi;
+                outLo = lo;
+            }
+        }
+        WAVE_SYNC();
+    }
+
+    DBG_TAP(3);
+    // ====================== ETC1 differential cluster fit (d = 1 only) ======================
+    {
+        bool etcBest = false;
+        int bFlip = 0;
+        u32 bPacked0 = 0, bPacked1 = 0; // selectors | colour << 16
+        int bTable0 = 0, bTable1 = 0;
+
+        for (int flip = 0; flip < 2; flip++)
+        {
+            // half-block membership: flip 0 = left/right 2x4 columns, flip 1 = top/bottom (g_flipTables, ETC.cpp:47-57)
+            // pixel list of (flip, sector): computed on the fly
+            // ---- de-duplicated base colours: lane = sector * 8 + table (ETC.cpp:2690-2791) ----
+            if (lane < 16)
+            {
+                const int sector = lane >> 3, table = lane & 7;
+                int cumulative[3] = {0, 0, 0};
+#pragma unroll
+                for (int px = 0; px < 16; px++)
+                {
+                    const int inSector = flip == 0 ? ((px >> 1) & 1) : (px >> 3);
+                    if (inSector == sector)
+                    {
+                        cumulative[0] += S.pix[px][0];
+                        cumulative[1] += S.pix[px][1];
+                        cumulative[2] += S.pix[px][2];
+                    }
+                }
+                const int numOffsets = T->clusterCount[table];
+                const int start = T->clusterStart[table];
+                int n = 0, last = -1;
+                for (int oi = 0; oi < numOffsets; oi++)
+                {
+                    const int off = T->clusterOffsets[start + oi];
+                    int packed = 0;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                    {
+                        int cu = (int)(short)(cumulative[ch] + off);
+                        cu = cu < 0 ? 0 : (cu > 2040 ? 2040 : cu);
+                        const u32 q = ((((u32)cu << 5) - (u32)cu + ((u32)cu >> 3) + 1024u) & 0xffffu) >> 11;
+                        packed |= (int)q << (ch * 5);
+                    }
+                    if (n == 0 || packed != last)
+                    {
+                        S.dColors[lane][n++] = (unsigned short)packed;
+                        last = packed;
+                    }
+                }
+                S.dCount[lane] = n;
+            }
+            WAVE_SYNC();
+            int prefix[17];
+            prefix[0] = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                prefix[i + 1] = prefix[i] + S.dCount[i];
+            const int numA0 = prefix[8], numA1 = prefix[16] - prefix[8];
+
+            // ---- TestHalfBlock per candidate: lane = candidate (ETC.cpp:94-149, 2793-2828) ----
+            for (int base = 0; base < prefix[16]; base += 64)
+            {
+                const int id = base + lane;
+                if (id < prefix[16])
+                {
+                    int slot = 0;
+#pragma unroll
+                    for (int i = 1; i < 16; i++)
+                        if (id >= prefix[i])
+                            slot = i;
+                    const int sector = slot >> 3, table = slot & 7;
+                    const int packed = S.dColors[slot][id - prefix[slot]];
+                    int modified[4][3];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                    {
+                        const int q = (packed >> (ch * 5)) & 31;
+                        const int u = (q << 3) | (q >> 2);
+#pragma unroll
+                        for (int s = 0; s < 4; s++)
+                        {
+                            const int v = u + T->etc1Modifiers[table][s];
+                            modified[s][ch] = v < 0 ? 0 : (v > 255 ? 255 : v);
+                        }
+                    }
+                    u32 selectors = 0;
+                    float totalError = 0.0f;
+                    for (int spx = 0; spx < 8; spx++)
+                    {
+                        // g_flipTables[flip][sector][spx]
+                        const int px = flip == 0 ? ((spx >> 1) * 4 + (spx & 1) + sector * 2) : (spx + sector * 8);
+                        float be = FLT_MAX;
+                        u32 bs = 0;
+#pragma unroll
+                        for (int s = 0; s < 4; s++)
+                        {
+                            const float e = E(modified[s][0], modified[s][1], modified[s][2], S.pix[px], S.pw[px]);
+                            if (e < be)
+                                bs = (u32)s;
+                            be = sseMin(e, be);
+                        }
+                        totalError = totalError + be;
+                        selectors |= bs << (spx * 2);
+                    }
+                    const int pos = sector == 0 ? id : id - prefix[8];
+                    S.u.a.err[sector][pos] = totalError;
+                    S.u.a.packed[sector][pos] = selectors | ((u32)packed << 16);
+                }
+            }
+            WAVE_SYNC();
+
+            // ---- FindBestDifferentialCombination (ETC.cpp:219-362), wave-parallel scans ----
+            const float blockBest0 = bestError;
+            // cheapest attempt per sector (strict '<' in index order -> lowest index on ties)
+            float m0 = FLT_MAX, m1 = FLT_MAX;
+            int i0 = 0x7fffffff, i1 = 0x7fffffff;
+            for (int i = lane; i < numA0; i += 64)
+            {
+                const float e = S.u.a.err[0][i];
+                if (e < m0) { m0 = e; i0 = i; }
+            }
+            for (int i = lane; i < numA1; i += 64)
+            {
+                const float e = S.u.a.err[1][i];
+                if (e < m1) { m1 = e; i1 = i; }
+            }
+            waveArgmin(m0, i0);
+            waveArgmin(m1, i1);
+            if (i0 == 0x7fffffff) i0 = 0;
+            if (i1 == 0x7fffffff) i1 = 0;
+            auto tableOf = [&](int sector, int pos) {
+                int t = 0;
+#pragma unroll
+                for (int i = 1; i < 8; i++)
+                    if (pos + (sector ? prefix[8] : 0) >= prefix[sector * 8 + i])
+                        t = i;
+                return t;
+            };
+            auto legal = [](u32 a, u32 b) {
+                const int d2 = (int)(b >> 10) - (int)(a >> 10);
+                const int d1 = (int)((b >> 5) & 31u) - (int)((a >> 5) & 31u);
+                const int d0 = (int)(b & 31u) - (int)(a & 31u);
+                return d2 >= -4 && d2 <= 3 && d1 >= -4 && d1 <= 3 && d0 >= -4 && d0 <= 3;
+            };
+            if (m0 + m1 < blockBest0)
+            {
+                const u32 p0 = S.u.a.packed[0][i0], p1 = S.u.a.packed[1][i1];
+                if (legal(p0 >> 16, p1 >> 16))
+                {
+                    etcBest = true;
+                    bestError = m0 + m1;
+                    bFlip = flip;
+                    bPacked0 = p0;
+                    bPacked1 = p1;
+                    bTable0 = tableOf(0, i0);
+                    bTable1 = tableOf(1, i1);
+                }
+                else
+                {
+                    // slow path: walk sector 0's attempts in (error, index) order without sorting;
+                    // for each, the cheapest legal partner (lowest (error, index)) of sector 1
+                    float prevE = -1.0f;
+                    int prevI = -1;
+                    float blockBest = blockBest0;
+                    for (;;)
+                    {
+                        // next attempt of sector 0 in sorted order among those with error < blockBest0
+                        float nE = FLT_MAX;
+                        int nI = 0x7fffffff;
+                        for (int i = lane; i < numA0; i += 64)
+                        {
+                            const float e = S.u.a.err[0][i];
+                            const bool after = (e > prevE) || (e == prevE && i > prevI);
+                            if (e < blockBest0 && after && ((e < nE) || (e == nE && i < nI)))
+                            {
+                                nE = e;
+                                nI = i;
+                            }
+                        }
+                        waveArgmin(nE, nI);
+                        if (nI == 0x7fffffff)
+                            break;
+                        prevE = nE;
+                        prevI = nI;
+                        const float error0 = nE;
+                        if (error0 >= blockBest)
+                            break;
+                        const float maxError1 = bestError - error0;
+                        if (maxError1 < m1)
+                            break;
+                        const u32 c0 = S.u.a.packed[0][nI] >> 16;
+                        // the sorted scan of sector 1 stops at the first entry with error >= maxError1,
+                        // so the partner is the cheapest LEGAL entry provided it is below maxError1
+                        float pE = FLT_MAX;
+                        int pI = 0x7fffffff;
+                        for (int j = lane; j < numA1; j += 64)
+                        {
+                            const float e = S.u.a.err[1][j];
+                            if (e < blockBest0 && legal(c0, S.u.a.packed[1][j] >> 16) && ((e < pE) || (e == pE && j < pI)))
+                            {
+                                pE = e;
+                                pI = j;
+                            }
+                        }
+                        waveArgmin(pE, pI);
+                        if (pI != 0x7fffffff && pE < maxError1)
+                        {
+                            blockBest = error0 + pE;
+                            etcBest = true;
+                            bestError = blockBest;
+                            bFlip = flip;
+                            bPacked0 = S.u.a.packed[0][nI];
+                            bPacked1 = S.u.a.packed[1][pI];
+                            bTable0 = tableOf(0, nI);
+                            bTable1 = tableOf(1, pI);
+                        }
+                    }
+                }
+            }
+            WAVE_SYNC();
+        }
+
+        if (etcBest)
+        {
+            // EmitETC1Block, ETC.cpp:2565-2622 (differential, opaque)
+            const u32 col0 = bPacked0 >> 16, col1 = bPacked1 >> 16;
+            int colors[2][3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+            {
+                colors[0][ch] = (int)((col0 >> (ch * 5)) & 31u);
+                colors[1][ch] = (int)((col1 >> (ch * 5)) & 31u);
+            }
+            u32 hi = 0, lo = 0;
+            hi |= (u32)colors[0][0] << 27;
+            hi |= (u32)((colors[1][0] - colors[0][0]) & 7) << 24;
+            hi |= (u32)colors[0][1] << 19;
+            hi |= (u32)((colors[1][1] - colors[0][1]) & 7) << 16;
+            hi |= (u32)colors[0][2] << 11;
+            hi |= (u32)((colors[1][2] - colors[0][2]) & 7) << 8;
+            hi |= (u32)bTable0 << 5;
+            hi |= (u32)bTable1 << 2;
+            hi |= 1u << 1;
+            hi |= (u32)bFlip;
+            // selector -> modifier code {3, 2, 0, 1}, scattered through the flip table then column-major
+            u32 codes = 0; // 2 bits per pixel position
+#pragma unroll
+            for (int sector = 0; sector < 2; sector++)
+            {
+                const u32 sels = (sector == 0 ? bPacked0 : bPacked1) & 0xffffu;
+#pragma unroll
+                for (int spx = 0; spx < 8; spx++)
+                {
+                    const int px = bFlip == 0 ? ((spx >> 1) * 4 + (spx & 1) + sector * 2) : (spx + sector * 8);
+                    const u32 sel = (sels >> (2 * spx)) & 3u;
+                    const u32 code = (0x4Bu >> (2 * sel)) & 3u; // {3,2,0,1} packed little-endian: 3 | 2<<2 | 0<<4 | 1<<6
+                    codes |= code << (2 * px);
+                }
+            }
+#pragma unroll
+            for (int px = 0; px < 16; px++)
+            {
+                const int src = ((px & 3) << 2) | (px >> 2);
+                const u32 code = (codes >> (2 * src)) & 3u;
+                lo |= (code & 1u) << px;
+                lo |= ((code >> 1) & 1u) << (16 + px);
+            }
+            outHi = hi;
+            outLo = lo;
+        }
+    }
+
+    DBG_TAP(4);
+    if (lane == 0)
+    {
+        uint2 o;
+        o.x = bswap32(outHi);
+        o.y = bswap32(outLo);
+        *reinterpret_cast<uint2 *>(out + (size_t)blockIndex * A.outStride + A.outOffset) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// EAC 8-bit alpha: CompressETC2AlphaBlockInternal (ETC.cpp:1902-2085), QuantizeETC2Alpha 2366-2411.
+__global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+                                                             const CvttEtcArgs A, const CvttDeviceTables *__restrict__ T)
+{
+    const u32 blockIndex = blockIdx.x * 64u + threadIdx.x;
+    const bool valid = blockIndex < A.numBlocks;
+    u32 pk[4]; // 16 alpha bytes
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(blocks + (size_t)(valid ? blockIndex : 0u) * 64u);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const uint4 v = src[i];
+            pk[i] = (v.x >> 24) | ((v.y >> 24) << 8) | ((v.z >> 24) << 16) | ((v.w >> 24) << 24);
+        }
+    }
+    int minAlpha = 255, maxAlpha = 0;
+#pragma unroll
+    for (int px = 0; px < 16; px++)
+    {
+        const int a = (int)((pk[px >> 2] >> (8 * (px & 3))) & 0xffu);
+        minAlpha = a < minAlpha ? a : minAlpha;
+        maxAlpha = a > maxAlpha ? a : maxAlpha;
+    }
+    const int alphaSpan = maxAlpha - minAlpha;
+    const int midTimes2 = maxAlpha + minAlpha;
+
+    u32 bestTotalError = 0x7fffffffu;
+    int bestTable = 0, bestBase = 0, bestMultiplier = 0;
+    u32 bestIdxLo = 0, bestIdxHi = 0; // 3 bits per pixel
+
+    for (int tableIndex = 0; tableIndex < 16; tableIndex++)
+    {
+        const int pos[4] = {T->eacPositive[tableIndex][0], T->eacPositive[tableIndex][1], T->eacPositive[tableIndex][2], T->eacPositive[tableIndex][3]};
+        for (int r = 0; r < 10; r++)
+        {
+            const int subrange = r % 3, mainRange = r / 3;
+            const int maxOffset = T->eacPositive[tableIndex][3 - mainRange - (subrange & 1)];
+            const int minOffset = -(int)T->eacPositive[tableIndex][3 - mainRange - ((subrange >> 1) & 1)] - 1;
+            const int offsetSpan = maxOffset - minOffset;
+            int minMultiplier = udivSmall(alphaSpan, offsetSpan);
+            minMultiplier = minMultiplier > 14 ? 14 : minMultiplier;
+            minMultiplier = minMultiplier < 1 ? 1 : minMultiplier;
+            for (int mo = 0; mo < 2; mo++)
+            {
+                const int multiplier = minMultiplier + mo;
+                int base2 = midTimes2 - multiplier * maxOffset - multiplier * minOffset;
+                base2 = base2 < 0 ? 0 : (base2 > 510 ? 510 : base2);
+                const int baseAlpha = (base2 + 1) >> 1;
+                const float rcpMul = __frcp_rn((float)multiplier);
+                u32 idxLo = 0, idxHi = 0, totalError = 0;
+#pragma unroll
+                for (int px = 0; px < 16; px++)
+                {
+                    const int a = (int)((pk[px >> 2] >> (8 * (px & 3))) & 0xffu);
+                    const int refl2 = (a - baseAlpha) * 2 + multiplier;
+                    const int absv = refl2 < 0 ? -refl2 : refl2;
+                    const int lookup = absv >> 1;
+                    // lookup / multiplier (lookup < 2^10, multiplier <= 15)
+                    int li = (int)((float)lookup * rcpMul);
+                    const int rem = lookup - li * multiplier;
+                    if (rem < 0) li--;
+                    if (rem >= multiplier) li++;
+                    li = li >= 13 ? 12 : li;
+                    const int index = T->eacRounding[tableIndex][li];
+                    const int pOff = index == 0 ? pos[0] : (index == 1 ? pos[1] : (index == 2 ? pos[2] : pos[3]));
+                    const int sign = refl2 < 0 ? -1 : 0;
+                    const int quantizedOffset = (pOff ^ sign) * multiplier;
+                    int q = baseAlpha + quantizedOffset;
+                    q = q < 0 ? 0 : (q > 255 ? 255 : q);
+                    const int d = q - a;
+                    totalError += (u32)(d * d);
+                    const u32 code = (u32)(index + 4 - (sign & 4));
+                    if (px < 8)
+                        idxLo |= code << (3 * px);
+                    else
+                        idxHi |= code << (3 * (px - 8));
+                }
+                if (totalError < bestTotalError)
+                {
+                    bestTotalError = totalError;
+                    bestTable = tableIndex;
+                    bestBase = baseAlpha;
+                    bestMultiplier = multiplier;
+                    bestIdxLo = idxLo;
+                    bestIdxHi = idxHi;
+                }
+            }
+        }
+    }
+    if (valid)
+    {
+        // 16 x 3-bit indexes, column-major pixel order, MSB first (ETC.cpp:2049-2084)
+        u64 bits = 0;
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+        {
+            const int px = ((s & 3) << 2) | (s >> 2); // s-th emitted = pixel with selectorOrder[px] == s
+            const u32 code = px < 8 ? (bestIdxLo >> (3 * px)) & 7u : (bestIdxHi >> (3 * (px - 8))) & 7u;
+            bits = (bits << 3) | code;
+        }
+        uint8_t *o = out + (size_t)blockIndex * A.outStride + A.outOffset;
+        const u32 w0 = (u32)bestBase | ((u32)((bestMultiplier << 4) | bestTable) << 8) | ((u32)((bits >> 40) & 0xff) << 16) | ((u32)((bits >> 32) & 0xff) << 24);
+        const u32 w1 = bswap32((u32)bits);
+        uint2 v;
+        v.x = w0;
+        v.y = w1;
+        *reinterpret_cast<uint2 *>(o) = v;
+    }
+}
+
+extern "C" hipError_t cvttmi_launch_etc2(const void *d_blocks, void *d_out, const CvttEtcArgs *args,
+                                         const CvttDeviceTables *d_tables, int mode, hipStream_t stream)
+{
+    // mode 0: RGB (8 B), 1: RGBA = [alpha | colour] (16 B), 2: alpha only (8 B)
+    if (args->numBlocks == 0)
+        return hipSuccess;
+    CvttEtcArgs a = *args;
+    a.outStride = (mode == 1) ? 16u : 8u;
+    if (mode != 2)
+    {
+        a.outOffset = (mode == 1) ? 8u : 0u;
+        hipLaunchKernelGGL(cvttmi_etc2_color_kernel, dim3(a.numBlocks / 8u), dim3(512), 0, stream, (const uint8_t *)d_blocks,
+                           (uint8_t *)d_out, a, d_tables);
+    }
+    if (mode != 0)
+    {
+        a.outOffset = 0u;
+        hipLaunchKernelGGL(cvttmi_eac_alpha_kernel, dim3((a.numBlocks + 63u) / 64u), dim3(64), 0, stream, (const uint8_t *)d_blocks,
+                           (uint8_t *)d_out, a, d_tables);
+    }
+    return hipGetLastError();
+}

@@ -18,6 +18,7 @@
 #include "cvtt_device.h"
 #include "bc7_tables.h"
 #include "bc6h_layout.h"
+#include "etc_tables.h"
 
 extern "C" hipError_t cvttmi_launch_bc7(const void *d_blocks, void *d_out, const CvttBc7Args *args,
                                         const CvttDeviceTables *d_tables, const CvttBc7DevicePlan *d_plan,
@@ -29,6 +30,9 @@ extern "C" hipError_t cvttmi_launch_bc1(const void *d_blocks, void *d_out, const
 extern "C" hipError_t cvttmi_launch_bc6h(const void *d_blocks, void *d_out, const CvttBc6hArgs *args,
                                          const CvttDeviceTables *d_tables, int isSigned, void *d_scratch, hipStream_t stream);
 extern "C" size_t cvttmi_bc6h_scratch_bytes(uint32_t numBlocks);
+
+extern "C" hipError_t cvttmi_launch_etc2(const void *d_blocks, void *d_out, const CvttEtcArgs *args,
+                                         const CvttDeviceTables *d_tables, int mode, hipStream_t stream);
 
 static_assert(sizeof(cvttmi_options) == 44, "cvtt::Options layout");
 static_assert(sizeof(cvttmi_bc7_plan) == 808, "cvtt::BC7EncodingPlan layout");
@@ -128,6 +132,23 @@ namespace
             for (int b = 0; b < 82; b++)
                 t.bc6hLayout[m][b] = k_bc6h_header_layout[m][b];
         }
+        for (int i = 0; i < 8; i++)
+        {
+            for (int s = 0; s < 4; s++)
+                t.etc1Modifiers[i][s] = k_etc1_modifiers[i * 4 + s];
+            t.thDistance[i] = k_th_distance[i];
+            t.clusterCount[i] = k_cluster_count[i];
+            t.clusterStart[i] = k_cluster_start[i];
+        }
+        for (int i = 0; i < 16; i++)
+        {
+            for (int s = 0; s < 4; s++)
+                t.eacPositive[i][s] = k_eac_positive[i * 4 + s];
+            for (int s = 0; s < 13; s++)
+                t.eacRounding[i][s] = k_eac_rounding[i * 13 + s];
+        }
+        for (int i = 0; i < 632; i++)
+            t.clusterOffsets[i] = k_cluster_offsets[i];
         t.rcpMaxIndex[0] = 0.0f;
         for (int bits = 1; bits <= 4; bits++)
         {
@@ -449,6 +470,106 @@ extern "C"
         }
         return CVTTMI_OK;
     }
+
+    // mode 0: EncodeETC2, 1: EncodeETC2RGBA, 2: EncodeETC2Alpha
+    static int etc2Device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
+                          const cvttmi_options *options, int mode, void *hipStream)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        if (!d_out || !d_blocks || !options || (numBlocks % 8) != 0 || numBlocks > 0xfffffff0u)
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        if (options->flags & CVTTMI_FLAG_ETC_USE_FAKE_BT709)
+            return fail(ctx, CVTTMI_E_UNSUPPORTED, "ETC_UseFakeBT709 is not implemented on the GPU path");
+        if (numBlocks == 0)
+            return CVTTMI_OK;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        hipStream_t stream = static_cast<hipStream_t>(hipStream);
+        CvttEtcArgs args;
+        memset(&args, 0, sizeof(args));
+        args.rw = options->redWeight;
+        args.gw = options->greenWeight;
+        args.bw = options->blueWeight;
+        {
+            // ETC2CompressionDataInternal constructor, reference ETC.cpp:3117-3145 (scalar binary32)
+            volatile float cd[3] = {options->redWeight, options->greenWeight, options->blueWeight};
+            volatile float rotCD[3] = {cd[1], cd[2], cd[0]};
+            volatile float offs = -(rotCD[0] * cd[0] + rotCD[1] * cd[1] + rotCD[2] * cd[2]) / (cd[0] * cd[0] + cd[1] * cd[1] + cd[2] * cd[2]);
+            volatile float a0[3] = {rotCD[0] + cd[0] * offs, rotCD[1] + cd[1] * offs, rotCD[2] + cd[2] * offs};
+            volatile float a1u[3] = {a0[1] * cd[2] - a0[2] * cd[1], a0[2] * cd[0] - a0[0] * cd[2], a0[0] * cd[1] - a0[1] * cd[0]};
+            volatile float l0 = (a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2]);
+            volatile float l1 = (a1u[0] * a1u[0] + a1u[1] * a1u[1] + a1u[2] * a1u[2]);
+            volatile float ratio = static_cast<float>(sqrt(static_cast<double>(l0 / l1)));
+            for (int i = 0; i < 3; i++)
+            {
+                args.axis0[i] = a0[i];
+                args.axis1[i] = a1u[i] * ratio;
+            }
+        }
+        args.flags = options->flags;
+        args.numBlocks = static_cast<uint32_t>(numBlocks);
+        args.debug = getenv("CVTTMI_ETC_DEBUG_PTR") ? strtoull(getenv("CVTTMI_ETC_DEBUG_PTR"), NULL, 0) : 0;
+        if (ctx->timing)
+            hipEventRecord(ctx->evStart, stream);
+        e = cvttmi_launch_etc2(d_blocks, d_out, &args, ctx->dTables, mode, stream);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "etc2 kernel launch", e);
+        if (ctx->timing)
+        {
+            hipEventRecord(ctx->evStop, stream);
+            hipEventSynchronize(ctx->evStop);
+            float ms = 0.0f;
+            hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop);
+            ctx->totalMs += ms;
+            ctx->launches += 1;
+        }
+        return CVTTMI_OK;
+    }
+
+    static int etc2Host(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
+                        const cvttmi_options *options, int mode)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        if (!out || !blocks || !options || (numBlocks % 8) != 0)
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        if (numBlocks == 0)
+            return CVTTMI_OK;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        const size_t inBytes = numBlocks * 64, outBytes = numBlocks * (mode == 1 ? 16 : 8);
+        int rc = ensureStaging(ctx, inBytes, outBytes);
+        if (rc != CVTTMI_OK)
+            return rc;
+        memcpy(ctx->pinnedIn, blocks, inBytes);
+        if ((e = hipMemcpyAsync(ctx->dIn, ctx->pinnedIn, inBytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "H2D", e);
+        rc = etc2Device(ctx, ctx->dOut, ctx->dIn, numBlocks, options, mode, ctx->stream);
+        if (rc != CVTTMI_OK)
+            return rc;
+        if ((e = hipMemcpyAsync(ctx->pinnedOut, ctx->dOut, outBytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "D2H", e);
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "kernel execution", e);
+        memcpy(out, ctx->pinnedOut, outBytes);
+        return CVTTMI_OK;
+    }
+
+    int cvttmi_encode_etc2_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, void *hipStream)
+    { return etc2Device(ctx, d_out, d_blocks, numBlocks, options, 0, hipStream); }
+    int cvttmi_encode_etc2_rgba_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, void *hipStream)
+    { return etc2Device(ctx, d_out, d_blocks, numBlocks, options, 1, hipStream); }
+    int cvttmi_encode_etc2_alpha_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, void *hipStream)
+    { return etc2Device(ctx, d_out, d_blocks, numBlocks, options, 2, hipStream); }
+    int cvttmi_encode_etc2(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options)
+    { return etc2Host(ctx, out, blocks, numBlocks, options, 0); }
+    int cvttmi_encode_etc2_rgba(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options)
+    { return etc2Host(ctx, out, blocks, numBlocks, options, 1); }
+    int cvttmi_encode_etc2_alpha(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options)
+    { return etc2Host(ctx, out, blocks, numBlocks, options, 2); }
 
     int cvttmi_encode_bc6h_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
                                   const cvttmi_options *options, int isSigned, void *hipStream)

@@ -130,6 +130,21 @@ int cvttmi_encode_bc1_device(cvttmi_context *ctx, void *d_out, const void *d_blo
 int cvttmi_encode_bc6h_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
                               const cvttmi_options *options, int isSigned, void *hipStream);
 
+/* replace cvtt::Kernels::EncodeETC2 / EncodeETC2RGBA / EncodeETC2Alpha
+ * (ConvectionKernels_API.cpp:216-229, 270-286, 246-256 -> ETCComputer::CompressETC2Block with
+ * punchthroughAlpha = false, ConvectionKernels_ETC.cpp:1664-1887, and CompressETC2AlphaBlock,
+ * 1889-2085).  numBlocks * 64 B of PixelBlockU8 in; 8 B (RGB, alpha) or 16 B (RGBA: EAC alpha
+ * block then colour block) per block out.  The reference's ETC2CompressionData scratch
+ * (AllocETC2Data / ReleaseETC2Data) has no counterpart: the kernels keep their scratch in
+ * LDS and derive the two chroma axes from options->{red,green,blue}Weight on every call.
+ * Uses the Uniform flag and the colour weights; ETC_UseFakeBT709 is CVTTMI_E_UNSUPPORTED. */
+int cvttmi_encode_etc2_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
+                              const cvttmi_options *options, void *hipStream);
+int cvttmi_encode_etc2_rgba_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
+                                   const cvttmi_options *options, void *hipStream);
+int cvttmi_encode_etc2_alpha_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
+                                    const cvttmi_options *options, void *hipStream);
+
 /* ---- host-buffer convenience entry points: stage through pinned memory, launch, copy
  * back, synchronise.  Same semantics as the *_device calls. ---- */
 int cvttmi_encode_bc7(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
@@ -140,6 +155,13 @@ int cvttmi_encode_bc1(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, 
 
 int cvttmi_encode_bc6h(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
                        const cvttmi_options *options, int isSigned);
+
+int cvttmi_encode_etc2(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
+                       const cvttmi_options *options);
+int cvttmi_encode_etc2_rgba(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
+                            const cvttmi_options *options);
+int cvttmi_encode_etc2_alpha(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
+                             const cvttmi_options *options);
 
 /* Search strategy.  By default the kernels skip candidates (partitions / subsets) whose
  * rigorous error lower bound already exceeds the best candidate found so far -- an exact

@@ -47,3 +47,48 @@ def test_t_mode_group_coupling(oracle_lib):
     blocks = content.mixed_ldr_blocks(8, 12)
     out = oracle_lib.encode_etc2(blocks, pyref.make_options(), 0, 4)
     assert out.shape == (96, 8)
+
+
+# ------------------------------------------------------------------ GPU
+def _enc(ctx, mode):
+    return {0: ctx.encode_etc2, 1: ctx.encode_etc2_rgba, 2: ctx.encode_etc2_alpha}[mode]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_golden(gpu_ctx, name):
+    from convectionkernels_amd import api
+    g = np.load(os.path.join(GOLD, "etc2_mixed.npz"))
+    opt = api.Options.frombytes(g["opt_" + name])
+    for mode, tag in MODES:
+        out = _enc(gpu_ctx, mode)(g["blocks"], opt)
+        bad = np.nonzero((out != g["out_%s_%s" % (tag, name)]).any(axis=1))[0]
+        assert bad.size == 0, (tag, bad[:8])
+
+
+@pytest.mark.gpu
+def test_gpu_known_answers_and_config4(gpu_ctx, oracle_lib):
+    """App. H vector; BASELINE configs[3] content (random RGBA, seed 4) vs the oracle; device path"""
+    import torch
+    from convectionkernels_amd import api
+    g = np.load(os.path.join(GOLD, "known_answers.npz"))
+    assert (gpu_ctx.encode_etc2_rgba(g["blocks"], api.Options()) == g["etc2rgba"]).all()
+    blocks = content.config_blocks(4, 512, 512)  # 16384 blocks
+    exp = oracle_lib.encode_etc2(blocks, pyref.make_options(), 1, threads=8)
+    out = gpu_ctx.encode_etc2_rgba(torch.from_numpy(blocks).cuda(), api.Options()).cpu().numpy()
+    bad = np.nonzero((out != exp).any(axis=1))[0]
+    assert bad.size == 0, bad[:8]
+    smooth = content.mixed_ldr_blocks(99, 96)
+    for mode, _ in MODES:
+        exp = oracle_lib.encode_etc2(smooth, pyref.make_options(), mode, threads=8)
+        assert (_enc(gpu_ctx, mode)(smooth, api.Options()) == exp).all()
+    with pytest.raises(api.CvttError):
+        gpu_ctx.encode_etc2(blocks[:8].copy(), api.Options(flags=api.Flags.Default | api.Flags.ETC_UseFakeBT709))
+
+
+@pytest.mark.gpu
+def test_gpu_vs_reference_on_this_box(gpu_ctx, ref_lib):
+    from convectionkernels_amd import api
+    blocks = np.concatenate([content.mixed_ldr_blocks(777, 48), content.config_blocks(4, 64, 64)])
+    for mode, _ in MODES:
+        assert (_enc(gpu_ctx, mode)(blocks, api.Options()) == ref_lib.encode_etc2(blocks, ref_lib.default_options(), mode)).all()

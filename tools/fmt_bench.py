@@ -10,14 +10,15 @@ fmt = sys.argv[1]
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 ctx = api.Context(0)
-if fmt in ("bc7", "bc7o", "bc1"):
+if fmt in ("bc7", "bc7o", "bc1", "etc2", "etc2rgba", "eac"):
     b = synth.tile_blocks(synth.image_rgba8(2, size, size, opaque=(fmt == "bc7o")))
 else:
     b = synth.tile_blocks(synth.image_f16bits(3, size, size))
 t = torch.from_numpy(b).cuda()
 enc = {"bc7": ctx.encode_bc7, "bc7o": ctx.encode_bc7, "bc1": ctx.encode_bc1,
        "bc6hu": lambda x, out=None: ctx.encode_bc6h(x, signed=False, out=out),
-       "bc6hs": lambda x, out=None: ctx.encode_bc6h(x, signed=True, out=out)}[fmt]
+       "bc6hs": lambda x, out=None: ctx.encode_bc6h(x, signed=True, out=out),
+       "etc2": ctx.encode_etc2, "etc2rgba": ctx.encode_etc2_rgba, "eac": ctx.encode_etc2_alpha}[fmt]
 o = enc(t); torch.cuda.synchronize()
 ms = []
 for _ in range(reps):
