@@ -1,0 +1,132 @@
+// C++ face (include/cvtt/ConvectionKernels.h) on top of the C ABI: same names and call
+// convention as the reference's cvtt::Kernels (reference ConvectionKernels_API.cpp:41-99,
+// 216-286), one process-wide context on HIP device CVTTMI_DEVICE (default 0).
+#include "../../include/cvtt/ConvectionKernels.h"
+#include "../../include/cvtt_mi355x.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+
+static_assert(sizeof(cvtt::Options) == sizeof(cvttmi_options), "cvtt::Options layout");
+static_assert(sizeof(cvtt::BC7EncodingPlan) == sizeof(cvttmi_bc7_plan), "cvtt::BC7EncodingPlan layout");
+static_assert(sizeof(cvtt::PixelBlockU8) == 64 && sizeof(cvtt::PixelBlockF16) == 128, "pixel block layout");
+
+namespace
+{
+    std::mutex g_lock; // the context owns one set of staging buffers
+    cvttmi_context *g_ctx = NULL;
+
+    cvttmi_context *context()
+    {
+        if (!g_ctx)
+        {
+            const char *dev = getenv("CVTTMI_DEVICE");
+            const int rc = cvttmi_create(&g_ctx, dev ? atoi(dev) : 0);
+            if (rc != CVTTMI_OK)
+            {
+                fprintf(stderr, "cvtt (MI355X): no usable gfx950 device (cvttmi_create = %d); there is no CPU fallback\n", rc);
+                abort();
+            }
+        }
+        return g_ctx;
+    }
+
+    void check(int rc, const char *what)
+    {
+        if (rc != CVTTMI_OK)
+        {
+            fprintf(stderr, "cvtt (MI355X): %s failed (%d): %s\n", what, rc, cvttmi_last_error(g_ctx));
+            abort();
+        }
+    }
+
+    const cvttmi_options *opt(const cvtt::Options &o) { return reinterpret_cast<const cvttmi_options *>(&o); }
+
+    struct Etc2Marker : public cvtt::ETC2CompressionData
+    {
+        void *context;
+    };
+}
+
+cvtt::Options::Options()
+{
+    cvttmi_default_options(reinterpret_cast<cvttmi_options *>(this));
+}
+
+cvtt::BC7EncodingPlan::BC7EncodingPlan()
+{
+    cvttmi_default_bc7_plan(reinterpret_cast<cvttmi_bc7_plan *>(this));
+}
+
+namespace cvtt
+{
+    namespace Kernels
+    {
+        void EncodeBC7Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options, const BC7EncodingPlan &plan)
+        {
+            std::lock_guard<std::mutex> g(g_lock);
+            check(cvttmi_encode_bc7(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options),
+                                    reinterpret_cast<const cvttmi_bc7_plan *>(&plan)), "EncodeBC7");
+        }
+        void EncodeBC1Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
+        {
+            std::lock_guard<std::mutex> g(g_lock);
+            check(cvttmi_encode_bc1(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeBC1");
+        }
+        void EncodeBC6HUBatch(uint8_t *pBC, const PixelBlockF16 *pBlocks, size_t numBlocks, const Options &options)
+        {
+            std::lock_guard<std::mutex> g(g_lock);
+            check(cvttmi_encode_bc6h(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), 0), "EncodeBC6HU");
+        }
+        void EncodeBC6HSBatch(uint8_t *pBC, const PixelBlockF16 *pBlocks, size_t numBlocks, const Options &options)
+        {
+            std::lock_guard<std::mutex> g(g_lock);
+            check(cvttmi_encode_bc6h(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), 1), "EncodeBC6HS");
+        }
+        void EncodeETC2Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
+        {
+            std::lock_guard<std::mutex> g(g_lock);
+            check(cvttmi_encode_etc2(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeETC2");
+        }
+        void EncodeETC2RGBABatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
+        {
+            std::lock_guard<std::mutex> g(g_lock);
+            check(cvttmi_encode_etc2_rgba(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeETC2RGBA");
+        }
+        void EncodeETC2AlphaBatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
+        {
+            std::lock_guard<std::mutex> g(g_lock);
+            check(cvttmi_encode_etc2_alpha(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeETC2Alpha");
+        }
+
+        void EncodeBC7(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, const BC7EncodingPlan &plan) { EncodeBC7Batch(pBC, pBlocks, NumParallelBlocks, options, plan); }
+        void EncodeBC1(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options) { EncodeBC1Batch(pBC, pBlocks, NumParallelBlocks, options); }
+        void EncodeBC6HU(uint8_t *pBC, const PixelBlockF16 *pBlocks, const Options &options) { EncodeBC6HUBatch(pBC, pBlocks, NumParallelBlocks, options); }
+        void EncodeBC6HS(uint8_t *pBC, const PixelBlockF16 *pBlocks, const Options &options) { EncodeBC6HSBatch(pBC, pBlocks, NumParallelBlocks, options); }
+        void EncodeETC2(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC2CompressionData *) { EncodeETC2Batch(pBC, pBlocks, NumParallelBlocks, options); }
+        void EncodeETC2RGBA(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC2CompressionData *) { EncodeETC2RGBABatch(pBC, pBlocks, NumParallelBlocks, options); }
+        void EncodeETC2Alpha(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options) { EncodeETC2AlphaBatch(pBC, pBlocks, NumParallelBlocks, options); }
+
+        // The reference places 136 KB of scratch in caller memory (ETC.cpp:3100-3115); here only the
+        // allocator context survives so that ReleaseETC2Data can hand the block back.
+        ETC2CompressionData *AllocETC2Data(allocFunc_t allocFunc, void *ctx, const Options &)
+        {
+            void *buffer = allocFunc(ctx, sizeof(Etc2Marker));
+            if (!buffer)
+                return NULL;
+            Etc2Marker *m = new (buffer) Etc2Marker();
+            m->context = ctx;
+            return m;
+        }
+        void ReleaseETC2Data(ETC2CompressionData *data, freeFunc_t freeFunc)
+        {
+            Etc2Marker *m = static_cast<Etc2Marker *>(data);
+            void *ctx = m->context;
+            freeFunc(ctx, data, sizeof(Etc2Marker));
+        }
+    }
+}

@@ -66,5 +66,95 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not bad.search(text), os.path.join(dirpath, f)
-    for hdr in os.listdir(os.path.join(ROOT, "include")):
-        assert not bad.search(open(os.path.join(ROOT, "include", hdr)).read()), hdr
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "include")):
+        for hdr in files:
+            assert not bad.search(open(os.path.join(dirpath, hdr)).read()), hdr
+
+
+CXX_CLIENT = r"""
+// a client written against the reference's C++ header, built against ours
+#include "cvtt/ConvectionKernels.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+static void *allocate(void *, size_t n) { return malloc(n); }
+static void release(void *, void *p, size_t) { free(p); }
+int main(int argc, char **argv)
+{
+    cvtt::Options options;
+    cvtt::BC7EncodingPlan plan;
+    if (sizeof(options) != 44 || sizeof(plan) != 808 || options.refineRoundsIIC != 8 || !plan.mode6Enabled)
+        return 2;
+    if (argc < 2)
+        return 0; // layout check only
+    cvtt::PixelBlockU8 in[cvtt::NumParallelBlocks];
+    cvtt::PixelBlockF16 hdr[cvtt::NumParallelBlocks];
+    for (unsigned b = 0; b < 8; b++)
+        for (int p = 0; p < 16; p++)
+            for (int c = 0; c < 4; c++)
+            {
+                int v = (29 * b + 13 * p + 71 * c + (p * p + 3 * b) * (c + 1)) & 0xFF;
+                if (b >= 4 && c == 3) v = 255;
+                in[b].m_pixels[p][c] = (uint8_t)v;
+                hdr[b].m_pixels[p][c] = (int16_t)(c == 3 ? 0x3C00 : (((8 + (b + p + c) % 12) << 10) | ((131 * b + 61 * p + 17 * c + 7 * p * p) & 0x3FF)));
+            }
+    uint8_t out[7][128];
+    memset(out, 0, sizeof(out));
+    cvtt::Kernels::EncodeBC7(out[0], in, options, plan);
+    cvtt::Kernels::EncodeBC1(out[1], in, options);
+    cvtt::Kernels::EncodeBC6HU(out[2], hdr, options);
+    cvtt::Kernels::EncodeBC6HS(out[3], hdr, options);
+    cvtt::ETC2CompressionData *data = cvtt::Kernels::AllocETC2Data(allocate, NULL, options);
+    cvtt::Kernels::EncodeETC2(out[4], in, options, data);
+    cvtt::Kernels::EncodeETC2RGBA(out[5], in, options, data);
+    cvtt::Kernels::ReleaseETC2Data(data, release);
+    cvtt::Kernels::EncodeETC2Alpha(out[6], in, options);
+    for (int k = 0; k < 7; k++)
+    {
+        for (int i = 0; i < 128; i++)
+            printf("%02x", out[k][i]);
+        printf("\n");
+    }
+    return 0;
+}
+"""
+
+
+def _build_cxx_client(tmp_path):
+    import subprocess
+    from convectionkernels_amd import api
+    src = tmp_path / "client.cpp"
+    src.write_text(CXX_CLIENT)
+    exe = tmp_path / "client"
+    libdir = os.path.dirname(os.path.abspath(os.environ.get("CVTTMI_LIB", api._LIB_PATH)))
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lcvtt_mi355x", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_cxx_header_is_source_compatible(tmp_path):
+    """a client of the reference's cvtt::Kernels API compiles and links against our header + .so"""
+    import subprocess
+    exe = _build_cxx_client(tmp_path)
+    assert subprocess.call([str(exe)]) == 0
+
+
+@pytest.mark.gpu
+def test_cxx_api_matches_oracle(tmp_path, oracle_lib, gpu_ctx):
+    import subprocess
+    from tests import content
+    from oracle import pyref
+    exe = _build_cxx_client(tmp_path)
+    lines = subprocess.check_output([str(exe), "run"]).decode().split()
+    ldr = content.known_answer_group_ldr()
+    hdr = content.known_answer_group_hdr()
+    o = pyref.make_options()
+    from convectionkernels_amd import api
+    plan = np.frombuffer(bytes(api.BC7EncodingPlan()), np.uint8).copy()
+    rcp = api.Context(0).get_rcp_table()  # a fresh context's built-in table, as the C++ client's
+    want = [oracle_lib.encode_bc7(ldr, o, plan, rcp), oracle_lib.encode_bc1(ldr, o, rcp),
+            oracle_lib.encode_bc6h(hdr, o, signed=False, rcp=rcp), oracle_lib.encode_bc6h(hdr, o, signed=True, rcp=rcp),
+            oracle_lib.encode_etc2(ldr, o, mode=0), oracle_lib.encode_etc2(ldr, o, mode=1), oracle_lib.encode_etc2(ldr, o, mode=2)]
+    for k, w in enumerate(want):
+        got = bytes.fromhex(lines[k])[:w.size]
+        assert got == w.tobytes(), k

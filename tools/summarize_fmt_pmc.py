@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Condense the per-format rocprofv3 CSVs of tools/profile_formats.sh into fmt_summary.json."""
+import csv, glob, json, os, sys
+
+out_dir = sys.argv[1]
+summary = {"fmt_bench": [json.loads(l) for l in open(os.path.join(out_dir, "fmt_bench.jsonl")) if l.strip()]}
+for d in sorted(glob.glob(os.path.join(out_dir, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    fmt = os.path.basename(d)[4:]
+    f = glob.glob(os.path.join(d, "*counter_collection.csv"))
+    if not f:
+        continue
+    disp = {}
+    for r in csv.DictReader(open(f[0])):
+        if "cvttmi" not in r["Kernel_Name"]:
+            continue
+        e = disp.setdefault(r["Dispatch_Id"], {"kernel": r["Kernel_Name"].split("(")[0], "vgpr": r["VGPR_Count"], "sgpr": r["SGPR_Count"],
+                                               "scratch": r["Scratch_Size"], "lds": r.get("LDS_Block_Size", ""), "grid": int(r["Grid_Size"]),
+                                               "wg": int(r["Workgroup_Size"]),
+                                               "dur_us": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, "counters": {}})
+        e["counters"][r["Counter_Name"]] = e["counters"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    # keep the last dispatch of each kernel (the timed one)
+    last = {}
+    for e in disp.values():
+        last[e["kernel"]] = e
+    for e in last.values():
+        c = e["counters"]
+        try:
+            xcd = c["GRBM_GUI_ACTIVE"] / 8.0
+            simd = xcd * 1024
+            e["derived"] = {"valu_insts_per_wave": c["SQ_INSTS_VALU"] / (e["grid"] / 64),
+                            "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4 / simd,
+                            "avg_waves_per_simd": c["SQ_WAVE_CYCLES"] * 4 / simd,
+                            "cycles_per_valu_inst": c["SQ_ACTIVE_INST_VALU"] * 4 / c["SQ_INSTS_VALU"]}
+        except Exception as ex:  # noqa
+            e["derived_error"] = str(ex)
+    summary[fmt] = list(last.values())
+    st = glob.glob(os.path.join(out_dir, "trace_" + fmt, "*kernel_stats.csv"))
+    if st:
+        summary[fmt + "_kernel_stats"] = [r for r in csv.DictReader(open(st[0])) if "cvttmi" in r["Name"]]
+json.dump(summary, open(os.path.join(out_dir, "fmt_summary.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1)[:6000])
