@@ -35,6 +35,29 @@
 
 #include "cvtt_kernel_common.h"
 
+// Developer-only phase profile (-DCVTT_BC7_PROFILE): wave cycles per phase, summed over waves.
+#ifdef CVTT_BC7_PROFILE
+__device__ unsigned long long g_bc7Prof[48];
+#define PROF_DECL unsigned long long profT = __builtin_readcyclecounter(); unsigned long long profAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long profCnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF_MARK(slot) { const unsigned long long now = __builtin_readcyclecounter(); profAcc[slot] += now - profT; profT = now; }
+#define PROF_FLUSH if (threadIdx.x == 0) { unsigned long long tot = 0; for (int i = 0; i < 8; i++) { atomicAdd(&g_bc7Prof[i], profAcc[i]); tot += profAcc[i]; } \
+    int bucket = 63 - __builtin_clzll(tot | 1ull) - 12; bucket = bucket < 0 ? 0 : (bucket > 15 ? 15 : bucket); atomicAdd(&g_bc7Prof[16 + bucket], 1ull); \
+    for (int i = 0; i < 8; i++) atomicAdd(&g_bc7Prof[32 + i], profCnt[i]); }
+#define PROF_COUNT(slot, n) { profCnt[slot] += (unsigned long long)(n); }
+extern "C" int cvttmi_bc7_prof_read(unsigned long long *out)
+{
+    unsigned long long zero[48] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bc7Prof), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bc7Prof), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#else
+#define PROF_DECL
+#define PROF_MARK(slot)
+#define PROF_COUNT(slot, n)
+#define PROF_FLUSH
+#endif
+
 namespace
 {
 // ---- BC7 endpoint quantisation (reference BC67.cpp:829-860); all values fit 16 bits ----
@@ -122,15 +145,17 @@ __device__ __forceinline__ void quadArgminBroadcast(ShapeBest &b, int lane)
     b.idxHi = __shfl(b.idxHi, src);
 }
 
-// One shape of a single-plane mode: the reference's pIter x tweak x refine loops
-// (BC67.cpp:1298-1434) spread over the quad.  NRC = numRealChannels (3 for modes 0-3).
+// One CHAIN of a single-plane shape: a (p-bit combination, seed point) pair of the reference's
+// pIter x tweak loops (BC67.cpp:1298-1434) with its refine rounds, run by one lane.  The
+// pixels of the block are read from LDS (`lp`, 16 packed RGBA8 words) in ascending order of
+// the shape's members.  NRC = numRealChannels (3 for modes 0-3).  maxCount = wave-uniform
+// upper bound on popcount(mask).
 template <int NRC, bool FAST>
-__device__ __forceinline__ void evalShape(const u32 (&pix)[16], u32 mask, const ModeDesc md, const Unfinished &u,
-                                          int numTweak, const CvttBc7Args &A, const CvttDeviceTables *__restrict__ T,
-                                          int numRefine, int lane, ShapeBest &best)
+__device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount, const ModeDesc md, const Unfinished &u,
+                                          int pIter, int tweak, bool active, const CvttBc7Args &A,
+                                          const CvttDeviceTables *__restrict__ T, int numRefine, ShapeBest &best)
 {
     const bool isRGB = (NRC == 3);
-    const int c = lane & 3;
     const int range = 1 << md.indexBits;
     const float maxValue = (float)(range - 1);
     const float rcpMaxIndex = T->rcpMaxIndex[md.indexBits];
@@ -140,244 +165,286 @@ __device__ __forceinline__ void evalShape(const u32 (&pix)[16], u32 mask, const 
     const float wCount = (float)count;
     const bool uniformErr = (A.flags & CVTTMI_FLAG_UNIFORM) != 0;
 
-    // static alpha error of RGB modes (reference BC67.cpp:1250-1264); zero on opaque groups
+    best.err = FLT_MAX;
+    best.ep0 = best.ep1 = 0;
+    best.idxLo = best.idxHi = 0;
+    if (!active)
+        mask = 0;
+
+    // static alpha error of RGB modes (reference BC67.cpp:1250-1264); zero on opaque blocks
     float staticAlphaError = 0.0f;
     if (isRGB)
     {
         u32 acc = 0;
-#pragma unroll
-        for (int px = 0; px < 16; px++)
-            if ((mask >> px) & 1u)
+        u32 rem = mask;
+        for (int i = 0; i < maxCount; i++)
+        {
+            if (rem)
             {
-                const int d = 255 - byteI(fetchPixel(pix[px]), 3);
+                const int px = __ffs((int)rem) - 1;
+                rem &= rem - 1;
+                const int d = 255 - byteI(lp[px], 3);
                 acc = (u32)mad24(d, d, (int)acc);
             }
+        }
         staticAlphaError = uniformErr ? (float)(int)acc : (float)(int)acc * A.wSq[3];
     }
 
-    best.err = FLT_MAX;
-    best.ep0 = best.ep1 = 0;
-    best.idxLo = best.idxHi = 0;
-
-    // chains of this sub-lane: (pIter, tweak) pairs in increasing sequential order
-    int chainsPerLane, pIter, tweak0;
-    if (md.numP == 4) { chainsPerLane = 4; pIter = c; tweak0 = 0; }
-    else if (md.numP == 2) { chainsPerLane = 2; pIter = c >> 1; tweak0 = (c & 1) * 2; }
-    else { chainsPerLane = 1; pIter = 0; tweak0 = c; }
-
-    for (int k = 0; k < chainsPerLane; k++)
+    // UnfinishedEndpoints::FinishLDR (reference UnfinishedEndpoints.h:77-91)
+    const float tf0 = T->tweakFactors[md.indexBits - 2][tweak][0];
+    const float tf1 = T->tweakFactors[md.indexBits - 2][tweak][1];
+    int ep[2][4];
+#pragma unroll
+    for (int ch = 0; ch < 4; ch++)
     {
-        const int tweak = tweak0 + k;
-        if (tweak < numTweak)
+        if (ch < NRC)
         {
-            // UnfinishedEndpoints::FinishLDR (reference UnfinishedEndpoints.h:77-91)
-            const float tf0 = T->tweakFactors[md.indexBits - 2][tweak][0];
-            const float tf1 = T->tweakFactors[md.indexBits - 2][tweak][1];
-            int ep[2][4];
+            ep[0][ch] = (int)clampRound(u.base[ch] + u.offset[ch] * tf0, 255.0f);
+            ep[1][ch] = (int)clampRound(u.base[ch] + u.offset[ch] * tf1, 255.0f);
+        }
+        else
+            ep[0][ch] = ep[1][ch] = 255;
+    }
+
+    for (int refine = 0; refine < numRefine; refine++)
+    {
+        const bool last = (refine == numRefine - 1);
+        compressEndpoints(md, ep, pIter, isRGB);
+
+        // IndexSelector<4>::Init (reference IndexSelector.h:27-77)
+        float origin[4], axis[4];
+        int recBase[4], recDelta[4];
+        {
+            float epDW[4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++)
+            {
+                origin[ch] = (float)ep[0][ch];
+                epDW[ch] = ((float)ep[1][ch] - origin[ch]) * A.w[ch];
+                recBase[ch] = (ep[0][ch] << 6) + 32;
+                recDelta[ch] = ep[1][ch] - ep[0][ch];
+            }
+            float lenSq = epDW[0] * epDW[0];
+#pragma unroll
+            for (int ch = 1; ch < 4; ch++)
+                lenSq = lenSq + epDW[ch] * epDW[ch];
+            lenSq = safeDenom(lenSq);
+            const float mvdls = maxValue / lenSq;
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++)
+                axis[ch] = epDW[ch] * A.w[ch] * mvdls;
+        }
+
+        u32 err[4] = {0, 0, 0, 0};
+        float slowErr = 0.0f;
+        float tv[4] = {0, 0, 0, 0}, vs[4] = {0, 0, 0, 0};
+        float tt = 0.0f, ts = 0.0f;
+        u64 idx = 0;
+        u32 rem = mask;
+
+        for (int i = 0; i < maxCount; i++)
+        {
+            if (rem)
+            {
+                const int px = __ffs((int)rem) - 1;
+                rem &= rem - 1;
+                const u32 pk = lp[px];
+                // SelectIndexLDR (reference IndexSelector.h:124-131)
+                float dist = (byteF(pk, 0) - origin[0]) * axis[0];
+#pragma unroll
+                for (int ch = 1; ch < 4; ch++)
+                    dist = dist + (byteF(pk, ch) - origin[ch]) * axis[ch];
+                float fidx = clampRound(dist, maxValue);
+                int index = (int)fidx;
+
+                if (FAST)
+                {
+                    // ReconstructLDR_BC7 + ComputeErrorLDR (IndexSelector.h:90-100, BCCommon.h:24-29)
+                    const int wgt = mad24(weightRcp, index, 256) >> 9;
+#pragma unroll
+                    for (int ch = 0; ch < NRC; ch++)
+                    {
+                        const int rec = mad24(wgt, recDelta[ch], recBase[ch]) >> 6;
+                        const int d = rec - byteI(pk, ch);
+                        err[ch] = (u32)mad24(d, d, (int)err[ch]);
+                    }
+                }
+                else
+                {
+                    // slow indexing: also probe index-1 / index+1 (reference BC67.cpp:1367-1386)
+                    float bestE = 0.0f;
+#pragma unroll
+                    for (int probe = 0; probe < 3; probe++)
+                    {
+                        int cand = index;
+                        if (probe == 1) cand = (index > 1 ? index : 1) - 1;
+                        if (probe == 2) cand = (index + 1 < range - 1) ? index + 1 : range - 1;
+                        const int wgt = mad24(weightRcp, cand, 256) >> 9;
+                        u32 e4[4] = {0, 0, 0, 0};
+#pragma unroll
+                        for (int ch = 0; ch < NRC; ch++)
+                        {
+                            const int rec = mad24(wgt, recDelta[ch], recBase[ch]) >> 6;
+                            const int d = rec - byteI(pk, ch);
+                            e4[ch] = (u32)__mul24(d, d);
+                        }
+                        float e;
+                        if (uniformErr)
+                            e = (float)(int)(e4[0] + e4[1] + e4[2] + e4[3]);
+                        else
+                        {
+                            e = (float)(int)e4[0] * A.wSq[0];
+                            e = e + (float)(int)e4[1] * A.wSq[1];
+                            e = e + (float)(int)e4[2] * A.wSq[2];
+                            e = e + (float)(int)e4[3] * A.wSq[3];
+                        }
+                        if (probe == 0)
+                            bestE = e;
+                        else
+                        {
+                            // both alternatives derive from the initial index (BC67.cpp:1367-1386)
+                            const bool better = e < bestE;
+                            bestE = sseMin(bestE, e);
+                            if (better)
+                                fidx = (float)cand;
+                        }
+                    }
+                    slowErr = slowErr + bestE;
+                    index = (int)fidx;
+                }
+
+                if (!last)
+                {
+                    // EndpointRefiner::ContributeUnweightedPW (EndpointRefiner.h:78-92)
+                    const float t = fidx * rcpMaxIndex;
+#pragma unroll
+                    for (int ch = 0; ch < NRC; ch++)
+                    {
+                        const float v = byteF(pk, ch) * A.w[ch];
+                        tv[ch] = tv[ch] + t * v;
+                        vs[ch] = vs[ch] + v;
+                    }
+                    tt = tt + t * t;
+                    ts = ts + t;
+                }
+                idx |= (u64)(u32)index << (4 * px);
+            }
+        }
+
+        // AggregatedError<4>::Finalize (reference AggregatedError.h:29-46)
+        float shapeError;
+        if (FAST)
+        {
+            if (uniformErr)
+                shapeError = (float)(int)(err[0] + err[1] + err[2] + err[3]);
+            else
+            {
+                shapeError = (float)(int)err[0] * A.wSq[0];
+                shapeError = shapeError + (float)(int)err[1] * A.wSq[1];
+                shapeError = shapeError + (float)(int)err[2] * A.wSq[2];
+                shapeError = shapeError + (float)(int)err[3] * A.wSq[3];
+            }
+        }
+        else
+            shapeError = slowErr;
+        if (isRGB)
+            shapeError = shapeError + staticAlphaError;
+
+        if (active && shapeError < best.err)
+        {
+            best.err = shapeError;
+            best.ep0 = packEP(ep[0]);
+            best.ep1 = packEP(ep[1]);
+            best.idxLo = (u32)idx;
+            best.idxHi = (u32)(idx >> 32);
+        }
+
+        if (!last)
+        {
+            // EndpointRefiner::GetRefinedEndpointsLDR (EndpointRefiner.h:99-152)
+            float adenom = (tt * wCount - ts * ts) * wRcp;
+            const bool adenomZero = (adenom == 0.0f);
+            if (adenomZero)
+                adenom = 1.0f;
 #pragma unroll
             for (int ch = 0; ch < 4; ch++)
             {
                 if (ch < NRC)
                 {
-                    ep[0][ch] = (int)clampRound(u.base[ch] + u.offset[ch] * tf0, 255.0f);
-                    ep[1][ch] = (int)clampRound(u.base[ch] + u.offset[ch] * tf1, 255.0f);
-                }
-                else
-                    ep[0][ch] = ep[1][ch] = 255;
-            }
-
-            for (int refine = 0; refine < numRefine; refine++)
-            {
-                const bool last = (refine == numRefine - 1);
-                compressEndpoints(md, ep, pIter, isRGB);
-
-                // IndexSelector<4>::Init (reference IndexSelector.h:27-77)
-                float origin[4], axis[4];
-                int recBase[4], recDelta[4];
-                {
-                    float epDW[4];
-#pragma unroll
-                    for (int ch = 0; ch < 4; ch++)
-                    {
-                        origin[ch] = (float)ep[0][ch];
-                        epDW[ch] = ((float)ep[1][ch] - origin[ch]) * A.w[ch];
-                        recBase[ch] = (ep[0][ch] << 6) + 32;
-                        recDelta[ch] = ep[1][ch] - ep[0][ch];
-                    }
-                    float lenSq = epDW[0] * epDW[0];
-#pragma unroll
-                    for (int ch = 1; ch < 4; ch++)
-                        lenSq = lenSq + epDW[ch] * epDW[ch];
-                    lenSq = safeDenom(lenSq);
-                    const float mvdls = maxValue / lenSq;
-#pragma unroll
-                    for (int ch = 0; ch < 4; ch++)
-                        axis[ch] = epDW[ch] * A.w[ch] * mvdls;
-                }
-
-                const u32 m = opaqueUniform(mask);
-                u32 err[4] = {0, 0, 0, 0};
-                float slowErr = 0.0f;
-                float tv[4] = {0, 0, 0, 0}, vs[4] = {0, 0, 0, 0};
-                float tt = 0.0f, ts = 0.0f;
-                u32 idxLo = 0, idxHi = 0;
-
-#pragma unroll
-                for (int px = 0; px < 16; px++)
-                {
-                    if ((m >> px) & 1u)
-                    {
-                        const u32 pk = fetchPixel(pix[px]);
-                        // SelectIndexLDR (reference IndexSelector.h:124-131)
-                        float dist = (byteF(pk, 0) - origin[0]) * axis[0];
-#pragma unroll
-                        for (int ch = 1; ch < 4; ch++)
-                            dist = dist + (byteF(pk, ch) - origin[ch]) * axis[ch];
-                        float fidx = clampRound(dist, maxValue);
-                        int index = (int)fidx;
-
-                        if (FAST)
-                        {
-                            // ReconstructLDR_BC7 + ComputeErrorLDR (IndexSelector.h:90-100, BCCommon.h:24-29)
-                            const int wgt = mad24(weightRcp, index, 256) >> 9;
-#pragma unroll
-                            for (int ch = 0; ch < NRC; ch++)
-                            {
-                                const int rec = mad24(wgt, recDelta[ch], recBase[ch]) >> 6;
-                                const int d = rec - byteI(pk, ch);
-                                err[ch] = (u32)mad24(d, d, (int)err[ch]);
-                            }
-                        }
-                        else
-                        {
-                            // slow indexing: also probe index-1 / index+1 (reference BC67.cpp:1367-1386)
-                            float bestE = 0.0f;
-#pragma unroll
-                            for (int probe = 0; probe < 3; probe++)
-                            {
-                                int cand = index;
-                                if (probe == 1) cand = (index > 1 ? index : 1) - 1;
-                                if (probe == 2) cand = (index + 1 < range - 1) ? index + 1 : range - 1;
-                                if (probe == 0) cand = index;
-                                const int baseIndex = index;
-                                (void)baseIndex;
-                                const int wgt = mad24(weightRcp, cand, 256) >> 9;
-                                u32 e4[4] = {0, 0, 0, 0};
-#pragma unroll
-                                for (int ch = 0; ch < NRC; ch++)
-                                {
-                                    const int rec = mad24(wgt, recDelta[ch], recBase[ch]) >> 6;
-                                    const int d = rec - byteI(pk, ch);
-                                    e4[ch] = (u32)__mul24(d, d);
-                                }
-                                float e;
-                                if (uniformErr)
-                                    e = (float)(int)(e4[0] + e4[1] + e4[2] + e4[3]);
-                                else
-                                {
-                                    e = (float)(int)e4[0] * A.wSq[0];
-                                    e = e + (float)(int)e4[1] * A.wSq[1];
-                                    e = e + (float)(int)e4[2] * A.wSq[2];
-                                    e = e + (float)(int)e4[3] * A.wSq[3];
-                                }
-                                if (probe == 0)
-                                    bestE = e;
-                                else
-                                {
-                                    // alternatives are derived from the index chosen so far
-                                    // (the reference computes both from the initial index)
-                                    const bool better = e < bestE;
-                                    bestE = sseMin(bestE, e);
-                                    if (better)
-                                        fidx = (float)cand;
-                                }
-                            }
-                            slowErr = slowErr + bestE;
-                            index = (int)fidx;
-                        }
-
-                        if (!last)
-                        {
-                            // EndpointRefiner::ContributeUnweightedPW (EndpointRefiner.h:78-92)
-                            const float t = fidx * rcpMaxIndex;
-#pragma unroll
-                            for (int ch = 0; ch < NRC; ch++)
-                            {
-                                const float v = byteF(pk, ch) * A.w[ch];
-                                tv[ch] = tv[ch] + t * v;
-                                vs[ch] = vs[ch] + v;
-                            }
-                            tt = tt + t * t;
-                            ts = ts + t;
-                        }
-                        if (px < 8)
-                            idxLo |= (u32)index << (4 * px);
-                        else
-                            idxHi |= (u32)index << (4 * (px - 8));
-                    }
-                }
-
-                // AggregatedError<4>::Finalize (reference AggregatedError.h:29-46)
-                float shapeError;
-                if (FAST)
-                {
-                    if (uniformErr)
-                        shapeError = (float)(int)(err[0] + err[1] + err[2] + err[3]);
-                    else
-                    {
-                        shapeError = (float)(int)err[0] * A.wSq[0];
-                        shapeError = shapeError + (float)(int)err[1] * A.wSq[1];
-                        shapeError = shapeError + (float)(int)err[2] * A.wSq[2];
-                        shapeError = shapeError + (float)(int)err[3] * A.wSq[3];
-                    }
-                }
-                else
-                    shapeError = slowErr;
-                if (isRGB)
-                    shapeError = shapeError + staticAlphaError;
-
-                if (shapeError < best.err)
-                {
-                    best.err = shapeError;
-                    best.ep0 = packEP(ep[0]);
-                    best.ep1 = packEP(ep[1]);
-                    best.idxLo = idxLo;
-                    best.idxHi = idxHi;
-                }
-
-                if (!last)
-                {
-                    // EndpointRefiner::GetRefinedEndpointsLDR (EndpointRefiner.h:99-152)
-                    float adenom = (tt * wCount - ts * ts) * wRcp;
-                    const bool adenomZero = (adenom == 0.0f);
+                    const float a = (tv[ch] - ts * vs[ch] * wRcp) / adenom;
+                    const float b = (vs[ch] - a * ts) * wRcp;
+                    float p1 = b;
+                    float p2 = a + b;
                     if (adenomZero)
-                        adenom = 1.0f;
-#pragma unroll
-                    for (int ch = 0; ch < 4; ch++)
                     {
-                        if (ch < NRC)
-                        {
-                            const float a = (tv[ch] - ts * vs[ch] * wRcp) / adenom;
-                            const float b = (vs[ch] - a * ts) * wRcp;
-                            float p1 = b;
-                            float p2 = a + b;
-                            if (adenomZero)
-                            {
-                                p1 = vs[ch] * wRcp;
-                                p2 = p1;
-                            }
-                            ep[0][ch] = (int)clampRound(p1 * A.rcpW[ch], 255.0f);
-                            ep[1][ch] = (int)clampRound(p2 * A.rcpW[ch], 255.0f);
-                        }
-                        else
-                            ep[0][ch] = ep[1][ch] = 0; // overwritten with 255 by compressEndpoints
+                        p1 = vs[ch] * wRcp;
+                        p2 = p1;
                     }
+                    ep[0][ch] = (int)clampRound(p1 * A.rcpW[ch], 255.0f);
+                    ep[1][ch] = (int)clampRound(p2 * A.rcpW[ch], 255.0f);
                 }
+                else
+                    ep[0][ch] = ep[1][ch] = 0; // overwritten with 255 by compressEndpoints
             }
         }
     }
-    quadArgminBroadcast(best, lane);
 }
+
+// Order-preserving argmin over aligned groups of `width` lanes (4, 8 or 16): ties go to the
+// lower lane, i.e. the earlier chain in the reference's sequential commit order.
+__device__ __forceinline__ void groupArgminBroadcast(ShapeBest &b, int lane, int width)
+{
+    int who = lane;
+    float err = b.err;
+    for (int step = 1; step < width; step <<= 1)
+    {
+        const float oErr = __shfl_xor(err, step);
+        const int oWho = __shfl_xor(who, step);
+        const bool take = (oErr < err) || (oErr == err && oWho < who);
+        err = take ? oErr : err;
+        who = take ? oWho : who;
+    }
+    b.err = err;
+    b.ep0 = __shfl(b.ep0, who);
+    b.ep1 = __shfl(b.ep1, who);
+    b.idxLo = __shfl(b.idxLo, who);
+    b.idxHi = __shfl(b.idxHi, who);
+}
+
+// Pixel source for the PCA passes of a block staged in LDS.
+struct FetchLDS
+{
+    const u32 *lp;
+    const float (&w)[4];
+    template <int N>
+    __device__ __forceinline__ void get(int px, float (&v)[N]) const
+    {
+        const u32 pk = lp[px];
+#pragma unroll
+        for (int ch = 0; ch < N; ch++)
+            v[ch] = byteF(pk, ch) * w[ch];
+    }
+};
+
+template <int N>
+__device__ __forceinline__ void pcaEndpointsLDS(const u32 *lp, u32 mask, const float (&w)[4], Unfinished &u)
+{
+    const FetchLDS F = {lp, w};
+    Moments<N> m;
+    pcaMomentsT<N>(F, mask, m);
+    pcaFinishT<N>(F, mask, w, m, u);
+}
+
+// What one lane of the PCA pass leaves for the chain lanes of its (block, partition, subset).
+struct UnitRec
+{
+    float base[4];
+    float offset[4];
+    u32 mask;
+    int numTweak;
+    int blk;
+    int sub;
+};
 
 // 128-bit little-endian bit writer (reference PackingVector, BC67.cpp:652-698)
 struct BitWriter
@@ -737,6 +804,302 @@ __device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int ind
     quadArgminBroadcast(bestA, lane);
 }
 
+
+// =====================================================================================
+// Exact branch-and-bound, part 2: cheap bounds for every partition before anything is
+// searched (part 1, the bound itself, is shapeErrorLowerBound in cvtt_kernel_common.h).
+//
+// The weighted pixels of a block are projected on an orthonormal pair (e1, e2) -- the two
+// leading principal axes of the whole block, so that little of any subset's residual is lost --
+// scaled and rounded to 12-bit integers.  An orthogonal projection never increases distances,
+// so the total-least-squares residual of the projected, rounded points (minus the allowance
+// for the rounding radius) still bounds the error of every trial from below; in 2-D the
+// residual is the smaller eigenvalue of a 2x2 matrix whose entries are exact integers
+// accumulated with v_dot2_i32_i16 over a per-lane pixel mask.  Sub-lane c of a quad walks
+// partitions c, c+4, ...; the bounds land in LDS (64 partitions x 16 blocks).
+// =====================================================================================
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int dot2(u32 a, u32 b, int acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b), acc, false);
+}
+
+__device__ __forceinline__ constexpr int tri(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
+
+struct BlockScatter
+{
+    float S[10];     // weighted scatter matrix of the 16 pixels (lower triangle, row-major)
+    float meanW[4];  // weighted centroid
+};
+
+__device__ __forceinline__ void blockScatter(const u32 (&pix)[16], const CvttBc7Args &A, BlockScatter &bs)
+{
+    int s[4] = {0, 0, 0, 0};
+    int p[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int px = 0; px < 16; px++)
+    {
+        const u32 pk = fetchPixel(pix[px]);
+        int x[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++)
+        {
+            x[ch] = byteI(pk, ch);
+            s[ch] += x[ch];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c <= r; c++)
+                p[tri(r, c)] = mad24(x[r], x[c], p[tri(r, c)]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        bs.meanW[r] = (float)s[r] * A.w[r] * 0.0625f;
+#pragma unroll
+        for (int c = 0; c <= r; c++)
+        {
+            // 16*sum(xy) - sum(x)*sum(y): an exact integer below 2^24
+            const int v = 16 * p[tri(r, c)] - __mul24(s[r], s[c]);
+            bs.S[tri(r, c)] = (float)v * (A.w[r] * A.w[c] * 0.0625f);
+        }
+    }
+}
+
+// bound of a shape made of all 16 pixels restricted to three channels (a < b < c)
+__device__ __forceinline__ float planeBound(const BlockScatter &bs, int a, int b, int c, float delta)
+{
+    Moments<3> m;
+    m.cov[0] = bs.S[tri(a, a)];
+    m.cov[1] = bs.S[tri(b, a)];
+    m.cov[2] = bs.S[tri(b, b)];
+    m.cov[3] = bs.S[tri(c, a)];
+    m.cov[4] = bs.S[tri(c, b)];
+    m.cov[5] = bs.S[tri(c, c)];
+    return shapeErrorLowerBound<3>(m, 16.0f, delta);
+}
+
+// dominant eigenvector of a symmetric PSD 4x4 (power iteration from the column of the
+// largest diagonal entry).  Accuracy only affects how tight the bounds are, never their
+// validity: the caller orthonormalises whatever comes back.
+__device__ __forceinline__ void topEigenvector(const float (&M)[10], float (&e)[4])
+{
+    int k = 0;
+    float d = M[tri(0, 0)];
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if (M[tri(i, i)] > d)
+        {
+            d = M[tri(i, i)];
+            k = i;
+        }
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        v[i] = (k == 0) ? M[tri(i, 0)] : (k == 1) ? M[tri(i, 1)] : (k == 2) ? M[tri(i, 2)] : M[tri(i, 3)];
+    for (int it = 0; it < 6; it++)
+    {
+        float nv[4];
+        float big = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            float a = M[tri(r, 0)] * v[0];
+#pragma unroll
+            for (int c = 1; c < 4; c++)
+                a = __fmaf_rn(M[tri(r, c)], v[c], a);
+            nv[r] = a;
+            big = fmaxf(big, fabsf(a));
+        }
+        const float sc = (big > 0.0f) ? __frcp_rn(big) : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            v[r] = nv[r] * sc;
+    }
+    float len = v[0] * v[0];
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        len = __fmaf_rn(v[i], v[i], len);
+    const bool ok = len > 1e-12f && len < 1e12f; // false for 0 and NaN
+    const float inv = ok ? __frsqrt_rn(len) : 0.0f;
+    e[0] = ok ? v[0] * inv : 1.0f;
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        e[i] = v[i] * inv;
+}
+
+struct Proj2D
+{
+    u32 U[8], V[8];            // int16 pairs: pixel 2k in the low half, 2k+1 in the high half
+    int tU, tV, tUU, tVV, tUV; // sums over all 16 pixels
+};
+
+// Project the block on its two leading principal axes (channels 0..2 only when !use4).
+__device__ __forceinline__ void makeProjection(const u32 (&pix)[16], const BlockScatter &bs, const CvttBc7Args &A,
+                                               bool use4, float scale, Proj2D &P)
+{
+    float M[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+        M[i] = (use4 || i < 6) ? bs.S[i] : 0.0f;
+    float e1[4], e2[4];
+    topEigenvector(M, e1);
+    {
+        // deflate: M -= lambda e1 e1^T
+        float Me[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            float a = M[tri(r, 0)] * e1[0];
+#pragma unroll
+            for (int c = 1; c < 4; c++)
+                a = __fmaf_rn(M[tri(r, c)], e1[c], a);
+            Me[r] = a;
+        }
+        float lam = Me[0] * e1[0];
+#pragma unroll
+        for (int r = 1; r < 4; r++)
+            lam = __fmaf_rn(Me[r], e1[r], lam);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c <= r; c++)
+                M[tri(r, c)] = __fmaf_rn(-lam * e1[r], e1[c], M[tri(r, c)]);
+    }
+    topEigenvector(M, e2);
+    {
+        // Gram-Schmidt against e1; when nothing is left take the coordinate axis e1 leans on least
+        float d = e2[0] * e1[0];
+#pragma unroll
+        for (int i = 1; i < 4; i++)
+            d = __fmaf_rn(e2[i], e1[i], d);
+        float len = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            e2[i] = __fmaf_rn(-d, e1[i], e2[i]);
+            len = __fmaf_rn(e2[i], e2[i], len);
+        }
+        if (!(len > 1e-4f))
+        {
+            int k = 0;
+            float small = fabsf(e1[0]);
+#pragma unroll
+            for (int i = 1; i < 4; i++)
+                if ((use4 || i < 3) && fabsf(e1[i]) < small)
+                {
+                    small = fabsf(e1[i]);
+                    k = i;
+                }
+            const float ek = (k == 0) ? e1[0] : (k == 1) ? e1[1] : (k == 2) ? e1[2] : e1[3];
+            len = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                e2[i] = ((i == k) ? 1.0f : 0.0f) - ek * e1[i];
+                len = __fmaf_rn(e2[i], e2[i], len);
+            }
+        }
+        const float inv = __frsqrt_rn(len);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            e2[i] *= inv;
+    }
+    if (!use4)
+        e1[3] = e2[3] = 0.0f; // already zero up to rounding; keep alpha out exactly
+
+    float g1[4], g2[4];
+    float o1 = 0.0f, o2 = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < 4; ch++)
+    {
+        g1[ch] = e1[ch] * A.w[ch] * scale;
+        g2[ch] = e2[ch] * A.w[ch] * scale;
+        o1 = __fmaf_rn(e1[ch] * scale, bs.meanW[ch], o1);
+        o2 = __fmaf_rn(e2[ch] * scale, bs.meanW[ch], o2);
+    }
+    P.tU = P.tV = P.tUU = P.tVV = P.tUV = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+    {
+        int uu[2], vv[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+        {
+            const u32 pk = fetchPixel(pix[2 * k + h]);
+            float fu = -o1, fv = -o2;
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++)
+            {
+                const float x = byteF(pk, ch);
+                fu = __fmaf_rn(g1[ch], x, fu);
+                fv = __fmaf_rn(g2[ch], x, fv);
+            }
+            // clamping is a projection on a box: it never increases distances either
+            fu = fminf(fmaxf(fu, -2040.0f), 2040.0f);
+            fv = fminf(fmaxf(fv, -2040.0f), 2040.0f);
+            uu[h] = (int)rintf(fu);
+            vv[h] = (int)rintf(fv);
+        }
+        P.U[k] = ((u32)uu[0] & 0xffffu) | ((u32)uu[1] << 16);
+        P.V[k] = ((u32)vv[0] & 0xffffu) | ((u32)vv[1] << 16);
+        P.tU = dot2(P.U[k], 0x00010001u, P.tU);
+        P.tV = dot2(P.V[k], 0x00010001u, P.tV);
+        P.tUU = dot2(P.U[k], P.U[k], P.tUU);
+        P.tVV = dot2(P.V[k], P.V[k], P.tVV);
+        P.tUV = dot2(P.U[k], P.V[k], P.tUV);
+    }
+}
+
+struct Sums2D
+{
+    int n, u, v, uu, vv, uv;
+};
+
+__device__ __forceinline__ void maskedSums(const Proj2D &P, u32 mask, Sums2D &m)
+{
+    m.n = __popc(mask);
+    m.u = m.v = m.uu = m.vv = m.uv = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+    {
+        const u32 lo = (u32)__builtin_amdgcn_sbfe(mask, 2 * k, 1);
+        const u32 hi = (u32)__builtin_amdgcn_sbfe(mask, 2 * k + 1, 1);
+        const u32 sel = (lo & 0x0000ffffu) | (hi & 0xffff0000u);
+        const u32 um = P.U[k] & sel, vm = P.V[k] & sel;
+        m.u = dot2(um, 0x00010001u, m.u);
+        m.v = dot2(vm, 0x00010001u, m.v);
+        m.uu = dot2(um, P.U[k], m.uu);
+        m.vv = dot2(vm, P.V[k], m.vv);
+        m.uv = dot2(um, P.V[k], m.uv);
+    }
+}
+
+// Lower bound on the error of any trial of the subset with sums `m`.  |coordinates| <= 2040 and
+// n <= 16 keep n*sum(uu) and sum(u)^2 below 2^31, so A, B, C are exact; the float steps that
+// follow are protected by relative margins on the large terms.
+__device__ __forceinline__ float subsetBound2D(const Sums2D &m, float invScaleSq, float delta)
+{
+    if (m.n < 2)
+        return 0.0f;
+    const int a = m.n * m.uu - m.u * m.u;
+    const int c = m.n * m.vv - m.v * m.v;
+    const int b = m.n * m.uv - m.u * m.v;
+    const float fa = (float)a, fc = (float)c, fb = (float)b;
+    const float half = (fa + fc) * 0.5f;
+    const float diff = (fa - fc) * 0.5f;
+    const float rad = __fsqrt_rn(__fmaf_rn(diff, diff, fb * fb));
+    const float lam = half * 0.999998f - rad * 1.000002f; // n * scale^2 * (smaller eigenvalue), rounded down
+    const float n = (float)m.n;
+    const float r = lam * invScaleSq / n;
+    float lb = 0.0f;
+    if (r > n * delta * delta)
+        lb = (r - 2.0f * delta * __fsqrt_rn(n * r)) * 0.9999f;
+    return lb > 0.0f ? lb : 0.0f;
+}
+
 } // namespace
 
 // Broadcast the seeds computed by sub-lane `srcSub` of every quad to the whole quad.
@@ -756,12 +1119,19 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                                                         const CvttBc7Args A, const CvttDeviceTables *__restrict__ T,
                                                         const CvttBc7DevicePlan *__restrict__ dplan)
 {
+    __shared__ float s_bound[64][16]; // error lower bound of every partition of the current mode, per block
+    __shared__ u32 s_pix[16][16];     // the 16 blocks of this wave
+    __shared__ u32 s_blkFlags[16];    // wantPCA4 of the block's group
+    __shared__ u32 s_item[16];        // offers of the round: block | partition << 8
+    __shared__ UnitRec s_unit[48];    // PCA seeds per (item, subset)
+    __shared__ u32 s_res[16][3][5];   // best of every subset of the block's offer: error, endpoints, indexes
     const cvttmi_bc7_plan *__restrict__ plan = &dplan->plan;
     const int lane = threadIdx.x;
     const u32 blockIndex = blockIdx.x * 16u + (u32)(lane >> 2);
     const bool valid = blockIndex < A.numBlocks;
     const int c = lane & 3;
 
+    PROF_DECL
     u32 pix[16];
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(blocks + (size_t)(valid ? blockIndex : 0u) * 64u);
@@ -773,6 +1143,12 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             pix[4 * i + 1] = v.y;
             pix[4 * i + 2] = v.z;
             pix[4 * i + 3] = v.w;
+        }
+        if (c == 0)
+        {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                *reinterpret_cast<uint4 *>(&s_pix[lane >> 2][4 * i]) = make_uint4(pix[4 * i], pix[4 * i + 1], pix[4 * i + 2], pix[4 * i + 3]);
         }
     }
 
@@ -796,8 +1172,8 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     // RGBA seeds: PCA over 4 channels when the group has alpha or no RGB modes, otherwise the
     // RGB seeds extended with alpha = 255 (reference BC67.cpp:1113-1144)
     const bool wantPCA4 = anyBlockHasAlpha || !allowRGBModes;
-    const bool anyWantsPCA4 = __ballot(wantPCA4) != 0;
-    const bool anyWantsExpand = __ballot(!wantPCA4) != 0;
+    if (c == 0)
+        s_blkFlags[lane >> 2] = wantPCA4 ? 1u : 0u;
 
     int numRefine = A.refineRounds;
     if (numRefine < 1)
@@ -818,6 +1194,62 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     for (int s = 0; s < 3; s++)
         work.ep[s][0] = work.ep[s][1] = 0;
     work.idxLo = work.idxHi = work.idx2Lo = work.idx2Hi = 0;
+
+    // ------------- whole-block scatter matrix: bounds for mode 6 and the four rotations -------------
+    const bool prune = A.prune != 0;
+    BlockScatter bs;
+    float lbRot[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float lbMode6 = 0.0f;
+    int rotOrder[4] = {0, 1, 2, 3};
+    if (prune)
+    {
+        blockScatter(pix, A, bs);
+        {
+            Moments<4> m;
+#pragma unroll
+            for (int i = 0; i < 10; i++)
+                m.cov[i] = bs.S[i];
+            lbMode6 = shapeErrorLowerBound<4>(m, 16.0f, A.delta4);
+        }
+        // rotation r codes channel r-1 (alpha for r = 0) on its own; the other three share a line
+        {
+            const float s012 = A.wSq[0] + A.wSq[1] + A.wSq[2];
+            const float d0 = A.delta3;
+            const float d1 = 0.5000005f * __fsqrt_rn(s012 - A.wSq[0] + A.wSq[3]) * 1.000001f;
+            const float d2 = 0.5000005f * __fsqrt_rn(s012 - A.wSq[1] + A.wSq[3]) * 1.000001f;
+            const float d3 = 0.5000005f * __fsqrt_rn(s012 - A.wSq[2] + A.wSq[3]) * 1.000001f;
+            lbRot[0] = planeBound(bs, 0, 1, 2, d0);
+            lbRot[1] = planeBound(bs, 1, 2, 3, d1);
+            lbRot[2] = planeBound(bs, 0, 2, 3, d2);
+            lbRot[3] = planeBound(bs, 0, 1, 3, d3);
+        }
+        // search the rotations in the order of their bounds summed over the wave: the likely
+        // winner first, so that the others meet a tight best error
+        float tot[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            float t = valid ? lbRot[r] : 0.0f;
+#pragma unroll
+            for (int step = 1; step < 64; step <<= 1)
+                t += __shfl_xor(t, step);
+            tot[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t)));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            int rank = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (q != r && (tot[q] < tot[r] || (tot[q] == tot[r] && q < r)))
+                    rank++;
+#pragma unroll
+            for (int slot = 0; slot < 4; slot++)
+                if (rank == slot)
+                    rotOrder[slot] = r;
+        }
+    }
+    PROF_MARK(6)
 
     // ================================ dual-plane modes 4,5 ================================
     // reference TryDualPlane, BC67.cpp:1678-1963.  The RGB seeds depend only on the rotation,
@@ -843,19 +1275,29 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 }
             pcaEndpoints<3>(rpix, 0xffffu, lw, -1, uRot);
         }
+        PROF_MARK(0)
 
         int curRotation = 0;
-        for (int cfg = 0; cfg < 12; cfg++)
+        for (int step = 0; step < 12; step++)
         {
-            // cfg order = reference commit order: mode 4 (rot 0: is 0,1; rot 1: ...), then mode 5 rot 0..3
-            const int mode = cfg < 8 ? 4 : 5;
-            const int rotation = cfg < 8 ? (cfg >> 1) : (cfg - 8);
-            const int indexSelector = cfg < 8 ? (cfg & 1) : 0;
+            const int slot = step / 3, which = step - slot * 3;
+            const int rotation = (slot == 0) ? rotOrder[0] : (slot == 1) ? rotOrder[1] : (slot == 2) ? rotOrder[2] : rotOrder[3];
+            // position in the reference's commit order: mode 4 (rot 0: is 0,1; rot 1: ...), then mode 5 rot 0..3
+            const int mode = which < 2 ? 4 : 5;
+            const int indexSelector = which < 2 ? which : 0;
+            const int cfg = which < 2 ? rotation * 2 + which : 8 + rotation;
             int numTweak = (mode == 4) ? plan->mode4SP[rotation][indexSelector] : plan->mode5SP[rotation];
             if (numTweak <= 0)
                 continue;
             if (numTweak > 4)
                 numTweak = 4;
+            if (prune)
+            {
+                // the second plane costs >= 0, the first at least the bound of its three channels
+                const float lb = (rotation == 0) ? lbRot[0] : (rotation == 1) ? lbRot[1] : (rotation == 2) ? lbRot[2] : lbRot[3];
+                if (__ballot(valid && !(lb > work.err)) == 0)
+                    continue;
+            }
 
             if (rotation != curRotation)
             {
@@ -884,6 +1326,8 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                     rrcpW[3] = A.rcpW[ch];
                 }
 
+            PROF_COUNT(0, 16)
+            PROF_COUNT(1, __popcll(__ballot(valid && c == 0 && !(((rotation == 0) ? lbRot[0] : (rotation == 1) ? lbRot[1] : (rotation == 2) ? lbRot[2] : lbRot[3]) > work.err))))
             Unfinished u;
             quadBroadcast(u, uRot, lane, rotation);
             ShapeBest b, bA;
@@ -923,26 +1367,44 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             for (int px = 0; px < 16; px++)
                 pix[px] = rotatePixel(pix[px], curRotation);
         }
+        PROF_MARK(1)
     }
 
     // =========================== single-plane modes 0,1,2,3,6,7 ===========================
-    // reference TrySinglePlane, BC67.cpp:1146-1660.  The (partition, subset) pairs of a mode
-    // form a flat list of shape evaluations; it is consumed in batches of four: sub-lane c
-    // runs the PCA seed search for item 4*batch + c (per-lane shape mask), then the four
-    // items are searched one after the other with the shape wave-uniform.
+    // reference TrySinglePlane, BC67.cpp:1146-1660.  Per mode: the partitions that can still
+    // win (bounds in LDS vs the best error so far) form a wave-uniform survivor list, which is
+    // consumed in batches of four (partition, subset) items: sub-lane c runs the PCA seed search
+    // of item c (per-lane shape mask), then the items are searched one after the other with the
+    // shape wave-uniform.
+    const int blk = lane >> 2;
+    int boundsFor = -1; // which bound set s_bound holds: 0 = two subsets RGBA, 1 = two subsets RGB, 2 = three subsets RGB, 3 = mode 6
+    // static alpha error of the RGB modes, whole block (BC67.cpp:1250-1264)
+    float staticAlphaBlock = 0.0f;
+    if (prune)
+    {
+        u32 acc = 0;
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+        {
+            const int d = 255 - byteI(pix[px], 3);
+            acc = (u32)mad24(d, d, (int)acc);
+        }
+        staticAlphaBlock = ((A.flags & CVTTMI_FLAG_UNIFORM) ? (float)(int)acc : (float)(int)acc * A.wSq[3]) * 0.9999f;
+    }
+
     for (int stageIter = 0; stageIter < 6; stageIter++)
     {
         ModeDesc md;
-        int numSubsets, numPartitions, stage;
+        int numSubsets, numPartitions, stage, boundSet;
         u64 enabled;
         switch (stageIter)
         {
-        case 0: stage = 4; md = {6, 4, 4, 7, 0}; numSubsets = 1; numPartitions = 1; enabled = plan->mode6Enabled ? 1 : 0; break;
-        case 1: stage = 5; md = {7, 2, 4, 5, 6}; numSubsets = 2; numPartitions = 64; enabled = ~0ull; break; // dead mask in the reference (BC67.cpp:1592-1597)
-        case 2: stage = 1; md = {1, 3, 2, 6, 7}; numSubsets = 2; numPartitions = 64; enabled = plan->mode1PartitionEnabled; break;
-        case 3: stage = 3; md = {3, 2, 4, 7, 0}; numSubsets = 2; numPartitions = 64; enabled = plan->mode3PartitionEnabled; break;
-        case 4: stage = 0; md = {0, 3, 4, 4, 5}; numSubsets = 3; numPartitions = 16; enabled = plan->mode0PartitionEnabled; break;
-        default: stage = 2; md = {2, 2, 1, 5, 5}; numSubsets = 3; numPartitions = 64; enabled = plan->mode2PartitionEnabled; break;
+        case 0: stage = 4; md = {6, 4, 4, 7, 0}; numSubsets = 1; numPartitions = 1; boundSet = 3; enabled = plan->mode6Enabled ? 1 : 0; break;
+        case 1: stage = 5; md = {7, 2, 4, 5, 6}; numSubsets = 2; numPartitions = 64; boundSet = 0; enabled = ~0ull; break; // dead mask in the reference (BC67.cpp:1592-1597)
+        case 2: stage = 1; md = {1, 3, 2, 6, 7}; numSubsets = 2; numPartitions = 64; boundSet = 1; enabled = plan->mode1PartitionEnabled; break;
+        case 3: stage = 3; md = {3, 2, 4, 7, 0}; numSubsets = 2; numPartitions = 64; boundSet = 1; enabled = plan->mode3PartitionEnabled; break;
+        case 4: stage = 0; md = {0, 3, 4, 4, 5}; numSubsets = 3; numPartitions = 16; boundSet = 2; enabled = plan->mode0PartitionEnabled & 0xffffull; break;
+        default: stage = 2; md = {2, 2, 1, 5, 5}; numSubsets = 3; numPartitions = 64; boundSet = 2; enabled = plan->mode2PartitionEnabled; break;
         }
         const int mode = md.mode;
         const bool isRGB = mode < 4;
@@ -951,241 +1413,272 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
         if (__ballot(laneRuns) == 0 || enabled == 0)
             continue;
 
-        const int numItems = numPartitions * numSubsets;
-        float totalError = 0.0f;
-        u32 pe00 = 0, pe01 = 0, pe10 = 0, pe11 = 0, pe20 = 0, pe21 = 0;
-        u32 pIdxLo = 0, pIdxHi = 0;
-
-        int deadPartition = -1; // partition proven unable to win (skipped from here on)
-
-        for (int batch = 0; batch * 4 < numItems; batch++)
+        // ---- bounds of every partition of this mode (shared by the modes with the same subsets/channels) ----
+        if (prune)
         {
-            // ---- phase A: moments (and the error lower bound) of up to four items, one per sub-lane ----
-            Moments<3> m3;
-            Moments<4> m4;
-            u32 myMask = 0;
-            bool do3 = false, do4 = false, expandAlpha = false;
-            float lbMine = 0.0f;
+            if (boundsFor != boundSet)
             {
-                const int item = batch * 4 + c;
-                int partition, sub;
-                if (numSubsets == 1) { partition = item; sub = 0; }
-                else if (numSubsets == 2) { partition = item >> 1; sub = item & 1; }
-                else { partition = item / 3; sub = item - partition * 3; }
-                const bool live = item < numItems && ((enabled >> partition) & 1ull) != 0;
-                int shape = 0;
-                if (live)
+                __syncthreads();
+                if (boundSet == 3)
                 {
-                    if (numSubsets == 2)
-                        shape = T->shapes2[partition][sub];
-                    else if (numSubsets == 3)
-                        shape = T->shapes3[partition][sub];
+                    if (c == 0)
+                        s_bound[0][blk] = lbMode6;
                 }
-                myMask = T->shapeMask[shape];
-                const int seeds = isRGB ? plan->seedPointsForShapeRGB[shape] : plan->seedPointsForShapeRGBA[shape];
+                else
+                {
+                    const bool use4 = (boundSet == 0);
+                    const float wsum = A.wSq[0] + A.wSq[1] + A.wSq[2] + (use4 ? A.wSq[3] : 0.0f);
+                    const float scale = 2000.0f / (255.0f * __fsqrt_rn(wsum));
+                    const float invScaleSq = 1.0f / (scale * scale);
+                    // rounding the projected points moves each by at most sqrt(2)/2 grid units
+                    const float delta = (use4 ? A.delta4 : A.delta3) + 0.7072f / scale;
+                    Proj2D P;
+                    makeProjection(pix, bs, A, use4, scale, P);
+                    for (int k = 0; k < 16; k++)
+                    {
+                        const int partition = 4 * k + c;
+                        float lb;
+                        if (boundSet < 2)
+                        {
+                            Sums2D s1, s0;
+                            maskedSums(P, T->shapeMask[T->shapes2[partition][1]], s1);
+                            s0.n = 16 - s1.n;
+                            s0.u = P.tU - s1.u;
+                            s0.v = P.tV - s1.v;
+                            s0.uu = P.tUU - s1.uu;
+                            s0.vv = P.tVV - s1.vv;
+                            s0.uv = P.tUV - s1.uv;
+                            lb = subsetBound2D(s0, invScaleSq, delta) + subsetBound2D(s1, invScaleSq, delta);
+                        }
+                        else
+                        {
+                            Sums2D s1, s2, s0;
+                            maskedSums(P, T->shapeMask[T->shapes3[partition][1]], s1);
+                            maskedSums(P, T->shapeMask[T->shapes3[partition][2]], s2);
+                            s0.n = 16 - s1.n - s2.n;
+                            s0.u = P.tU - s1.u - s2.u;
+                            s0.v = P.tV - s1.v - s2.v;
+                            s0.uu = P.tUU - s1.uu - s2.uu;
+                            s0.vv = P.tVV - s1.vv - s2.vv;
+                            s0.uv = P.tUV - s1.uv - s2.uv;
+                            lb = subsetBound2D(s0, invScaleSq, delta) + subsetBound2D(s1, invScaleSq, delta) +
+                                 subsetBound2D(s2, invScaleSq, delta);
+                        }
+                        if (!use4)
+                            lb += staticAlphaBlock;
+                        s_bound[partition][blk] = lb;
+                    }
+                }
+                __syncthreads();
+                boundsFor = boundSet;
+            }
+        }
+        PROF_MARK(2)
+
+        // ---- every block offers its cheapest-bound candidate partition per round, until the bound
+        // of the next one exceeds its best error.  Sub-lane c keeps the candidates 4k+c.
+        // The offers of a round are searched by the whole wave: one lane per chain. ----
+        const int CP = md.numP * 4;         // chains per subset: p-bit combinations x seed points
+        const int UPB = 64 / CP;            // subsets searched at once
+        u32 aliveBits = 0;
+        for (int k = 0; k * 4 < numPartitions; k++)
+        {
+            const int partition = 4 * k + c;
+            bool alive = valid && laneRuns && partition < numPartitions && ((enabled >> partition) & 1ull) != 0;
+            if (mode == 7 && anyBlockHasAlpha && !blockHasNonMaxAlpha && ((mode7RGB >> partition) & 1ull) == 0)
+                alive = false; // BC67.cpp:1625-1635: this lane may not take the partition
+            if (prune && alive)
+                alive = !(s_bound[partition][blk] > work.err);
+            aliveBits |= alive ? (1u << k) : 0u;
+        }
+
+        for (;;)
+        {
+            // quad-wide argmin of the bounds still alive (ties: lowest partition)
+            float pickLb = FLT_MAX;
+            int pick = 255;
+            for (int k = 0; k * 4 < numPartitions; k++)
+            {
+                if ((aliveBits >> k) & 1u)
+                {
+                    const float lb = prune ? s_bound[4 * k + c][blk] : 0.0f;
+                    if (lb < pickLb)
+                    {
+                        pickLb = lb;
+                        pick = 4 * k + c;
+                    }
+                }
+            }
+#pragma unroll
+            for (int step = 1; step <= 2; step <<= 1)
+            {
+                const float oLb = __shfl_xor(pickLb, step);
+                const int oPick = __shfl_xor(pick, step);
+                const bool take = (oLb < pickLb) || (oLb == pickLb && oPick < pick);
+                pickLb = take ? oLb : pickLb;
+                pick = take ? oPick : pick;
+            }
+            const bool go = pick < 64 && !(pickLb > work.err);
+            if (!go)
+                aliveBits = 0; // everything left costs even more
+            const u64 goBallot = __ballot(go && c == 0);
+            if (goBallot == 0)
+                break;
+            const int partition = go ? pick : 0;
+            if (go && (pick & 3) == c)
+                aliveBits &= ~(1u << (pick >> 2));
+
+            // ---- the round's items: (block, partition), compacted ----
+            const int numItems = __popcll(goBallot);
+            const int numUnits = numItems * numSubsets;
+            if (go && c == 0)
+                s_item[__popcll(goBallot & ((1ull << lane) - 1ull))] = (u32)blk | ((u32)partition << 8);
+            __syncthreads();
+
+            // ---- PCA seed search: lane l takes unit l = (item, subset) ----
+            if (lane < numUnits)
+            {
+                const int item = (numSubsets == 1) ? lane : (numSubsets == 2) ? (lane >> 1) : (lane / 3);
+                const int sub = lane - item * numSubsets;
+                const u32 it = s_item[item];
+                const int ublk = (int)(it & 255u), upart = (int)(it >> 8);
+                int shape = 0;
+                if (numSubsets == 2)
+                    shape = T->shapes2[upart][sub];
+                else if (numSubsets == 3)
+                    shape = T->shapes3[upart][sub];
+                const u32 uMask = T->shapeMask[shape];
+                int seeds = isRGB ? plan->seedPointsForShapeRGB[shape] : plan->seedPointsForShapeRGBA[shape];
+                if (seeds > 4)
+                    seeds = 4;
                 const bool rgbListed = ((dplan->rgbListed[shape >> 5] >> (shape & 31)) & 1u) != 0;
                 const bool rgbaListed = isRGB ? true : (((dplan->rgbaListed[shape >> 5] >> (shape & 31)) & 1u) != 0);
-                const bool wanted = live && seeds != 0;
-                // which PCA does this lane need?  (BC67.cpp:1085-1144; unlisted shapes keep zero seeds)
-                do4 = wanted && !isRGB && wantPCA4 && rgbaListed;
-                do3 = wanted && rgbListed && (isRGB || (!wantPCA4 && rgbaListed));
-                expandAlpha = !isRGB && wanted && !wantPCA4 && rgbaListed;
-                const float n = (float)__popc(myMask);
-                if (__ballot(do3) != 0)
-                {
-                    pcaMoments<3>(pix, do3 ? myMask : 0u, A.w, m3);
-                    if (do3 && A.prune)
-                        lbMine = shapeErrorLowerBound<3>(m3, n, isRGB ? A.delta3 : A.delta4);
-                }
-                if (__ballot(do4) != 0)
-                {
-                    pcaMoments<4>(pix, do4 ? myMask : 0u, A.w, m4);
-                    if (do4 && A.prune)
-                        lbMine = shapeErrorLowerBound<4>(m4, n, A.delta4);
-                }
-                if (isRGB && wanted && A.prune)
-                {
-                    // the RGB modes add the exact error of replacing alpha by 255 (BC67.cpp:1250-1264)
-                    u32 acc = 0;
+                const bool uWantPCA4 = s_blkFlags[ublk] != 0;
+                const bool wanted = seeds > 0;
+                // which PCA does this unit need?  (BC67.cpp:1085-1144; unlisted shapes keep zero seeds)
+                const bool do4 = wanted && !isRGB && uWantPCA4 && rgbaListed;
+                const bool do3 = wanted && rgbListed && (isRGB || (!uWantPCA4 && rgbaListed));
+                const bool expandAlpha = !isRGB && wanted && !uWantPCA4 && rgbaListed;
+                Unfinished uu;
 #pragma unroll
-                    for (int px = 0; px < 16; px++)
-                        if ((myMask >> px) & 1u)
-                        {
-                            const int d = 255 - byteI(pix[px], 3);
-                            acc = (u32)mad24(d, d, (int)acc);
-                        }
-                    const float st = (A.flags & CVTTMI_FLAG_UNIFORM) ? (float)(int)acc : (float)(int)acc * A.wSq[3];
-                    lbMine = lbMine + st;
-                }
-                if (live && seeds == 0)
-                    lbMine = FLT_MAX; // its error stays FLT_MAX (BC67.cpp:1228-1242)
-                if (!live)
-                    lbMine = 0.0f;
-            }
-
-            // ---- phase B: which items can still win?  bound = errors already known for the
-            // partition + lower bounds of its items in this batch; wave-uniform decisions ----
-            bool pruneItem[4];
-            float lbItem[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                lbItem[j] = __shfl(lbMine, (lane & ~3) | j);
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-            {
-                pruneItem[j] = false;
-                const int item = batch * 4 + j;
-                if (A.prune && item < numItems)
-                {
-                    int partition, sub;
-                    if (numSubsets == 1) { partition = item; sub = 0; }
-                    else if (numSubsets == 2) { partition = item >> 1; sub = item & 1; }
-                    else { partition = item / 3; sub = item - partition * 3; }
-                    // items of the same partition inside this batch: [jLo, jHi]
-                    int jLo = j - sub;
-                    int jHi = jLo + numSubsets - 1;
-                    float bound = (jLo < 0) ? totalError : 0.0f; // earlier subsets came with previous batches
-                    if (jLo < 0) jLo = 0;
-                    if (jHi > 3) jHi = 3;
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        if (i >= jLo && i <= jHi)
-                            bound = bound + lbItem[i];
-                    bound = bound * 0.999999f;
-                    const bool cannotWin = bound > work.err;
-                    pruneItem[j] = __ballot(valid && laneRuns && !cannotWin) == 0;
-                }
-            }
-
-            // ---- phase C: finish the seed search of the items that survive ----
-            Unfinished uMine;
-#pragma unroll
-            for (int ch = 0; ch < 4; ch++)
-                uMine.base[ch] = uMine.offset[ch] = 0.0f;
-            {
-                const bool myPruned = (c == 0) ? pruneItem[0] : (c == 1) ? pruneItem[1] : (c == 2) ? pruneItem[2] : pruneItem[3];
-                const bool fin3 = do3 && !myPruned, fin4 = do4 && !myPruned;
-                if (__ballot(fin3) != 0)
+                for (int ch = 0; ch < 4; ch++)
+                    uu.base[ch] = uu.offset[ch] = 0.0f;
+                const u32 *lp = &s_pix[ublk][0];
+                if (do3)
                 {
                     Unfinished u3;
-                    pcaFinish<3>(pix, fin3 ? myMask : 0u, A.w, m3, u3);
-                    if (fin3)
-                    {
+                    pcaEndpointsLDS<3>(lp, uMask, A.w, u3);
 #pragma unroll
-                        for (int ch = 0; ch < 3; ch++)
-                        {
-                            uMine.base[ch] = u3.base[ch];
-                            uMine.offset[ch] = u3.offset[ch];
-                        }
+                    for (int ch = 0; ch < 3; ch++)
+                    {
+                        uu.base[ch] = u3.base[ch];
+                        uu.offset[ch] = u3.offset[ch];
                     }
                 }
                 if (expandAlpha)
                 {
-                    uMine.base[3] = 255.0f; // ExpandTo<4>(255), UnfinishedEndpoints.h:93-114
-                    uMine.offset[3] = 0.0f;
+                    uu.base[3] = 255.0f; // ExpandTo<4>(255), UnfinishedEndpoints.h:93-114
+                    uu.offset[3] = 0.0f;
                 }
-                if (__ballot(fin4) != 0)
+                if (do4)
+                    pcaEndpointsLDS<4>(lp, uMask, A.w, uu);
+                UnitRec &r = s_unit[lane];
+#pragma unroll
+                for (int ch = 0; ch < 4; ch++)
                 {
-                    Unfinished u4;
-                    pcaFinish<4>(pix, fin4 ? myMask : 0u, A.w, m4, u4);
-                    if (fin4)
-                        uMine = u4;
+                    r.base[ch] = uu.base[ch];
+                    r.offset[ch] = uu.offset[ch];
                 }
+                r.mask = uMask;
+                r.numTweak = seeds;
+                r.blk = ublk;
+                r.sub = sub;
             }
+            __syncthreads();
+            PROF_MARK(3)
 
-            // ---- phase D: search the four items ----
-            for (int j = 0; j < 4; j++)
+            // ---- chains: lane l of a batch = (unit l / CP, p-bits (l % CP) / 4, seed point l % 4) ----
+            for (int u0 = 0; u0 < numUnits; u0 += UPB)
             {
-                const int item = batch * 4 + j;
-                if (item >= numItems)
-                    break;
-                int partition, sub;
-                if (numSubsets == 1) { partition = item; sub = 0; }
-                else if (numSubsets == 2) { partition = item >> 1; sub = item & 1; }
-                else { partition = item / 3; sub = item - partition * 3; }
-                if (((enabled >> partition) & 1ull) == 0)
-                    continue;
-                const bool prunedNow = (j == 0) ? pruneItem[0] : (j == 1) ? pruneItem[1] : (j == 2) ? pruneItem[2] : pruneItem[3];
-                if (prunedNow)
-                    deadPartition = partition;
-                if (partition == deadPartition)
-                    continue;
-
-                int shape = 0;
-                if (numSubsets == 2)
-                    shape = T->shapes2[partition][sub];
-                else if (numSubsets == 3)
-                    shape = T->shapes3[partition][sub];
-                const u32 mask = T->shapeMask[shape];
-                int numTweak = isRGB ? plan->seedPointsForShapeRGB[shape] : plan->seedPointsForShapeRGBA[shape];
-                if (numTweak > 4)
-                    numTweak = 4;
-
-                if (sub == 0)
+                const int unit = u0 + lane / CP;
+                const int chain = lane & (CP - 1);
+                const bool inRange = unit < numUnits;
+                const UnitRec &r = s_unit[inRange ? unit : 0];
+                const int tweak = chain & 3, pIter = chain >> 2;
+                const u32 uMask = r.mask;
+                const bool active = inRange && tweak < r.numTweak;
+                int maxCount = active ? __popc(uMask) : 0;
+#pragma unroll
+                for (int step = 1; step < 64; step <<= 1)
                 {
-                    totalError = 0.0f;
-                    pIdxLo = pIdxHi = 0;
+                    const int o = __shfl_xor(maxCount, step);
+                    maxCount = o > maxCount ? o : maxCount;
                 }
+                maxCount = __builtin_amdgcn_readfirstlane(maxCount);
+                Unfinished uu;
+#pragma unroll
+                for (int ch = 0; ch < 4; ch++)
+                {
+                    uu.base[ch] = r.base[ch];
+                    uu.offset[ch] = r.offset[ch];
+                }
+                const u32 *lp = &s_pix[r.blk][0];
+                PROF_COUNT(2, 64)
+                PROF_COUNT(3, __popcll(__ballot(active)))
                 ShapeBest b;
-                if (numTweak <= 0)
-                {
-                    b.err = FLT_MAX; // shapeBestError stays at its reset value (BC67.cpp:1228-1242)
-                    b.ep0 = b.ep1 = b.idxLo = b.idxHi = 0;
-                }
+                if (isRGB)
+                    evalChain<3, FAST>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b);
                 else
+                    evalChain<4, FAST>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b);
+                groupArgminBroadcast(b, lane, CP);
+                if (inRange && chain == 0)
                 {
-                    Unfinished u;
-                    quadBroadcast(u, uMine, lane, j);
-#ifndef CVTT_EXP_NO_RGB
-                    if (isRGB)
-                        evalShape<3, FAST>(pix, mask, md, u, numTweak, A, T, numRefine, lane, b);
-                    else
-#endif
-                        evalShape<4, FAST>(pix, mask, md, u, numTweak, A, T, numRefine, lane, b);
-                }
-                totalError = totalError + b.err;
-                if (sub == 0) { pe00 = b.ep0; pe01 = b.ep1; }
-                else if (sub == 1) { pe10 = b.ep0; pe11 = b.ep1; }
-                else { pe20 = b.ep0; pe21 = b.ep1; }
-                pIdxLo |= b.idxLo;
-                pIdxHi |= b.idxHi;
-
-                if (sub == numSubsets - 1)
-                {
-                    const int seq = stage * 64 + partition;
-                    bool better = laneRuns && (totalError < work.err || (totalError == work.err && seq < workSeq));
-                    if (mode == 7 && anyBlockHasAlpha)
-                    {
-                        // lanes without alpha may only take partitions enabled for RGB (BC67.cpp:1625-1635)
-                        const bool rgbAllowed = ((mode7RGB >> partition) & 1ull) != 0;
-                        if (!rgbAllowed)
-                            better = better && blockHasNonMaxAlpha;
-                    }
-                    if (better)
-                    {
-                        work.err = totalError;
-                        workSeq = seq;
-                        work.mode = mode;
-                        work.partOrIS = partition;
-                        work.ep[0][0] = pe00;
-                        work.ep[0][1] = pe01;
-                        work.ep[1][0] = pe10;
-                        work.ep[1][1] = pe11;
-                        work.ep[2][0] = pe20;
-                        work.ep[2][1] = pe21;
-                        work.idxLo = pIdxLo;
-                        work.idxHi = pIdxHi;
-                    }
-                }
-                else if (A.prune)
-                {
-                    // the partition already costs more than the best: its remaining subsets
-                    // cannot bring it back (errors are >= 0)
-                    const bool cannotWin = totalError * 0.999999f > work.err;
-                    if (__ballot(valid && laneRuns && !cannotWin) == 0)
-                        deadPartition = partition;
+                    // with no seed points the shape keeps its reset error FLT_MAX (BC67.cpp:1228-1242)
+                    u32 *dst = &s_res[r.blk][r.sub][0];
+                    dst[0] = __builtin_bit_cast(u32, b.err);
+                    dst[1] = b.ep0;
+                    dst[2] = b.ep1;
+                    dst[3] = b.idxLo;
+                    dst[4] = b.idxHi;
                 }
             }
+            __syncthreads();
+
+            // ---- every offering block adds up its subsets and commits ----
+            if (go)
+            {
+                float totalError = 0.0f;
+                u32 pe[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+                u32 pIdxLo = 0, pIdxHi = 0;
+                for (int sub = 0; sub < numSubsets; sub++)
+                {
+                    const u32 *src = &s_res[blk][sub][0];
+                    totalError = totalError + __builtin_bit_cast(float, src[0]);
+                    const u32 e0 = src[1], e1 = src[2];
+                    if (sub == 0) { pe[0][0] = e0; pe[0][1] = e1; }
+                    else if (sub == 1) { pe[1][0] = e0; pe[1][1] = e1; }
+                    else { pe[2][0] = e0; pe[2][1] = e1; }
+                    pIdxLo |= src[3];
+                    pIdxHi |= src[4];
+                }
+                const int seq = stage * 64 + partition;
+                if (totalError < work.err || (totalError == work.err && seq < workSeq))
+                {
+                    work.err = totalError;
+                    workSeq = seq;
+                    work.mode = mode;
+                    work.partOrIS = partition;
+#pragma unroll
+                    for (int sub = 0; sub < 3; sub++)
+                    {
+                        work.ep[sub][0] = pe[sub][0];
+                        work.ep[sub][1] = pe[sub][1];
+                    }
+                    work.idxLo = pIdxLo;
+                    work.idxHi = pIdxHi;
+                }
+            }
+            PROF_MARK(4)
         }
     }
 
@@ -1377,6 +1870,8 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             *reinterpret_cast<uint4 *>(out + (size_t)blockIndex * 16u) = o;
         }
     }
+    PROF_MARK(5)
+    PROF_FLUSH
 }
 
 extern "C" hipError_t cvttmi_launch_bc7(const void *d_blocks, void *d_out, const CvttBc7Args *args,
