@@ -221,8 +221,9 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
             {
                 origin[ch] = (float)ep[0][ch];
                 epDW[ch] = ((float)ep[1][ch] - origin[ch]) * A.w[ch];
-                recBase[ch] = (ep[0][ch] << 6) + 32;
-                recDelta[ch] = ep[1][ch] - ep[0][ch];
+                // scaled by 4: the reconstructed value (x >> 6) is then byte 1 of the sum
+                recBase[ch] = ((ep[0][ch] << 6) + 32) << 2;
+                recDelta[ch] = (ep[1][ch] - ep[0][ch]) << 2;
             }
             float lenSq = epDW[0] * epDW[0];
 #pragma unroll
@@ -235,9 +236,12 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
                 axis[ch] = epDW[ch] * A.w[ch] * mvdls;
         }
 
+        const v2f org01 = {origin[0], origin[1]}, org23 = {origin[2], origin[3]};
+        const v2f ax01 = {axis[0], axis[1]}, ax23 = {axis[2], axis[3]};
+        const v2f w01 = {A.w[0], A.w[1]}, w23 = {A.w[2], A.w[3]};
         u32 err[4] = {0, 0, 0, 0};
         float slowErr = 0.0f;
-        float tv[4] = {0, 0, 0, 0}, vs[4] = {0, 0, 0, 0};
+        v2f tv01 = {0.0f, 0.0f}, tv23 = {0.0f, 0.0f}, vs01 = {0.0f, 0.0f}, vs23 = {0.0f, 0.0f};
         float tt = 0.0f, ts = 0.0f;
         u64 idx = 0;
         u32 rem = mask;
@@ -250,10 +254,11 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
                 rem &= rem - 1;
                 const u32 pk = lp[px];
                 // SelectIndexLDR (reference IndexSelector.h:124-131)
-                float dist = (byteF(pk, 0) - origin[0]) * axis[0];
-#pragma unroll
-                for (int ch = 1; ch < 4; ch++)
-                    dist = dist + (byteF(pk, ch) - origin[ch]) * axis[ch];
+                const v2f x01 = {byteF(pk, 0), byteF(pk, 1)}, x23 = {byteF(pk, 2), byteF(pk, 3)};
+                const v2f p01 = (x01 - org01) * ax01, p23 = (x23 - org23) * ax23;
+                float dist = p01.x + p01.y;
+                dist = dist + p23.x;
+                dist = dist + p23.y;
                 float fidx = clampRound(dist, maxValue);
                 int index = (int)fidx;
 
@@ -261,13 +266,11 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
                 {
                     // ReconstructLDR_BC7 + ComputeErrorLDR (IndexSelector.h:90-100, BCCommon.h:24-29)
                     const int wgt = mad24(weightRcp, index, 256) >> 9;
-#pragma unroll
-                    for (int ch = 0; ch < NRC; ch++)
-                    {
-                        const int rec = mad24(wgt, recDelta[ch], recBase[ch]) >> 6;
-                        const int d = rec - byteI(pk, ch);
-                        err[ch] = (u32)mad24(d, d, (int)err[ch]);
-                    }
+                    err[0] = accumulateChannelError<0>(wgt, recDelta[0], recBase[0], pk, err[0]);
+                    err[1] = accumulateChannelError<1>(wgt, recDelta[1], recBase[1], pk, err[1]);
+                    err[2] = accumulateChannelError<2>(wgt, recDelta[2], recBase[2], pk, err[2]);
+                    if (NRC == 4)
+                        err[3] = accumulateChannelError<3>(wgt, recDelta[3], recBase[3], pk, err[3]);
                 }
                 else
                 {
@@ -281,13 +284,11 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
                         if (probe == 2) cand = (index + 1 < range - 1) ? index + 1 : range - 1;
                         const int wgt = mad24(weightRcp, cand, 256) >> 9;
                         u32 e4[4] = {0, 0, 0, 0};
-#pragma unroll
-                        for (int ch = 0; ch < NRC; ch++)
-                        {
-                            const int rec = mad24(wgt, recDelta[ch], recBase[ch]) >> 6;
-                            const int d = rec - byteI(pk, ch);
-                            e4[ch] = (u32)__mul24(d, d);
-                        }
+                        e4[0] = channelError<0>(wgt, recDelta[0], recBase[0], pk);
+                        e4[1] = channelError<1>(wgt, recDelta[1], recBase[1], pk);
+                        e4[2] = channelError<2>(wgt, recDelta[2], recBase[2], pk);
+                        if (NRC == 4)
+                            e4[3] = channelError<3>(wgt, recDelta[3], recBase[3], pk);
                         float e;
                         if (uniformErr)
                             e = (float)(int)(e4[0] + e4[1] + e4[2] + e4[3]);
@@ -317,13 +318,12 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
                 {
                     // EndpointRefiner::ContributeUnweightedPW (EndpointRefiner.h:78-92)
                     const float t = fidx * rcpMaxIndex;
-#pragma unroll
-                    for (int ch = 0; ch < NRC; ch++)
-                    {
-                        const float v = byteF(pk, ch) * A.w[ch];
-                        tv[ch] = tv[ch] + t * v;
-                        vs[ch] = vs[ch] + v;
-                    }
+                    const v2f t2 = {t, t};
+                    const v2f v01 = x01 * w01, v23 = x23 * w23; // channel 3 is unused when NRC == 3
+                    tv01 = tv01 + t2 * v01;
+                    tv23 = tv23 + t2 * v23;
+                    vs01 = vs01 + v01;
+                    vs23 = vs23 + v23;
                     tt = tt + t * t;
                     ts = ts + t;
                 }
@@ -362,6 +362,7 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
         if (!last)
         {
             // EndpointRefiner::GetRefinedEndpointsLDR (EndpointRefiner.h:99-152)
+            const float tv[4] = {tv01.x, tv01.y, tv23.x, tv23.y}, vs[4] = {vs01.x, vs01.y, vs23.x, vs23.y};
             float adenom = (tt * wCount - ts * ts) * wRcp;
             const bool adenomZero = (adenom == 0.0f);
             if (adenomZero)
@@ -443,7 +444,7 @@ struct UnitRec
     u32 mask;
     int numTweak;
     int blk;
-    int sub;
+    int slot; // item * 3 + subset: where the subset's result goes
 };
 
 // 128-bit little-endian bit writer (reference PackingVector, BC67.cpp:652-698)
@@ -589,42 +590,42 @@ __device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int ind
 #pragma unroll
                 for (int ch = 0; ch < 4; ch++)
                 {
-                    recBase[ch] = (ep[0][ch] << 6) + 32;
-                    recDelta[ch] = ep[1][ch] - ep[0][ch];
+                    // scaled by 4: the reconstructed value (x >> 6) is then byte 1 of the sum
+                    recBase[ch] = ((ep[0][ch] << 6) + 32) << 2;
+                    recDelta[ch] = (ep[1][ch] - ep[0][ch]) << 2;
                 }
             }
+            const v2f org01 = {origin[0], origin[1]}, org23 = {origin[2], origin[3]};
+            const v2f ax01 = {axis[0], axis[1]}, ax23 = {axis[2], axis[3]};
+            const v2f w01 = {rw[0], rw[1]}, w23 = {rw[2], 1.0f};
+            const v2f rcpMax2 = {rgbRcpMax, alphaRcpMax};
 
             u32 err[4] = {0, 0, 0, 0};
             float slowRGB = 0.0f, slowA = 0.0f;
-            float tv[4] = {0, 0, 0, 0}, vs[4] = {0, 0, 0, 0};
-            float ttRGB = 0.0f, tsRGB = 0.0f, ttA = 0.0f, tsA = 0.0f;
+            v2f tv01 = {0.0f, 0.0f}, tv23 = {0.0f, 0.0f}, vs01 = {0.0f, 0.0f}, vs23 = {0.0f, 0.0f};
+            v2f tt2 = {0.0f, 0.0f}, ts2 = {0.0f, 0.0f}; // {RGB plane, alpha plane}
             u32 rgbLo = 0, rgbHi = 0, aLo = 0, aHi = 0;
 
 #pragma unroll
             for (int px = 0; px < 16; px++)
             {
                 const u32 pk = fetchPixel(pix[px]);
-                float dist = (byteF(pk, 0) - origin[0]) * axis[0];
-                dist = dist + (byteF(pk, 1) - origin[1]) * axis[1];
-                dist = dist + (byteF(pk, 2) - origin[2]) * axis[2];
+                const v2f x01 = {byteF(pk, 0), byteF(pk, 1)}, x23 = {byteF(pk, 2), byteF(pk, 3)};
+                const v2f p01 = (x01 - org01) * ax01, p23 = (x23 - org23) * ax23;
+                float dist = p01.x + p01.y;
+                dist = dist + p23.x;
                 float fRGB = clampRound(dist, rgbMax);
-                float fA = clampRound((byteF(pk, 3) - origin[3]) * axis[3], alphaMaxV);
+                float fA = clampRound(p23.y, alphaMaxV);
                 int iRGB = (int)fRGB, iA = (int)fA;
 
                 if (FAST)
                 {
                     const int wgt = mad24(rgbWR, iRGB, 256) >> 9;
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++)
-                    {
-                        const int rec = mad24(wgt, recDelta[ch], recBase[ch]) >> 6;
-                        const int d = rec - byteI(pk, ch);
-                        err[ch] = (u32)mad24(d, d, (int)err[ch]);
-                    }
+                    err[0] = accumulateChannelError<0>(wgt, recDelta[0], recBase[0], pk, err[0]);
+                    err[1] = accumulateChannelError<1>(wgt, recDelta[1], recBase[1], pk, err[1]);
+                    err[2] = accumulateChannelError<2>(wgt, recDelta[2], recBase[2], pk, err[2]);
                     const int wa = mad24(alphaWR, iA, 256) >> 9;
-                    const int recA = mad24(wa, recDelta[3], recBase[3]) >> 6;
-                    const int dA = recA - byteI(pk, 3);
-                    err[3] = (u32)mad24(dA, dA, (int)err[3]);
+                    err[3] = accumulateChannelError<3>(wa, recDelta[3], recBase[3], pk, err[3]);
                 }
                 else
                 {
@@ -646,17 +647,11 @@ __device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int ind
                         }
                         const int wgt = mad24(rgbWR, candRGB, 256) >> 9;
                         u32 e3[3];
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++)
-                        {
-                            const int rec = mad24(wgt, recDelta[ch], recBase[ch]) >> 6;
-                            const int d = rec - byteI(pk, ch);
-                            e3[ch] = (u32)__mul24(d, d);
-                        }
+                        e3[0] = channelError<0>(wgt, recDelta[0], recBase[0], pk);
+                        e3[1] = channelError<1>(wgt, recDelta[1], recBase[1], pk);
+                        e3[2] = channelError<2>(wgt, recDelta[2], recBase[2], pk);
                         const int wa = mad24(alphaWR, candA, 256) >> 9;
-                        const int recA = mad24(wa, recDelta[3], recBase[3]) >> 6;
-                        const int dA = recA - byteI(pk, 3);
-                        const u32 e1 = (u32)__mul24(dA, dA);
+                        const u32 e1 = channelError<3>(wa, recDelta[3], recBase[3], pk);
                         float er, ea;
                         if (uniformErr)
                         {
@@ -692,22 +687,17 @@ __device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int ind
 
                 if (!last)
                 {
-                    const float t = fRGB * rgbRcpMax;
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++)
-                    {
-                        const float v = byteF(pk, ch) * rw[ch];
-                        tv[ch] = tv[ch] + t * v;
-                        vs[ch] = vs[ch] + v;
-                    }
-                    ttRGB = ttRGB + t * t;
-                    tsRGB = tsRGB + t;
-                    const float ta = fA * alphaRcpMax;
-                    const float va = byteF(pk, 3);
-                    tv[3] = tv[3] + ta * va;
-                    vs[3] = vs[3] + va;
-                    ttA = ttA + ta * ta;
-                    tsA = tsA + ta;
+                    // EndpointRefiner<3> with the rotated weights and EndpointRefiner<1> with weight 1
+                    const v2f f2 = {fRGB, fA};
+                    const v2f t2 = f2 * rcpMax2;
+                    const v2f tt = {t2.x, t2.x};
+                    const v2f v01 = x01 * w01, v23 = x23 * w23;
+                    tv01 = tv01 + tt * v01;
+                    tv23 = tv23 + t2 * v23;
+                    vs01 = vs01 + v01;
+                    vs23 = vs23 + v23;
+                    tt2 = tt2 + t2 * t2;
+                    ts2 = ts2 + t2;
                 }
                 if (px < 8)
                 {
@@ -764,6 +754,8 @@ __device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int ind
             {
                 // EndpointRefiner<3> / <1>::GetRefinedEndpointsLDR, 16 contributions each
                 {
+                    const float tv[4] = {tv01.x, tv01.y, tv23.x, tv23.y}, vs[4] = {vs01.x, vs01.y, vs23.x, vs23.y};
+                    const float ttRGB = tt2.x, tsRGB = ts2.x;
                     float adenom = (ttRGB * 16.0f - tsRGB * tsRGB) * wRcp16;
                     const bool z = (adenom == 0.0f);
                     if (z) adenom = 1.0f;
@@ -783,6 +775,8 @@ __device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int ind
                     }
                 }
                 {
+                    const float tv[4] = {tv01.x, tv01.y, tv23.x, tv23.y}, vs[4] = {vs01.x, vs01.y, vs23.x, vs23.y};
+                    const float ttA = tt2.y, tsA = ts2.y;
                     float adenom = (ttA * 16.0f - tsA * tsA) * wRcp16;
                     const bool z = (adenom == 0.0f);
                     if (z) adenom = 1.0f;
@@ -913,7 +907,7 @@ __device__ __forceinline__ void topEigenvector(const float (&M)[10], float (&e)[
             nv[r] = a;
             big = fmaxf(big, fabsf(a));
         }
-        const float sc = (big > 0.0f) ? __frcp_rn(big) : 0.0f;
+        const float sc = (big > 0.0f) ? __builtin_amdgcn_rcpf(big) : 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; r++)
             v[r] = nv[r] * sc;
@@ -923,7 +917,7 @@ __device__ __forceinline__ void topEigenvector(const float (&M)[10], float (&e)[
     for (int i = 1; i < 4; i++)
         len = __fmaf_rn(v[i], v[i], len);
     const bool ok = len > 1e-12f && len < 1e12f; // false for 0 and NaN
-    const float inv = ok ? __frsqrt_rn(len) : 0.0f;
+    const float inv = ok ? __builtin_amdgcn_rsqf(len) : 0.0f;
     e[0] = ok ? v[0] * inv : 1.0f;
 #pragma unroll
     for (int i = 1; i < 4; i++)
@@ -1002,7 +996,7 @@ __device__ __forceinline__ void makeProjection(const u32 (&pix)[16], const Block
                 len = __fmaf_rn(e2[i], e2[i], len);
             }
         }
-        const float inv = __frsqrt_rn(len);
+        const float inv = __builtin_amdgcn_rsqf(len);
 #pragma unroll
         for (int i = 0; i < 4; i++)
             e2[i] *= inv;
@@ -1090,13 +1084,14 @@ __device__ __forceinline__ float subsetBound2D(const Sums2D &m, float invScaleSq
     const float fa = (float)a, fc = (float)c, fb = (float)b;
     const float half = (fa + fc) * 0.5f;
     const float diff = (fa - fc) * 0.5f;
-    const float rad = __fsqrt_rn(__fmaf_rn(diff, diff, fb * fb));
+    // v_sqrt_f32 / v_rcp_f32 are accurate to 1 ulp; the margins below cover that
+    const float rad = __builtin_amdgcn_sqrtf(__fmaf_rn(diff, diff, fb * fb));
     const float lam = half * 0.999998f - rad * 1.000002f; // n * scale^2 * (smaller eigenvalue), rounded down
     const float n = (float)m.n;
-    const float r = lam * invScaleSq / n;
+    const float L = lam * invScaleSq;                      // n * R
     float lb = 0.0f;
-    if (r > n * delta * delta)
-        lb = (r - 2.0f * delta * __fsqrt_rn(n * r)) * 0.9999f;
+    if (L > n * n * delta * delta)
+        lb = (L * __builtin_amdgcn_rcpf(n) - 2.0f * delta * __builtin_amdgcn_sqrtf(L)) * 0.9999f;
     return lb > 0.0f ? lb : 0.0f;
 }
 
@@ -1122,9 +1117,10 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     __shared__ float s_bound[64][16]; // error lower bound of every partition of the current mode, per block
     __shared__ u32 s_pix[16][16];     // the 16 blocks of this wave
     __shared__ u32 s_blkFlags[16];    // wantPCA4 of the block's group
-    __shared__ u32 s_item[16];        // offers of the round: block | partition << 8
-    __shared__ UnitRec s_unit[48];    // PCA seeds per (item, subset)
-    __shared__ u32 s_res[16][3][5];   // best of every subset of the block's offer: error, endpoints, indexes
+    __shared__ u32 s_item[32];        // offers of the round: block | partition << 8
+    __shared__ uint8_t s_myItems[16][8]; // the items a block offered this round
+    __shared__ UnitRec s_unit[64];    // PCA seeds per (item, subset)
+    __shared__ u32 s_res[96][5];      // best of every (item, subset): error, endpoints, indexes
     const cvttmi_bc7_plan *__restrict__ plan = &dplan->plan;
     const int lane = threadIdx.x;
     const u32 blockIndex = blockIdx.x * 16u + (u32)(lane >> 2);
@@ -1428,7 +1424,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 {
                     const bool use4 = (boundSet == 0);
                     const float wsum = A.wSq[0] + A.wSq[1] + A.wSq[2] + (use4 ? A.wSq[3] : 0.0f);
-                    const float scale = 2000.0f / (255.0f * __fsqrt_rn(wsum));
+                    const float scale = 2000.0f / (255.0f * __fsqrt_rn(wsum)); // wave-uniform
                     const float invScaleSq = 1.0f / (scale * scale);
                     // rounding the projected points moves each by at most sqrt(2)/2 grid units
                     const float delta = (use4 ? A.delta4 : A.delta3) + 0.7072f / scale;
@@ -1441,7 +1437,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                         if (boundSet < 2)
                         {
                             Sums2D s1, s0;
-                            maskedSums(P, T->shapeMask[T->shapes2[partition][1]], s1);
+                            maskedSums(P, T->partition2[partition], s1);
                             s0.n = 16 - s1.n;
                             s0.u = P.tU - s1.u;
                             s0.v = P.tV - s1.v;
@@ -1453,8 +1449,8 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                         else
                         {
                             Sums2D s1, s2, s0;
-                            maskedSums(P, T->shapeMask[T->shapes3[partition][1]], s1);
-                            maskedSums(P, T->shapeMask[T->shapes3[partition][2]], s2);
+                            maskedSums(P, T->subsetMask3[partition][0], s1);
+                            maskedSums(P, T->subsetMask3[partition][1], s2);
                             s0.n = 16 - s1.n - s2.n;
                             s0.u = P.tU - s1.u - s2.u;
                             s0.v = P.tV - s1.v - s2.v;
@@ -1492,47 +1488,65 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             aliveBits |= alive ? (1u << k) : 0u;
         }
 
+        const int itemCap = (numSubsets == 3) ? 21 : 32; // items * subsets <= 64 lanes of the seed pass
         for (;;)
         {
-            // quad-wide argmin of the bounds still alive (ties: lowest partition)
-            float pickLb = FLT_MAX;
-            int pick = 255;
-            for (int k = 0; k * 4 < numPartitions; k++)
+            // ---- offers.  Pass 0: every block offers its cheapest-bound candidate.  When few blocks
+            // offer, the idle lanes take further candidates of the same blocks (they might have been
+            // pruned by the first result, but waiting for it would cost a whole round). ----
+            int numItems = 0, myCount = 0, maxPasses = 1;
+            for (int pass = 0; pass < maxPasses; pass++)
             {
-                if ((aliveBits >> k) & 1u)
+                // quad-wide argmin of the bounds still alive (ties: lowest partition)
+                float pickLb = FLT_MAX;
+                int pick = 255;
+                for (int k = 0; k * 4 < numPartitions; k++)
                 {
-                    const float lb = prune ? s_bound[4 * k + c][blk] : 0.0f;
-                    if (lb < pickLb)
+                    if ((aliveBits >> k) & 1u)
                     {
-                        pickLb = lb;
-                        pick = 4 * k + c;
+                        const float lb = prune ? s_bound[4 * k + c][blk] : 0.0f;
+                        if (lb < pickLb)
+                        {
+                            pickLb = lb;
+                            pick = 4 * k + c;
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int step = 1; step <= 2; step <<= 1)
-            {
-                const float oLb = __shfl_xor(pickLb, step);
-                const int oPick = __shfl_xor(pick, step);
-                const bool take = (oLb < pickLb) || (oLb == pickLb && oPick < pick);
-                pickLb = take ? oLb : pickLb;
-                pick = take ? oPick : pick;
+                for (int step = 1; step <= 2; step <<= 1)
+                {
+                    const float oLb = __shfl_xor(pickLb, step);
+                    const int oPick = __shfl_xor(pick, step);
+                    const bool take = (oLb < pickLb) || (oLb == pickLb && oPick < pick);
+                    pickLb = take ? oLb : pickLb;
+                    pick = take ? oPick : pick;
+                }
+                const bool offer = pick < 64 && !(pickLb > work.err);
+                if (!offer)
+                    aliveBits = 0; // everything left costs even more
+                const u64 offers = __ballot(offer && c == 0);
+                const int numOffers = __popcll(offers);
+                if (numOffers == 0 || numItems + numOffers > itemCap)
+                    break;
+                if (pass == 0)
+                    maxPasses = (numOffers <= 1) ? 8 : (numOffers <= 2) ? 6 : (numOffers <= 4) ? 4 : (numOffers <= 8) ? 2 : 1;
+                if (offer)
+                {
+                    const int item = numItems + __popcll(offers & ((1ull << (lane & ~3)) - 1ull));
+                    if (c == 0)
+                    {
+                        s_item[item] = (u32)blk | ((u32)pick << 8);
+                        s_myItems[blk][pass] = (uint8_t)item;
+                    }
+                    if ((pick & 3) == c)
+                        aliveBits &= ~(1u << (pick >> 2));
+                    myCount = pass + 1;
+                }
+                numItems += numOffers;
             }
-            const bool go = pick < 64 && !(pickLb > work.err);
-            if (!go)
-                aliveBits = 0; // everything left costs even more
-            const u64 goBallot = __ballot(go && c == 0);
-            if (goBallot == 0)
+            if (numItems == 0)
                 break;
-            const int partition = go ? pick : 0;
-            if (go && (pick & 3) == c)
-                aliveBits &= ~(1u << (pick >> 2));
-
-            // ---- the round's items: (block, partition), compacted ----
-            const int numItems = __popcll(goBallot);
             const int numUnits = numItems * numSubsets;
-            if (go && c == 0)
-                s_item[__popcll(goBallot & ((1ull << lane) - 1ull))] = (u32)blk | ((u32)partition << 8);
             __syncthreads();
 
             // ---- PCA seed search: lane l takes unit l = (item, subset) ----
@@ -1592,7 +1606,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 r.mask = uMask;
                 r.numTweak = seeds;
                 r.blk = ublk;
-                r.sub = sub;
+                r.slot = item * 3 + sub;
             }
             __syncthreads();
             PROF_MARK(3)
@@ -1634,7 +1648,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 if (inRange && chain == 0)
                 {
                     // with no seed points the shape keeps its reset error FLT_MAX (BC67.cpp:1228-1242)
-                    u32 *dst = &s_res[r.blk][r.sub][0];
+                    u32 *dst = &s_res[r.slot][0];
                     dst[0] = __builtin_bit_cast(u32, b.err);
                     dst[1] = b.ep0;
                     dst[2] = b.ep1;
@@ -1644,38 +1658,45 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             }
             __syncthreads();
 
-            // ---- every offering block adds up its subsets and commits ----
-            if (go)
+            // ---- every offering block adds up the subsets of its items and commits ----
+            for (int j = 0; j < 8; j++)
             {
-                float totalError = 0.0f;
-                u32 pe[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-                u32 pIdxLo = 0, pIdxHi = 0;
-                for (int sub = 0; sub < numSubsets; sub++)
+                if (__ballot(j < myCount) == 0)
+                    break;
+                if (j < myCount)
                 {
-                    const u32 *src = &s_res[blk][sub][0];
-                    totalError = totalError + __builtin_bit_cast(float, src[0]);
-                    const u32 e0 = src[1], e1 = src[2];
-                    if (sub == 0) { pe[0][0] = e0; pe[0][1] = e1; }
-                    else if (sub == 1) { pe[1][0] = e0; pe[1][1] = e1; }
-                    else { pe[2][0] = e0; pe[2][1] = e1; }
-                    pIdxLo |= src[3];
-                    pIdxHi |= src[4];
-                }
-                const int seq = stage * 64 + partition;
-                if (totalError < work.err || (totalError == work.err && seq < workSeq))
-                {
-                    work.err = totalError;
-                    workSeq = seq;
-                    work.mode = mode;
-                    work.partOrIS = partition;
-#pragma unroll
-                    for (int sub = 0; sub < 3; sub++)
+                    const int item = s_myItems[blk][j];
+                    const int partition = (int)(s_item[item] >> 8);
+                    float totalError = 0.0f;
+                    u32 pe[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+                    u32 pIdxLo = 0, pIdxHi = 0;
+                    for (int sub = 0; sub < numSubsets; sub++)
                     {
-                        work.ep[sub][0] = pe[sub][0];
-                        work.ep[sub][1] = pe[sub][1];
+                        const u32 *src = &s_res[item * 3 + sub][0];
+                        totalError = totalError + __builtin_bit_cast(float, src[0]);
+                        const u32 e0 = src[1], e1 = src[2];
+                        if (sub == 0) { pe[0][0] = e0; pe[0][1] = e1; }
+                        else if (sub == 1) { pe[1][0] = e0; pe[1][1] = e1; }
+                        else { pe[2][0] = e0; pe[2][1] = e1; }
+                        pIdxLo |= src[3];
+                        pIdxHi |= src[4];
                     }
-                    work.idxLo = pIdxLo;
-                    work.idxHi = pIdxHi;
+                    const int seq = stage * 64 + partition;
+                    if (totalError < work.err || (totalError == work.err && seq < workSeq))
+                    {
+                        work.err = totalError;
+                        workSeq = seq;
+                        work.mode = mode;
+                        work.partOrIS = partition;
+#pragma unroll
+                        for (int sub = 0; sub < 3; sub++)
+                        {
+                            work.ep[sub][0] = pe[sub][0];
+                            work.ep[sub][1] = pe[sub][1];
+                        }
+                        work.idxLo = pIdxLo;
+                        work.idxHi = pIdxHi;
+                    }
                 }
             }
             PROF_MARK(4)

@@ -34,6 +34,9 @@ struct CvttDeviceTables
     uint8_t clusterCount[8];
     uint16_t clusterStart[8];
     int16_t clusterOffsets[632];
+    // pixel bitmasks of subsets 1 and 2 of every three-subset partition (subset 1 of a
+    // two-subset partition is partition2 itself)
+    uint16_t subsetMask3[64][2];
 };
 
 // The caller's plan plus two bitmaps derived on the host: which shapes the plan's

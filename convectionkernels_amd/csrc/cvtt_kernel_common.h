@@ -13,6 +13,7 @@ namespace
 {
 typedef uint32_t u32;
 typedef uint64_t u64;
+typedef float v2f __attribute__((ext_vector_type(2))); // v_pk_add_f32 / v_pk_mul_f32 operands
 
 // ---- lane arithmetic helpers -------------------------------------------------------
 // MINPS/MAXPS operand order (reference ParallelMath.h:522-559): second operand wins on
@@ -52,6 +53,45 @@ __device__ __forceinline__ u32 opaqueUniform(u32 v)
 
 // 24-bit integer multiply-add: full-rate v_mad_i32_i24 (operands here are < 2^16)
 __device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
+
+// Forced instruction selection for the reconstruct-and-compare step (the optimiser otherwise
+// rewrites it into 64-bit multiply-adds and mask/shift sequences):
+//   sum = w * delta4 + base4            one v_mad_i32_i24; the reconstructed channel is byte 1
+//   d   = byte1(sum) - byteCH(pixel)    one SDWA subtract
+//   acc = d * d + acc                   one v_mad_i32_i24
+__device__ __forceinline__ int madI24(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+template <int CH>
+__device__ __forceinline__ int subByte1(int sum, u32 pk)
+{
+    int r;
+    if (CH == 0)
+        asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_0" : "=v"(r) : "v"(sum), "v"(pk));
+    else if (CH == 1)
+        asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(r) : "v"(sum), "v"(pk));
+    else if (CH == 2)
+        asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2" : "=v"(r) : "v"(sum), "v"(pk));
+    else
+        asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_3" : "=v"(r) : "v"(sum), "v"(pk));
+    return r;
+}
+// squared error of channel CH for interpolation weight w, added to acc
+template <int CH>
+__device__ __forceinline__ u32 accumulateChannelError(int w, int delta4, int base4, u32 pk, u32 acc)
+{
+    const int d = subByte1<CH>(madI24(w, delta4, base4), pk);
+    return (u32)madI24(d, d, (int)acc);
+}
+template <int CH>
+__device__ __forceinline__ u32 channelError(int w, int delta4, int base4, u32 pk)
+{
+    const int d = subByte1<CH>(madI24(w, delta4, base4), pk);
+    return (u32)__mul24(d, d);
+}
 
 struct Unfinished
 {
@@ -261,15 +301,16 @@ __device__ __forceinline__ float shapeErrorLowerBound(const Moments<N> &m, float
             {
                 const int a0 = i > k ? i : k, a1 = i > k ? k : i;
                 const int b0 = j > k ? j : k, b1 = j > k ? k : j;
-                e += m.cov[a0 * (a0 + 1) / 2 + a1] * m.cov[b0 * (b0 + 1) / 2 + b1];
+                e = __fmaf_rn(m.cov[a0 * (a0 + 1) / 2 + a1], m.cov[b0 * (b0 + 1) / 2 + b1], e);
             }
-            t4 += (i == j ? 1.0f : 2.0f) * e * e;
+            t4 = __fmaf_rn((i == j ? 1.0f : 2.0f) * e, e, t4);
         }
-    const float lambdaUp = __fsqrt_rn(__fsqrt_rn(t4)) * 1.0001f;
+    // v_sqrt_f32 is accurate to 1 ulp; the 1e-4 margins cover it
+    const float lambdaUp = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(t4)) * 1.0001f;
     const float r = trace - lambdaUp;
     float lb = 0.0f;
     if (r > n * delta * delta)
-        lb = (r - 2.0f * delta * __fsqrt_rn(n * r)) * 0.9999f;
+        lb = (r - 2.0f * delta * __builtin_amdgcn_sqrtf(n * r)) * 0.9999f;
     return lb > 0.0f ? lb : 0.0f; // NaN / inf inputs end up as "no bound"
 }
 

@@ -110,6 +110,8 @@ namespace
             t.shapes2[i][1] = k_shapes2[i * 2 + 1];
             for (int s = 0; s < 3; s++)
                 t.shapes3[i][s] = k_shapes3[i * 3 + s];
+            t.subsetMask3[i][0] = k_shape_mask[k_shapes3[i * 3 + 1]];
+            t.subsetMask3[i][1] = k_shape_mask[k_shapes3[i * 3 + 2]];
             t.anchor2[i] = k_anchor2[i];
             t.anchor3[i][0] = k_anchor3[i * 2 + 0];
             t.anchor3[i][1] = k_anchor3[i * 2 + 1];
