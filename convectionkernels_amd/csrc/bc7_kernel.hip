@@ -447,26 +447,6 @@ struct UnitRec
     int slot; // item * 3 + subset: where the subset's result goes
 };
 
-// 128-bit little-endian bit writer (reference PackingVector, BC67.cpp:652-698)
-struct BitWriter
-{
-    u64 lo, hi;
-    int off;
-    __device__ __forceinline__ void put(u32 value, int bits)
-    {
-        const u64 v = (u64)value;
-        if (off < 64)
-        {
-            lo |= v << off;
-            if (off + bits > 64)
-                hi |= v >> (64 - off);
-        }
-        else
-            hi |= v << (off - 64);
-        off += bits;
-    }
-};
-
 struct WorkState
 {
     float err;
@@ -1815,79 +1795,114 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 }
         }
 
-        BitWriter bw;
-        bw.lo = bw.hi = 0;
-        bw.off = 0;
-        bw.put(1u << mode, mode + 1);
-        if (partitionBits)
-            bw.put((u32)partition, partitionBits);
-        if (separateAlpha)
-            bw.put((u32)work.rotation, 2);
-        if (mode == 4)
-            bw.put((u32)indexSelector, 1);
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++)
-#pragma unroll
-            for (int s = 0; s < 3; s++)
-                if (s < numSubsets)
-                {
-                    bw.put(((ep[s][0] >> (8 * ch)) & 0xffu) >> (8 - rgbBits), rgbBits);
-                    bw.put(((ep[s][1] >> (8 * ch)) & 0xffu) >> (8 - rgbBits), rgbBits);
-                }
-        if (alphaBits)
-        {
-#pragma unroll
-            for (int s = 0; s < 3; s++)
-                if (s < numSubsets)
-                {
-                    bw.put((ep[s][0] >> 24) >> (8 - alphaBits), alphaBits);
-                    bw.put((ep[s][1] >> 24) >> (8 - alphaBits), alphaBits);
-                }
-        }
-        if (pBitMode == 1)
-        {
-#pragma unroll
-            for (int s = 0; s < 3; s++)
-                if (s < numSubsets)
-                    bw.put(((ep[s][0] & 0xffu) >> (7 - rgbBits)) & 1u, 1);
-        }
-        else if (pBitMode == 0)
-        {
-#pragma unroll
-            for (int s = 0; s < 3; s++)
-                if (s < numSubsets)
-                {
-                    bw.put(((ep[s][0] & 0xffu) >> (7 - rgbBits)) & 1u, 1);
-                    bw.put(((ep[s][1] & 0xffu) >> (7 - rgbBits)) & 1u, 1);
-                }
-        }
-#pragma unroll
-        for (int px = 0; px < 16; px++)
-        {
-            int bits = indexBits;
-            if (px == 0 || px == fix1 || px == fix2)
-                bits--;
-            bw.put((u32)((idx >> (4 * px)) & 0xfull), bits);
-        }
-        if (separateAlpha)
-        {
-#pragma unroll
-            for (int px = 0; px < 16; px++)
+        // ---- bit packing: the (up to 66) fields of the block are dealt round-robin to the four
+        // lanes of the quad, each lane shifts its fields to their absolute bit positions, and
+        // the quad ORs the four partial blocks together ----
+        u64 lo = 0, hi = 0;
+        auto put = [&](u32 value, int off, int bits) {
+            const u64 v = (u64)value;
+            (void)bits;
+            if (off < 64)
             {
-                int bits = alphaIndexBits;
-                if (px == 0)
-                    bits--;
-                bw.put((u32)((idx2 >> (4 * px)) & 0xfull), bits);
+                lo |= v << off;
+                if (off > 56)
+                    hi |= v >> (64 - off); // fields are at most 8 bits wide
             }
+            else
+                hi |= v << (off - 64);
+        };
+        // header
+        int epBase = mode + 1;
+        if (c == 0)
+        {
+            put(1u << mode, 0, mode + 1);
+            if (partitionBits)
+                put((u32)partition, epBase, partitionBits);
+        }
+        epBase += partitionBits;
+        if (separateAlpha)
+        {
+            if (c == 1)
+            {
+                put((u32)work.rotation, epBase, 2);
+                if (mode == 4)
+                    put((u32)indexSelector, epBase + 2, 1);
+            }
+            epBase += (mode == 4) ? 3 : 2;
+        }
+        // endpoints: channel-major, then subset, then endpoint 0/1; then alpha; then p-bits
+        const int perChannel = 2 * numSubsets;
+        const int numRGB = 3 * perChannel;
+        const int numAlpha = alphaBits ? perChannel : 0;
+        const int numPBits = (pBitMode == 0) ? perChannel : (pBitMode == 1) ? numSubsets : 0;
+        const int alphaBase = epBase + numRGB * rgbBits;
+        const int pBase = alphaBase + numAlpha * alphaBits;
+        const int idxBase = pBase + numPBits;
+        for (int i = 0; i < 8; i++)
+        {
+            const int f = 4 * i + c;
+            if (__ballot(f < numRGB + numAlpha + numPBits) == 0)
+                break;
+            if (f < numRGB + numAlpha)
+            {
+                // colour or alpha endpoint field
+                const bool isAlpha = f >= numRGB;
+                const int g = isAlpha ? f - numRGB : f;
+                const int ch = isAlpha ? 3 : ((numSubsets == 1) ? (g >> 1) : (numSubsets == 2) ? (g >> 2) : (g / 6));
+                const int rem = isAlpha ? g : g - ch * perChannel;
+                const int sub = rem >> 1, e = rem & 1;
+                const u32 e0 = (sub == 0) ? ep[0][0] : (sub == 1) ? ep[1][0] : ep[2][0];
+                const u32 e1 = (sub == 0) ? ep[0][1] : (sub == 1) ? ep[1][1] : ep[2][1];
+                const u32 val = ((e ? e1 : e0) >> (8 * ch)) & 0xffu;
+                const int bits = isAlpha ? alphaBits : rgbBits;
+                put(val >> (8 - bits), isAlpha ? alphaBase + g * alphaBits : epBase + g * rgbBits, bits);
+            }
+            else if (f < numRGB + numAlpha + numPBits)
+            {
+                const int g = f - numRGB - numAlpha;
+                const int sub = (pBitMode == 1) ? g : (g >> 1);
+                const int e = (pBitMode == 1) ? 0 : (g & 1);
+                const u32 e0 = (sub == 0) ? ep[0][0] : (sub == 1) ? ep[1][0] : ep[2][0];
+                const u32 e1 = (sub == 0) ? ep[0][1] : (sub == 1) ? ep[1][1] : ep[2][1];
+                put((((e ? e1 : e0) & 0xffu) >> (7 - rgbBits)) & 1u, pBase + g, 1);
+            }
+        }
+        // indexes: pixel px at idxBase + px*indexBits minus one bit per anchor before it
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const int px = 4 * i + c;
+            const bool anchor = (px == 0 || px == fix1 || px == fix2);
+            const int before = (px > 0 ? 1 : 0) + ((fix1 != 0 && px > fix1) ? 1 : 0) + ((fix2 != 0 && px > fix2) ? 1 : 0);
+            put((u32)((idx >> (4 * px)) & 0xfull), idxBase + px * indexBits - before, indexBits - (anchor ? 1 : 0));
+        }
+        if (separateAlpha)
+        {
+            const int idx2Base = idxBase + 16 * indexBits - 1;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                const int px = 4 * i + c;
+                put((u32)((idx2 >> (4 * px)) & 0xfull), idx2Base + px * alphaIndexBits - (px > 0 ? 1 : 0), alphaIndexBits - (px == 0 ? 1 : 0));
+            }
+        }
+        u32 w0 = (u32)lo, w1 = (u32)(lo >> 32), w2 = (u32)hi, w3 = (u32)(hi >> 32);
+#pragma unroll
+        for (int step = 1; step <= 2; step <<= 1)
+        {
+            w0 |= __shfl_xor(w0, step);
+            w1 |= __shfl_xor(w1, step);
+            w2 |= __shfl_xor(w2, step);
+            w3 |= __shfl_xor(w3, step);
         }
 
         if (valid && c == 0)
         {
             uint4 o;
-            o.x = (u32)bw.lo;
-            o.y = (u32)(bw.lo >> 32);
-            o.z = (u32)bw.hi;
-            o.w = (u32)(bw.hi >> 32);
+            o.x = w0;
+            o.y = w1;
+            o.z = w2;
+            o.w = w3;
             *reinterpret_cast<uint4 *>(out + (size_t)blockIndex * 16u) = o;
         }
     }
