@@ -445,6 +445,8 @@ struct UnitRec
     int numTweak;
     int blk;
     int slot; // item * 3 + subset: where the subset's result goes
+    float scErr; // BC7_TrySingleColor: error of the fixed candidate (FLT_MAX when not tried)
+    int pad[3];
 };
 
 struct WorkState
@@ -1587,6 +1589,41 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 r.numTweak = seeds;
                 r.blk = ublk;
                 r.slot = item * 3 + sub;
+                float scErr = FLT_MAX;
+                if ((A.flags & CVTTMI_FLAG_BC7_TRY_SINGLE_COLOR) && seeds > 0)
+                {
+                    // BC67.cpp:1436-1570 + 940-1040.  With the reference's AndNot operand order no
+                    // single-colour table entry is ever taken (finite weights), so what reaches the
+                    // error test is endpoints (0,0,0[,255]) with index 0 for every pixel.
+                    u32 e[4] = {0, 0, 0, 0}, st = 0;
+#pragma unroll
+                    for (int px = 0; px < 16; px++)
+                        if ((uMask >> px) & 1u)
+                        {
+                            const u32 pk = lp[px];
+                            e[0] = (u32)mad24(byteI(pk, 0), byteI(pk, 0), (int)e[0]);
+                            e[1] = (u32)mad24(byteI(pk, 1), byteI(pk, 1), (int)e[1]);
+                            e[2] = (u32)mad24(byteI(pk, 2), byteI(pk, 2), (int)e[2]);
+                            const int d = 255 - byteI(pk, 3);
+                            if (isRGB)
+                                st = (u32)mad24(d, d, (int)st);
+                            else
+                                e[3] = (u32)mad24(d, d, (int)e[3]);
+                        }
+                    const bool uniformErr = (A.flags & CVTTMI_FLAG_UNIFORM) != 0;
+                    if (uniformErr)
+                        scErr = (float)(int)(e[0] + e[1] + e[2] + e[3]);
+                    else
+                    {
+                        scErr = (float)(int)e[0] * A.wSq[0];
+                        scErr = scErr + (float)(int)e[1] * A.wSq[1];
+                        scErr = scErr + (float)(int)e[2] * A.wSq[2];
+                        scErr = scErr + (float)(int)e[3] * A.wSq[3];
+                    }
+                    if (isRGB)
+                        scErr = scErr + (uniformErr ? (float)(int)st : (float)(int)st * A.wSq[3]);
+                }
+                r.scErr = scErr;
             }
             __syncthreads();
             PROF_MARK(3)
@@ -1627,6 +1664,13 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 groupArgminBroadcast(b, lane, CP);
                 if (inRange && chain == 0)
                 {
+                    if (r.scErr < b.err)
+                    {
+                        // the single-colour try comes after every chain of the shape (strict '<')
+                        b.err = r.scErr;
+                        b.ep0 = b.ep1 = isRGB ? 0u : 0xff000000u;
+                        b.idxLo = b.idxHi = 0;
+                    }
                     // with no seed points the shape keeps its reset error FLT_MAX (BC67.cpp:1228-1242)
                     u32 *dst = &s_res[r.slot][0];
                     dst[0] = __builtin_bit_cast(u32, b.err);

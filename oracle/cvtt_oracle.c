@@ -8,6 +8,7 @@
  */
 #include "cvtt_oracle.h"
 #include "cvtt_oracle_tables.h"
+#include "cvtt_oracle_bc7sc.h"
 
 #include <float.h>
 #include <math.h>
@@ -596,6 +597,102 @@ static void bc7_single_plane_trial(const bc7_ctx_t *cx, bc7_lane_t *ln, int mode
     ln->shapeError = shapeError;
 }
 
+/* BC7_TrySingleColor: call site BC67.cpp:1436-1570 + TrySingleColorRGBAMultiTable, BC67.cpp:940-1040.
+ * Restated as the reference behaves, not as it was meant:
+ *   - the shape average is taken over pixels[pxi] (the FIRST shapeLength pixels of the block),
+ *     BC67.cpp:1446, not over the members of the shape;
+ *   - `better = AndNot(pti, better)` is `pti & ~better` (ParallelMath.h:900-905), so a table is
+ *     only ever taken by lanes that are punch-through-invalid AND not better; bestAverageError
+ *     therefore stays FLT_MAX and, for finite weights, no table is ever taken: the candidate
+ *     that reaches the error test is endpoints (0,0,0[,255]) with index 0.
+ * The 8 lanes run in lock-step (AnySet guards). */
+static void bc7_try_single_color(const bc7_ctx_t *cx, bc7_lane_t *lanes, int mode, int shape, const uint8_t *frag,
+                                 int shapeStart, int shapeLength, int numRealChannels)
+{
+    const uint32_t flags = cx->flags;
+    float average[8][4], bestAverageError[8];
+    int intAverage[8][4], eps[8][2][4], reconstructed[8][4], index[8];
+    const float rcpShapeLength = 1.0f / (float)shapeLength;
+    for (int l = 0; l < 8; l++)
+    {
+        for (int ch = 0; ch < 4; ch++)
+        {
+            uint16_t total = 0;
+            for (int pxi = 0; pxi < shapeLength; pxi++)
+                total = (uint16_t)(total + lanes[l].pixels[pxi][ch]);
+            average[l][ch] = (float)total * rcpShapeLength;
+            intAverage[l][ch] = cvt_rne_s16(average[l][ch]);
+        }
+        bestAverageError[l] = FLT_MAX;
+        for (int epi = 0; epi < 2; epi++)
+        {
+            eps[l][epi][0] = eps[l][epi][1] = eps[l][epi][2] = 0;
+            eps[l][epi][3] = 255;
+        }
+        reconstructed[l][0] = reconstructed[l][1] = reconstructed[l][2] = 0;
+        reconstructed[l][3] = 255;
+        index[l] = 0;
+    }
+
+    const int first = orc_bc7sc_first[mode], count = orc_bc7sc_count[mode];
+    for (int t = first; t < first + count; t++)
+    {
+        const int tableIndex = orc_bc7sc_info[t][0], tablePBits = orc_bc7sc_info[t][1];
+        int candRec[8][4], candEP[8][2][4], better[8], any = 0;
+        for (int l = 0; l < 8; l++)
+        {
+            float avgError = 0.0f;
+            for (int ch = 0; ch < numRealChannels; ch++)
+            {
+                const unsigned char *e = orc_bc7sc_entries[t][intAverage[l][ch] & 255];
+                candEP[l][0][ch] = e[0];
+                candEP[l][1][ch] = e[1];
+                candRec[l][ch] = e[2];
+                const float delta = (float)candRec[l][ch] - average[l][ch];
+                avgError = avgError + delta * delta * cx->wSq[ch];
+            }
+            const int isBetter = avgError < bestAverageError[l];
+            better[l] = lanes[l].punchThroughInvalid[tablePBits] && !isBetter; /* AndNot(pti, better) */
+            any = any || better[l];
+            if (better[l])
+                bestAverageError[l] = avgError; /* set below under AnySet; same lanes */
+        }
+        if (!any)
+            continue;
+        for (int l = 0; l < 8; l++)
+        {
+            if (!better[l])
+                continue;
+            index[l] = tableIndex;
+            for (int ch = 0; ch < numRealChannels; ch++)
+            {
+                reconstructed[l][ch] = candRec[l][ch];
+                eps[l][0][ch] = candEP[l][0][ch];
+                eps[l][1][ch] = candEP[l][1][ch];
+            }
+        }
+    }
+
+    for (int l = 0; l < 8; l++)
+    {
+        bc7_lane_t *ln = &lanes[l];
+        aggerr_t agg;
+        agg_init(&agg);
+        for (int pxi = 0; pxi < shapeLength; pxi++)
+            agg_add_pixel(&agg, reconstructed[l], ln->pixels[frag[pxi]], numRealChannels);
+        const float error = agg_finalize(&agg, 4, flags, cx->wSq) + ln->staticAlphaError;
+        if (error < ln->shapeBestError[shape])
+        {
+            ln->shapeBestError[shape] = error; /* Min(best, error) with error < best */
+            for (int epi = 0; epi < 2; epi++)
+                for (int ch = 0; ch < numRealChannels; ch++)
+                    ln->shapeBestEP[shape][epi][ch] = eps[l][epi][ch];
+            for (int pxi = 0; pxi < shapeLength; pxi++)
+                ln->fragmentBestIndexes[shapeStart + pxi] = index[l];
+        }
+    }
+}
+
 /* BC7Computer::TrySinglePlane, ConvectionKernels_BC67.cpp:1042-1662.
  * The 8 lanes run in lock-step because with BC7_RespectPunchThrough the commit rule of
  * BC67.cpp:1406-1428 couples them (AnySet guards + the operand order of
@@ -814,7 +911,8 @@ static void bc7_try_single_plane(const bc7_ctx_t *cx, bc7_lane_t *lanes)
                     }
                 }
             }
-            /* BC7_TrySingleColor (BC67.cpp:1436-1570) is rejected by the entry point. */
+            if (flags & ORC_FLAG_BC7_TRY_SINGLE_COLOR)
+                bc7_try_single_color(cx, lanes, mode, shape, frag, shapeStart, shapeLength, numRealChannels);
         }
 
         /* partition argmin, BC67.cpp:1573-1660.  For mode 7 the reference assigns the
@@ -1394,8 +1492,6 @@ int orc_encode_bc7(uint8_t *out, const uint8_t *blocks, size_t numBlocks, const 
 {
     if (numBlocks % 8 != 0)
         return -1;
-    if (options->flags & ORC_FLAG_BC7_TRY_SINGLE_COLOR)
-        return -2; /* single-colour tables are out of scope in the first pass */
     float probed[17];
     if (!rcp17)
     {

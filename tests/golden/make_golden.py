@@ -32,6 +32,9 @@ def bc7_variants(ref):
         "uniform": (P.make_options(flags=P.FLAGS_DEFAULT | P.FLAG_UNIFORM), ref.default_plan()),
         "punchthrough": (P.make_options(flags=P.FLAGS_DEFAULT | P.FLAG_BC7_RESPECT_PUNCHTHROUGH), ref.default_plan()),
         "better": (P.make_options(flags=P.FLAGS_BETTER), ref.default_plan()),
+        # Flags::Ultra = BC7_TrySingleColor | S3TC_Paranoid | S3TC_Exhaustive | ETC_FakeBT709Accurate (slow indexing)
+        "ultra": (P.make_options(flags=0x010 | 0x100 | 0x080 | 0x800), ref.default_plan()),
+        "singlecolor": (P.make_options(flags=P.FLAGS_DEFAULT | P.FLAG_BC7_TRY_SINGLE_COLOR), ref.default_plan()),
         "refine1": (P.make_options(refine_bc7=1), ref.default_plan()),
         "refine3": (P.make_options(refine_bc7=3), ref.default_plan()),
         "weights": (P.make_options(weights=(0.5, 1.0, 0.25, 2.0)), ref.default_plan()),

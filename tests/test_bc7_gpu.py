@@ -14,7 +14,7 @@ from oracle import pyref
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
-GPU_VARIANTS = ["default", "uniform", "better", "refine1", "refine3", "weights",
+GPU_VARIANTS = ["default", "uniform", "better", "ultra", "singlecolor", "refine1", "refine3", "weights",
                 "quality1", "quality20", "quality60", "quality100"]
 
 
@@ -112,7 +112,30 @@ def test_device_tensor_path_and_ragged_sizes(gpu_ctx, oracle_lib):
 def test_unsupported_flags_fail_loudly(gpu_ctx):
     api = _api()
     with pytest.raises(api.CvttError):
-        gpu_ctx.encode_bc7(np.zeros((8, 16, 4), np.uint8), api.Options(flags=api.Flags.Ultra))
+        gpu_ctx.encode_bc7(np.zeros((8, 16, 4), np.uint8), api.Options(flags=api.Flags.Default | api.Flags.BC7_RespectPunchThrough))
+
+
+def test_single_colour_flag_on_dark_content(gpu_ctx, oracle_lib):
+    """BC7_TrySingleColor / Flags::Ultra (BASELINE config 5b) on content where the fixed
+    (0,0,0[,255]) candidate is competitive: near-black noise, with and without alpha"""
+    api = _api()
+    rcp = oracle_lib.probe_rcp()
+    gpu_ctx.set_rcp_table(rcp)
+    rng = np.random.Generator(np.random.PCG64(5))
+    blocks = np.zeros((256, 16, 4), np.uint8)
+    for b in range(256):
+        blocks[b, :, :3] = rng.integers(0, (1, 2, 3, 4, 6, 8, 12, 20)[b % 8] + 1, (16, 3))
+        blocks[b, :, 3] = 255 if (b // 8) % 3 == 0 else (rng.integers(250, 256, 16) if (b // 8) % 3 == 1 else rng.choice(np.array([0, 255], np.uint8), 16))
+        if b % 5 == 0:
+            blocks[b, rng.integers(0, 16), :3] = rng.integers(0, 256, 3)
+    plan = api.BC7EncodingPlan()
+    for flags in (api.Flags.Default | api.Flags.BC7_TrySingleColor, api.Flags.Ultra, api.Flags.Ultra | api.Flags.Uniform):
+        opt = api.Options(flags=flags)
+        exp = oracle_lib.encode_bc7(blocks, np.frombuffer(opt.tobytes(), np.uint8).copy(),
+                                    np.frombuffer(plan.tobytes(), np.uint8).copy(), rcp, threads=8)
+        out = gpu_ctx.encode_bc7(blocks, opt, plan)
+        bad = _diff(out, exp)
+        assert bad.size == 0, "flags %x blocks %s" % (flags, bad[:8])
 
 
 def test_config2_full_size_hash(gpu_ctx):

@@ -38,7 +38,7 @@ def test_default_pods_match_golden():
     assert api.BC7EncodingPlan().tobytes() == g["plan_default"].tobytes()
 
 
-@pytest.mark.parametrize("name", ["default", "uniform", "punchthrough", "better", "refine1", "refine3", "weights",
+@pytest.mark.parametrize("name", ["default", "uniform", "punchthrough", "better", "ultra", "singlecolor", "refine1", "refine3", "weights",
                                   "quality1", "quality20", "quality60", "quality100"])
 def test_golden_mixed(oracle_lib, name):
     g = np.load(os.path.join(GOLD, "bc7_mixed.npz"))
@@ -100,7 +100,19 @@ def test_against_reference_fresh_inputs(oracle_lib, ref_lib):
         assert (a == b).all()
 
 
-def test_rejects_unsupported(oracle_lib):
-    blocks = np.zeros((8, 16, 4), np.uint8)
-    with pytest.raises(RuntimeError):
-        oracle_lib.encode_bc7(blocks, pyref.make_options(flags=pyref.FLAG_BC7_TRY_SINGLE_COLOR), _default_plan_bytes())
+def test_single_colour_tables_are_generated_from_the_rule():
+    """oracle/cvtt_oracle_bc7sc.h is what tools/gen_bc7_single_color.py emits (spot checks of the rule)"""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    spec = importlib.util.spec_from_file_location("gen_sc", os.path.join(root, "tools", "gen_bc7_single_color.py"))
+    sc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sc)
+    idx, pbits, ent = sc.table(7, 1, 0, 0, 1, 15)  # mode 6, p-bits 0, index 1
+    assert (idx, pbits) == (1, 0) and ent[0] == (0, 0, 0) and len(ent) == 256
+    for v in (0, 17, 128, 255):
+        lo, hi, c = ent[v]
+        assert c == ((64 - 4) * lo + 4 * hi + 32) >> 6 and abs(c - v) <= 1
+    text = open(os.path.join(root, "oracle", "cvtt_oracle_bc7sc.h")).read()
+    assert "ORC_BC7SC_NUM_TABLES 39" in text

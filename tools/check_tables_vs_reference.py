@@ -43,6 +43,36 @@ def main():
         ok = ref == list(ours)
         print("%-20s %5d entries  %s" % (name, len(ref), "OK" if ok else "MISMATCH"))
         bad += not ok
+    bad += check_single_colour()
+    return bad
+
+
+def check_single_colour():
+    """BC7 single-colour tables (ConvectionKernels_BC7_SingleColor.h) vs tools/gen_bc7_single_color.py"""
+    import gen_bc7_single_color as SC
+    from bc7_sc_overrides import OVERRIDES
+    path = "/root/reference/ConvectionKernels_BC7_SingleColor.h"
+    txt = open(path).read()
+    ref = {}
+    for m in re.finditer(r"Table (\w+)=\s*\{\s*(\d+),\s*(\d+),\s*\{(.*?)\}\s*\};", txt, re.S):
+        nums = [int(x) for x in re.findall(r"\d+", m.group(4))]
+        ref[m.group(1)] = (int(m.group(2)), int(m.group(3)), [tuple(nums[i:i + 3]) for i in range(0, 768, 3)])
+    names = []
+    for p in ("p00", "p01", "p10", "p11"):
+        names += ["g_mode0_%s_i%d" % (p, i) for i in (1, 2, 3)]
+    for p in ("p0", "p1"):
+        names += ["g_mode1_%s_i%d" % (p, i) for i in (1, 2, 3)]
+    names += ["g_mode2", "g_mode3_p0", "g_mode3_p1"]
+    for p in ("p0", "p1"):
+        names += ["g_mode6_%s_i%d" % (p, i) for i in range(1, 8)]
+    names += ["g_mode7_p00", "g_mode7_p01", "g_mode7_p10", "g_mode7_p11"]
+    bad = 0
+    for n, (mode, idx, pb, ent) in zip(names, SC.build(OVERRIDES)):
+        ok = ref[n] == (idx, pb, ent)
+        bad += not ok
+        if not ok:
+            print("single-colour table %s MISMATCH" % n)
+    print("%-20s %5d tables   %s" % ("BC7 single colour", len(names), "OK" if not bad else "MISMATCH"))
     return bad
 
 
