@@ -30,6 +30,26 @@ ALGO_BYTES_PER_BLOCK = 80  # 64 B PixelBlockU8 in + 16 B out
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def profiled_counters():
+    """PMC figures of the same kernel from the newest committed rocprofv3 summary (profiles/rNN/
+    summary.json, written by tools/profile_round.sh: separate --pmc passes, FETCH_SIZE corrected as
+    the microarch guide prescribes).  Counters cannot be read from inside this process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "summary.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        sq = d["pmc_sq"][0]
+        return {"source": os.path.relpath(files[-1], ROOT),
+                "hbm_bytes_per_launch": d["hbm_traffic_bytes_per_launch"]["bytes_corrected"],
+                "valu_insts_per_wave": sq["derived"]["valu_insts_per_wave"],
+                "valu_busy_frac": sq["derived"]["valu_busy_frac(ACTIVE_INST_VALU*4/simd_cycles)"],
+                "blocks": int(sq["grid"]) // 4}
+    except Exception:  # noqa
+        return None
+
+
 def cpu_baseline(blocks, gpu_out, opt_bytes, plan_bytes, rcp, budget_s=12.0):
     """Time the CPU path on a bounded sample of the same workload and check GPU == CPU on it."""
     from oracle import pyref
@@ -188,6 +208,17 @@ def main():
                 "note": "VALU-bound search: %d algorithmic bytes per block; see DESIGN.md for the lane-op model" % ALGO_BYTES_PER_BLOCK,
             },
         }
+        pmc = profiled_counters()
+        if pmc and pmc["blocks"] == nblk and not args.exhaustive and not args.opaque:
+            # same kernel, same workload: HBM bytes per launch from the PMC pass over this launch's duration
+            result["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9
+            result["roofline"]["traffic_source"] = pmc["source"]
+            # the bound that actually binds: VALU issue (one wave64 instruction per 4 cycles per SIMD)
+            waves = (nblk + 15) // 16
+            peak = 256 * 4 * 2.4e9 / 4.0
+            result["valu_issue"] = {"insts_per_wave": pmc["valu_insts_per_wave"], "achieved": waves * pmc["valu_insts_per_wave"] / (k_ms * 1e-3),
+                                    "peak": peak, "unit": "wave-instructions/s",
+                                    "frac": waves * pmc["valu_insts_per_wave"] / (k_ms * 1e-3) / peak, "source": pmc["source"]}
         if world == 1 and not args.exhaustive:
             # the same workload with pruning off, for reference (not the headline value)
             ctx.set_exhaustive(True)

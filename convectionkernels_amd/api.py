@@ -152,6 +152,7 @@ _EXPORTS = (
     "cvttmi_encode_bc6h_device", "cvttmi_encode_bc6h",
     "cvttmi_encode_etc2_device", "cvttmi_encode_etc2_rgba_device", "cvttmi_encode_etc2_alpha_device",
     "cvttmi_encode_etc2", "cvttmi_encode_etc2_rgba", "cvttmi_encode_etc2_alpha",
+    "cvttmi_tiled_block_count", "cvttmi_tile_image_device", "cvttmi_compact_rows_device",
 )
 
 _lib = None
@@ -191,6 +192,12 @@ def load_library():
         getattr(lib, n).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         getattr(lib, n + "_device").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                                  ctypes.c_void_p, ctypes.c_void_p]
+    lib.cvttmi_tiled_block_count.restype = ctypes.c_size_t
+    lib.cvttmi_tiled_block_count.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    lib.cvttmi_tile_image_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                             ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    lib.cvttmi_compact_rows_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                               ctypes.c_uint32, ctypes.c_void_p]
     lib.cvttmi_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_set_exhaustive.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_timing_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
@@ -343,6 +350,61 @@ class Context:
         """Batched cvtt::Kernels::EncodeETC2Alpha (EAC 8-bit): (N,16,4) uint8 -> (N,8) uint8."""
         return self._encode_simple(self._lib.cvttmi_encode_etc2_alpha, self._lib.cvttmi_encode_etc2_alpha_device,
                                    "encode_etc2_alpha", blocks, options, out, stream, 64, 8)
+
+
+    # -- image -> PixelBlock tiling on the device (reference etc2packer.cpp:215-247, 275-281) --
+    def tile_image(self, image, stream=None):
+        """(H,W,4) CUDA tensor, uint8 (RGBA8) or a 2-byte dtype (RGBA16F bit patterns), rows may be
+        strided -> (ceil(H/4) * ceil(ceil(W/4)/8)*8, 16, 4) PixelBlock tensor: groups of eight
+        horizontally adjacent blocks, reads clamped at the right / bottom edge."""
+        import torch
+        if not (isinstance(image, torch.Tensor) and image.is_cuda and image.dim() == 3 and image.shape[2] == 4):
+            raise CvttError("image must be a CUDA tensor of shape (H, W, 4)")
+        if image.stride(2) != 1 or image.stride(1) != 4:
+            image = image.contiguous()
+        h, w = int(image.shape[0]), int(image.shape[1])
+        esz = image.element_size()
+        if esz not in (1, 2):
+            raise CvttError("image must be RGBA8 or RGBA16F")
+        n = self._lib.cvttmi_tiled_block_count(w, h)
+        blocks = torch.empty((n, 16, 4), dtype=image.dtype, device=image.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(image.device).cuda_stream
+        self._check(self._lib.cvttmi_tile_image_device(self._h, blocks.data_ptr(), image.data_ptr(), w, h,
+                                                       image.stride(0) * esz, 0 if esz == 1 else 1, ctypes.c_void_p(stream)), "tile_image")
+        return blocks
+
+    def compact_rows(self, packed, width, height, stream=None):
+        """drop the blocks that only pad the last group of every block row: (padded N, B) -> (ceil(H/4)*ceil(W/4), B)"""
+        import torch
+        bpb = int(packed.shape[1])
+        out = torch.empty((((height + 3) // 4) * ((width + 3) // 4), bpb), dtype=torch.uint8, device=packed.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(packed.device).cuda_stream
+        self._check(self._lib.cvttmi_compact_rows_device(self._h, out.data_ptr(), packed.contiguous().data_ptr(), width, height, bpb,
+                                                         ctypes.c_void_p(stream)), "compact_rows")
+        return out
+
+    def encode_image(self, fmt, image, options=None, plan=None, stream=None):
+        """linear image in HBM -> packed blocks of format `fmt` in ("bc7","bc1","bc6hu","bc6hs","etc2","etc2rgba","eac"),
+        row-major, ceil(W/4) blocks per row: tiling, encode and row compaction all on the device."""
+        h, w = int(image.shape[0]), int(image.shape[1])
+        blocks = self.tile_image(image, stream)
+        if fmt == "bc7":
+            packed = self.encode_bc7(blocks, options, plan, stream=stream)
+        elif fmt == "bc1":
+            packed = self.encode_bc1(blocks, options, stream=stream)
+        elif fmt in ("bc6hu", "bc6hs"):
+            packed = self.encode_bc6h(blocks, options, signed=(fmt == "bc6hs"), stream=stream)
+        elif fmt == "etc2":
+            packed = self.encode_etc2(blocks, options, stream=stream)
+        elif fmt == "etc2rgba":
+            packed = self.encode_etc2_rgba(blocks, options, stream=stream)
+        elif fmt == "eac":
+            packed = self.encode_etc2_alpha(blocks, options, stream=stream)
+        else:
+            raise CvttError("unknown format %r" % (fmt,))
+        return packed if w % 32 == 0 else self.compact_rows(packed, w, h, stream)
 
 
 _default_ctx = {}

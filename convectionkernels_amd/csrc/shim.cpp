@@ -24,6 +24,10 @@ extern "C" hipError_t cvttmi_launch_bc7(const void *d_blocks, void *d_out, const
                                         const CvttDeviceTables *d_tables, const CvttBc7DevicePlan *d_plan,
                                         hipStream_t stream);
 
+extern "C" hipError_t cvttmi_launch_tile(const void *d_image, void *d_blocks, uint32_t width, uint32_t height, size_t rowPitch,
+                                         uint32_t bytesPerPixel, hipStream_t stream);
+extern "C" hipError_t cvttmi_launch_compact_rows(const void *d_packed, void *d_out, uint32_t width, uint32_t height,
+                                                 uint32_t bytesPerBlock, hipStream_t stream);
 extern "C" hipError_t cvttmi_launch_bc1(const void *d_blocks, void *d_out, const CvttBc1Args *args,
                                         const CvttDeviceTables *d_tables, hipStream_t stream);
 
@@ -390,6 +394,46 @@ extern "C"
             return CVTTMI_E_INVALID;
         for (int i = 0; i <= 16; i++)
             lut[i] = ctx->hostTables.rcpTable[i];
+        return CVTTMI_OK;
+    }
+
+    size_t cvttmi_tiled_block_count(uint32_t width, uint32_t height)
+    {
+        const size_t perRow = (((size_t)width + 3) / 4 + 7) / 8 * 8;
+        return perRow * (((size_t)height + 3) / 4);
+    }
+
+    int cvttmi_tile_image_device(cvttmi_context *ctx, void *d_blocks, const void *d_image, uint32_t width, uint32_t height,
+                                 size_t rowPitchBytes, int pixelFormat, void *hipStream)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        const uint32_t bpp = (pixelFormat == CVTTMI_PIXELS_RGBA8) ? 4u : (pixelFormat == CVTTMI_PIXELS_RGBA16F) ? 8u : 0u;
+        if (!d_blocks || !d_image || bpp == 0 || width == 0 || height == 0 || rowPitchBytes < (size_t)width * bpp ||
+            (rowPitchBytes % bpp) != 0)
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        e = cvttmi_launch_tile(d_image, d_blocks, width, height, rowPitchBytes, bpp, static_cast<hipStream_t>(hipStream));
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "tile kernel launch", e);
+        return CVTTMI_OK;
+    }
+
+    int cvttmi_compact_rows_device(cvttmi_context *ctx, void *d_out, const void *d_packed, uint32_t width, uint32_t height,
+                                   uint32_t bytesPerBlock, void *hipStream)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        if (!d_out || !d_packed || width == 0 || height == 0 || (bytesPerBlock != 8 && bytesPerBlock != 16))
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        e = cvttmi_launch_compact_rows(d_packed, d_out, width, height, bytesPerBlock, static_cast<hipStream_t>(hipStream));
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "compact kernel launch", e);
         return CVTTMI_OK;
     }
 

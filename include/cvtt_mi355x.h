@@ -170,6 +170,24 @@ int cvttmi_encode_etc2_alpha(cvttmi_context *ctx, uint8_t *out, const uint8_t *b
  * slower); the environment variable CVTTMI_EXHAUSTIVE=1 sets the default of new contexts. */
 int cvttmi_set_exhaustive(cvttmi_context *ctx, int exhaustive);
 
+/* ---- image -> PixelBlock tiling on the device (the caller side of the path: reference
+ * etc2packer/etc2packer.cpp:215-247 cuts a linear image into groups of eight horizontally
+ * adjacent 4x4 blocks, clamping reads at the right and bottom edges; 275-281 drops the blocks
+ * that only pad the last group of a block row) ----
+ * cvttmi_tiled_block_count: blocks the tiling produces = ceil(ceil(w/4)/8)*8 per block row
+ *   (a multiple of 8, so every block row is made of whole groups) times ceil(h/4) rows.
+ * cvttmi_tile_image_device: d_image = linear RGBA8 or RGBA16F image in HBM (rowPitchBytes
+ *   between rows) -> d_blocks = PixelBlockU8 / PixelBlockF16 array of that many blocks.
+ * cvttmi_compact_rows_device: packed blocks of the padded layout -> the ceil(w/4) real blocks of
+ *   every row, contiguous (what a container writer stores).  A no-op copy when w % 32 == 0. */
+#define CVTTMI_PIXELS_RGBA8 0
+#define CVTTMI_PIXELS_RGBA16F 1
+size_t cvttmi_tiled_block_count(uint32_t width, uint32_t height);
+int cvttmi_tile_image_device(cvttmi_context *ctx, void *d_blocks, const void *d_image, uint32_t width, uint32_t height,
+                             size_t rowPitchBytes, int pixelFormat, void *hipStream);
+int cvttmi_compact_rows_device(cvttmi_context *ctx, void *d_out, const void *d_packed, uint32_t width, uint32_t height,
+                               uint32_t bytesPerBlock, void *hipStream);
+
 /* Time (ms, HIP events on the launch stream) and launch count of the kernels of the most
  * recent *_device call sequence since cvttmi_timing_reset(); used by bench.py's roofline. */
 int cvttmi_timing_enable(cvttmi_context *ctx, int enable);

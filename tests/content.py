@@ -152,3 +152,24 @@ def mixed_hdr_blocks(seed, groups, signed=False):
 
 def config_blocks_hdr(seed, width, height):
     return synth.tile_blocks(synth.image_f16bits(seed, width, height))
+
+
+def tile_clamped(img):
+    """numpy statement of the reference caller's tiling (etc2packer/etc2packer.cpp:215-247): groups of
+    eight horizontally adjacent 4x4 blocks, reads clamped to the last column / row.
+    (H,W,C) -> (ceil(H/4) * ceil(ceil(W/4)/8)*8, 16, C)"""
+    h, w, c = img.shape
+    rows = (h + 3) // 4
+    per_row = ((w + 3) // 4 + 7) // 8 * 8
+    ys = np.minimum(np.arange(rows * 4), h - 1)
+    xs = np.minimum(np.arange(per_row * 4), w - 1)
+    big = img[ys][:, xs]
+    t = big.reshape(rows, 4, per_row, 4, c).transpose(0, 2, 1, 3, 4)
+    return np.ascontiguousarray(t.reshape(rows * per_row, 16, c))
+
+
+def compact_rows(packed, w, h):
+    rows = (h + 3) // 4
+    real = (w + 3) // 4
+    per_row = (real + 7) // 8 * 8
+    return np.ascontiguousarray(packed.reshape(rows, per_row, -1)[:, :real].reshape(rows * real, -1))
