@@ -153,6 +153,7 @@ _EXPORTS = (
     "cvttmi_encode_etc2_device", "cvttmi_encode_etc2_rgba_device", "cvttmi_encode_etc2_alpha_device",
     "cvttmi_encode_etc2", "cvttmi_encode_etc2_rgba", "cvttmi_encode_etc2_alpha",
     "cvttmi_tiled_block_count", "cvttmi_tile_image_device", "cvttmi_compact_rows_device",
+    "cvttmi_selftest_arith",
 )
 
 _lib = None
@@ -198,6 +199,8 @@ def load_library():
                                              ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
     lib.cvttmi_compact_rows_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
                                                ctypes.c_uint32, ctypes.c_void_p]
+    lib.cvttmi_selftest_arith.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
+                                          ctypes.POINTER(ctypes.c_uint64)]
     lib.cvttmi_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_set_exhaustive.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_timing_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
@@ -351,6 +354,12 @@ class Context:
         return self._encode_simple(self._lib.cvttmi_encode_etc2_alpha, self._lib.cvttmi_encode_etc2_alpha_device,
                                    "encode_etc2_alpha", blocks, options, out, stream, 64, 8)
 
+
+    def selftest_arith(self, count=1 << 22, seed=1):
+        """(divide mismatches, sqrt mismatches) of the device against the host's IEEE results"""
+        d, q = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self._lib.cvttmi_selftest_arith(self._h, count, seed, ctypes.byref(d), ctypes.byref(q)), "selftest_arith")
+        return int(d.value), int(q.value)
 
     # -- image -> PixelBlock tiling on the device (reference etc2packer.cpp:215-247, 275-281) --
     def tile_image(self, image, stream=None):

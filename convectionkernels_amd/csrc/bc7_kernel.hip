@@ -35,6 +35,17 @@
 
 #include "cvtt_kernel_common.h"
 
+// candidates a block may offer per round when 1 / 2 / <=4 / <=8 blocks of the wave offer at all
+#ifndef CVTT_SPEC_1
+#define CVTT_SPEC_1 8
+#define CVTT_SPEC_2 8
+#define CVTT_SPEC_4 6
+#define CVTT_SPEC_8 3
+#endif
+#ifndef CVTT_SPEC_16
+#define CVTT_SPEC_16 1
+#endif
+
 // Developer-only phase profile (-DCVTT_BC7_PROFILE): wave cycles per phase, summed over waves.
 #ifdef CVTT_BC7_PROFILE
 __device__ unsigned long long g_bc7Prof[48];
@@ -56,6 +67,20 @@ extern "C" int cvttmi_bc7_prof_read(unsigned long long *out)
 #define PROF_MARK(slot)
 #define PROF_COUNT(slot, n)
 #define PROF_FLUSH
+#endif
+
+// Developer-only trial trace (-DCVTT_BC7_DEBUG): per-round results of the dual-plane search of one block.
+#ifdef CVTT_BC7_DEBUG
+__device__ float g_bc7Dbg[2048];
+__device__ unsigned g_bc7DbgBlock = 0xffffffffu;
+extern "C" int cvttmi_bc7_debug_set(unsigned block)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_bc7DbgBlock), &block, sizeof(block)) == hipSuccess ? 0 : -1;
+}
+extern "C" int cvttmi_bc7_debug_read(float *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bc7Dbg), sizeof(float) * 2048) == hipSuccess ? 0 : -1;
+}
 #endif
 
 namespace
@@ -715,6 +740,19 @@ __device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int ind
                 errorA = slowA;
             }
 
+#ifdef CVTT_BC7_DEBUG
+            if (blockIdx.x * 16u + (u32)(lane >> 2) == g_bc7DbgBlock)
+            {
+                // slot: ((mode-4)*8 + rotationHint*2 + indexSelector) is not known here; the caller's config order is
+                // recovered from the write counter kept in element 0
+                const int cfgSlot = (int)g_bc7Dbg[0];
+                float *d = &g_bc7Dbg[16 + ((cfgSlot * 4 + c) * 3 + refine) * 12];
+                d[0] = (float)mode; d[1] = (float)indexSelector; d[2] = (float)c; d[3] = (float)refine;
+                d[4] = errorRGB; d[5] = errorA;
+                d[6] = (float)ep[0][0]; d[7] = (float)ep[0][1]; d[8] = (float)ep[0][2];
+                d[9] = (float)ep[1][0]; d[10] = (float)ep[1][1]; d[11] = (float)ep[1][2];
+            }
+#endif
             if (errorRGB < bestRGB.err)
             {
                 bestRGB.err = errorRGB;
@@ -1193,9 +1231,9 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
         {
             const float s012 = A.wSq[0] + A.wSq[1] + A.wSq[2];
             const float d0 = A.delta3;
-            const float d1 = 0.5000005f * __fsqrt_rn(s012 - A.wSq[0] + A.wSq[3]) * 1.000001f;
-            const float d2 = 0.5000005f * __fsqrt_rn(s012 - A.wSq[1] + A.wSq[3]) * 1.000001f;
-            const float d3 = 0.5000005f * __fsqrt_rn(s012 - A.wSq[2] + A.wSq[3]) * 1.000001f;
+            const float d1 = 0.5000005f * __builtin_amdgcn_sqrtf(s012 - A.wSq[0] + A.wSq[3]) * 1.000001f;
+            const float d2 = 0.5000005f * __builtin_amdgcn_sqrtf(s012 - A.wSq[1] + A.wSq[3]) * 1.000001f;
+            const float d3 = 0.5000005f * __builtin_amdgcn_sqrtf(s012 - A.wSq[2] + A.wSq[3]) * 1.000001f;
             lbRot[0] = planeBound(bs, 0, 1, 2, d0);
             lbRot[1] = planeBound(bs, 1, 2, 3, d1);
             lbRot[2] = planeBound(bs, 0, 2, 3, d2);
@@ -1311,6 +1349,14 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             ShapeBest b, bA;
             evalDual<FAST>(pix, mode, indexSelector, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
 
+#ifdef CVTT_BC7_DEBUG
+            if (blockIdx.x * 16u + (u32)(lane >> 2) == g_bc7DbgBlock && c == 0)
+            {
+                const int cfgSlot = (int)g_bc7Dbg[0];
+                g_bc7Dbg[1 + cfgSlot] = (float)(rotation * 100 + cfg);
+                g_bc7Dbg[0] = (float)(cfgSlot + 1);
+            }
+#endif
             const float combined = b.err + bA.err; // reference BC67.cpp:1942
             const int seq = 384 + cfg;
             if (combined < work.err || (combined == work.err && seq < workSeq))
@@ -1406,7 +1452,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 {
                     const bool use4 = (boundSet == 0);
                     const float wsum = A.wSq[0] + A.wSq[1] + A.wSq[2] + (use4 ? A.wSq[3] : 0.0f);
-                    const float scale = 2000.0f / (255.0f * __fsqrt_rn(wsum)); // wave-uniform
+                    const float scale = 2000.0f / (255.0f * __builtin_amdgcn_sqrtf(wsum)); // wave-uniform
                     const float invScaleSq = 1.0f / (scale * scale);
                     // rounding the projected points moves each by at most sqrt(2)/2 grid units
                     const float delta = (use4 ? A.delta4 : A.delta3) + 0.7072f / scale;
@@ -1511,7 +1557,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 if (numOffers == 0 || numItems + numOffers > itemCap)
                     break;
                 if (pass == 0)
-                    maxPasses = (numOffers <= 1) ? 8 : (numOffers <= 2) ? 6 : (numOffers <= 4) ? 4 : (numOffers <= 8) ? 2 : 1;
+                    maxPasses = (numOffers <= 1) ? CVTT_SPEC_1 : (numOffers <= 2) ? CVTT_SPEC_2 : (numOffers <= 4) ? CVTT_SPEC_4 : (numOffers <= 8) ? CVTT_SPEC_8 : CVTT_SPEC_16;
                 if (offer)
                 {
                     const int item = numItems + __popcll(offers & ((1ull << (lane & ~3)) - 1ull));

@@ -21,6 +21,11 @@ typedef float v2f __attribute__((ext_vector_type(2))); // v_pk_add_f32 / v_pk_mu
 __device__ __forceinline__ float sseMin(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ float sseMax(float a, float b) { return a > b ? a : b; }
 __device__ __forceinline__ float safeDenom(float v) { return v == 0.0f ? 1.0f : v; }
+// SQRTPS: correctly rounded.  NOT __fsqrt_rn -- in this toolchain that is the 1-ulp native
+// v_sqrt_f32 (__clang_hip_math.h); __builtin_sqrtf under -fhip-fp32-correctly-rounded-divide-sqrt
+// expands to the exact sequence.  (One block in two million lands on a rounding boundary
+// where the difference shows: tests/golden/regress_bc7_group_683856.npy.)
+__device__ __forceinline__ float sqrtExact(float v) { return __builtin_sqrtf(v); }
 
 // Clamp then CVTPS2DQ under round-to-nearest-even (reference ParallelMath.h:561-567,
 // 936-946).  fminf/fmaxf match MINPS/MAXPS here: a NaN input yields `hi`, and the sign of
@@ -221,7 +226,7 @@ __device__ __forceinline__ void pcaFinishT(const Fetch &F, u32 mask, const float
 #pragma unroll
     for (int ch = 0; ch < N; ch++)
         approxLen = approxLen + approx[ch] * approx[ch];
-    approxLen = safeDenom(__fsqrt_rn(approxLen));
+    approxLen = safeDenom(sqrtExact(approxLen));
     float direction[N];
 #pragma unroll
     for (int ch = 0; ch < N; ch++)

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
         }
         const float halfTrace = (covXX + covYY) * 0.5f;
         const float det = covXX * covYY - covXY * covXY;
-        const float mm = __fsqrt_rn(sseMax(0.0f, halfTrace * halfTrace - det));
+        const float mm = sqrtExact(sseMax(0.0f, halfTrace * halfTrace - det));
         const float ev = halfTrace + mm;
         float dx = (covYY - ev + covXY);
         const float dy = -(covXX - ev + covXY);

@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 #include <xmmintrin.h>
 #include <math.h>
 
@@ -28,6 +29,8 @@ extern "C" hipError_t cvttmi_launch_tile(const void *d_image, void *d_blocks, ui
                                          uint32_t bytesPerPixel, hipStream_t stream);
 extern "C" hipError_t cvttmi_launch_compact_rows(const void *d_packed, void *d_out, uint32_t width, uint32_t height,
                                                  uint32_t bytesPerBlock, hipStream_t stream);
+extern "C" hipError_t cvttmi_launch_selftest(uint64_t seed, uint64_t first, uint32_t count, void *d_operands, void *d_results,
+                                             hipStream_t stream);
 extern "C" hipError_t cvttmi_launch_bc1(const void *d_blocks, void *d_out, const CvttBc1Args *args,
                                         const CvttDeviceTables *d_tables, hipStream_t stream);
 
@@ -434,6 +437,61 @@ extern "C"
         e = cvttmi_launch_compact_rows(d_packed, d_out, width, height, bytesPerBlock, static_cast<hipStream_t>(hipStream));
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_HIP, "compact kernel launch", e);
+        return CVTTMI_OK;
+    }
+
+    int cvttmi_selftest_arith(cvttmi_context *ctx, uint64_t count, uint64_t seed, uint64_t *divMismatches, uint64_t *sqrtMismatches)
+    {
+        if (!ctx || !divMismatches || !sqrtMismatches)
+            return CVTTMI_E_INVALID;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        const uint32_t chunk = 1u << 20;
+        uint32_t *dOps = NULL, *dRes = NULL;
+        if (hipMalloc(&dOps, chunk * 8) != hipSuccess || hipMalloc(&dRes, chunk * 8) != hipSuccess)
+        {
+            hipFree(dOps);
+            return fail(ctx, CVTTMI_E_HIP, "hipMalloc (selftest)");
+        }
+        std::vector<uint32_t> ops(chunk * 2), res(chunk * 2);
+        uint64_t badDiv = 0, badSqrt = 0;
+        for (uint64_t first = 0; first < count; first += chunk)
+        {
+            const uint32_t n = static_cast<uint32_t>(count - first < chunk ? count - first : chunk);
+            e = cvttmi_launch_selftest(seed, first, n, dOps, dRes, NULL);
+            if (e == hipSuccess) e = hipMemcpy(ops.data(), dOps, (size_t)n * 8, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(res.data(), dRes, (size_t)n * 8, hipMemcpyDeviceToHost);
+            if (e != hipSuccess)
+            {
+                hipFree(dOps);
+                hipFree(dRes);
+                return fail(ctx, CVTTMI_E_HIP, "selftest kernel", e);
+            }
+            for (uint32_t i = 0; i < n; i++)
+            {
+                float a, b;
+                memcpy(&a, &ops[2 * i], 4);
+                memcpy(&b, &ops[2 * i + 1], 4);
+                const float q = _mm_cvtss_f32(_mm_div_ss(_mm_set_ss(a), _mm_set_ss(b)));
+                uint32_t absBits = ops[2 * i] & 0x7fffffffu;
+                float absA;
+                memcpy(&absA, &absBits, 4);
+                const float r = _mm_cvtss_f32(_mm_sqrt_ss(_mm_set_ss(absA)));
+                uint32_t qb, rb;
+                memcpy(&qb, &q, 4);
+                memcpy(&rb, &r, 4);
+                const bool qNan = (qb & 0x7fffffffu) > 0x7f800000u, gNan = (res[2 * i] & 0x7fffffffu) > 0x7f800000u;
+                if (!(qNan && gNan) && qb != res[2 * i])
+                    badDiv++;
+                if (rb != res[2 * i + 1])
+                    badSqrt++;
+            }
+        }
+        hipFree(dOps);
+        hipFree(dRes);
+        *divMismatches = badDiv;
+        *sqrtMismatches = badSqrt;
         return CVTTMI_OK;
     }
 

@@ -188,6 +188,12 @@ int cvttmi_tile_image_device(cvttmi_context *ctx, void *d_blocks, const void *d_
 int cvttmi_compact_rows_device(cvttmi_context *ctx, void *d_out, const void *d_packed, uint32_t width, uint32_t height,
                                uint32_t bytesPerBlock, void *hipStream);
 
+/* Arithmetic self-test: evaluates binary32 divide and square root on `count` pseudo-random finite
+ * operand patterns (zeros, denormals and both signs included) with the expressions and compiler
+ * flags the encoders use, and counts results that differ from the host's DIVSS / SQRTSS -- the
+ * arithmetic contract behind bit-exactness (reference ParallelMath.h:261-323, 959-965). */
+int cvttmi_selftest_arith(cvttmi_context *ctx, uint64_t count, uint64_t seed, uint64_t *divMismatches, uint64_t *sqrtMismatches);
+
 /* Time (ms, HIP events on the launch stream) and launch count of the kernels of the most
  * recent *_device call sequence since cvttmi_timing_reset(); used by bench.py's roofline. */
 int cvttmi_timing_enable(cvttmi_context *ctx, int enable);

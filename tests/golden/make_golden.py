@@ -141,9 +141,33 @@ def main():
 
     if "--skip-images" in sys.argv:
         return
+    plan = ref.default_plan()
+    if "--only-big-images" in sys.argv:
+        # configs 3, 4, 5 (BC6HU 4096^2, ETC2 RGBA 4096^2, BC7 16384^2): ~10 CPU-minutes on 8 cores;
+        # merged into the existing config_hashes.json
+        path = os.path.join(HERE, "config_hashes.json")
+        hashes = json.load(open(path))
+        assert hashes["rcp_hex"] == [int(x) for x in rcp.view(np.uint32)]
+        b = content.config_blocks_hdr(3, 4096, 4096)
+        out = parallel_encode(lambda x: ref.encode_bc6h(x, opt, False), b, 16)
+        hashes["config3_bc6hu_4096_seed3"] = hashlib.sha256(out.tobytes()).hexdigest()
+        print("config3", hashes["config3_bc6hu_4096_seed3"], flush=True)
+        b = content.config_blocks(4, 4096, 4096)
+        out = parallel_encode(lambda x: ref.encode_etc2(x, opt, 1), b, 16)
+        hashes["config4_etc2rgba_4096_seed4"] = hashlib.sha256(out.tobytes()).hexdigest()
+        print("config4", hashes["config4_etc2rgba_4096_seed4"], flush=True)
+        b = content.config_blocks(5, 16384, 16384)
+        out = parallel_encode(lambda x: fast.encode_bc7(x, opt, plan), b, 16)
+        hashes["config5_bc7_16384_seed5"] = hashlib.sha256(out.tobytes()).hexdigest()
+        # checksum of checksums: one SHA-256 per 4096-block-row band (4 bands of 4096 rows of pixels each)
+        band = out.shape[0] // 4
+        hashes["config5_band_hashes"] = [hashlib.sha256(out[i * band:(i + 1) * band].tobytes()).hexdigest() for i in range(4)]
+        print("config5", hashes["config5_bc7_16384_seed5"], flush=True)
+        with open(path, "w") as f:
+            json.dump(hashes, f, indent=1)
+        return
     # ---- whole-image hashes for the BASELINE.json configs ----
     hashes = {"rcp_hex": [int(x) for x in rcp.view(np.uint32)]}
-    plan = ref.default_plan()
     b = content.config_blocks(1, 256, 256)
     hashes["config1_bc1_256_seed1"] = hashlib.sha256(ref.encode_bc1(b, opt).tobytes()).hexdigest()
     for key, seed, opaque in (("config2_bc7_4096_seed2", 2, False), ("config2b_bc7_4096_seed2_opaque", 2, True)):

@@ -89,3 +89,20 @@ def test_gpu_vs_reference_on_this_box(gpu_ctx, ref_lib):
     assert (gpu_ctx.encode_bc6h(blocks, api.Options()) == ref_lib.encode_bc6h(blocks, ref_lib.default_options(), False)).all()
     sblocks = content.mixed_hdr_blocks(2025, 8, signed=True)
     assert (gpu_ctx.encode_bc6h(sblocks, api.Options(), signed=True) == ref_lib.encode_bc6h(sblocks, ref_lib.default_options(), True)).all()
+
+
+@pytest.mark.gpu
+def test_gpu_config3_full_size_hash(gpu_ctx):
+    """BASELINE configs[2]: EncodeBC6HU on 4096x4096 random HDR (seed 3): SHA-256 of the 16 MiB output equals the
+    reference's (canonical build, recorded RCPPS table)"""
+    import hashlib
+    import json
+    import torch
+    from convectionkernels_amd import api
+    h = json.load(open(os.path.join(GOLD, "config_hashes.json")))
+    if "config3_bc6hu_4096_seed3" not in h:
+        pytest.skip("config 3 hash not generated")
+    gpu_ctx.set_rcp_table(np.array(h["rcp_hex"], np.uint32).view(np.float32))
+    t = torch.from_numpy(content.config_blocks_hdr(3, 4096, 4096)).cuda()
+    out = gpu_ctx.encode_bc6h(t, api.Options()).cpu().numpy()
+    assert hashlib.sha256(out.tobytes()).hexdigest() == h["config3_bc6hu_4096_seed3"]

@@ -154,3 +154,46 @@ def test_config2_full_size_hash(gpu_ctx):
         head = np.load(os.path.join(GOLD, key + "_head.npy"))
         assert _diff(out[:512], head).size == 0
         assert hashlib.sha256(out.tobytes()).hexdigest() == h[key]
+
+
+def test_config5_full_size_hash(gpu_ctx):
+    """BASELINE config 5a: 16384x16384 random RGBA, seed 5 (16,777,216 blocks, 1 GiB in, 256 MiB out), through the
+    device-side tiling of the linear image; a checksum per quarter of the image and the SHA-256 of the whole
+    output equal the reference's."""
+    import torch
+    from convectionkernels_amd import synth
+    api = _api()
+    h = json.load(open(os.path.join(GOLD, "config_hashes.json")))
+    if "config5_bc7_16384_seed5" not in h:
+        pytest.skip("config 5 hash not generated")
+    gpu_ctx.set_rcp_table(np.array(h["rcp_hex"], np.uint32).view(np.float32))
+    img = torch.from_numpy(synth.image_rgba8(5, 16384, 16384)).cuda()
+    out = gpu_ctx.encode_image("bc7", img, api.Options(), api.BC7EncodingPlan())
+    torch.cuda.synchronize()
+    del img
+    out = out.cpu().numpy()
+    assert out.shape == (16777216, 16)
+    band = out.shape[0] // 4
+    for i in range(4):
+        assert hashlib.sha256(out[i * band:(i + 1) * band].tobytes()).hexdigest() == h["config5_band_hashes"][i], "band %d" % i
+    assert hashlib.sha256(out.tobytes()).hexdigest() == h["config5_bc7_16384_seed5"]
+
+
+def test_arithmetic_contract(gpu_ctx):
+    """the device's binary32 divide and square root are correctly rounded (DIVPS / SQRTPS of the reference's lanes):
+    4M pseudo-random finite operand patterns against the host"""
+    bad_div, bad_sqrt = gpu_ctx.selftest_arith(1 << 22, 20260929)
+    assert (bad_div, bad_sqrt) == (0, 0)
+
+
+def test_regression_sqrt_rounding_boundary(gpu_ctx, oracle_lib):
+    """group 85482 of BASELINE config 5: the PCA axis length of one block sits where a 1-ulp square root flips a 5-bit
+    endpoint (found by the 16384^2 hash); needs the exactly rounded sqrt"""
+    api = _api()
+    h = json.load(open(os.path.join(GOLD, "config_hashes.json")))
+    rcp = np.array(h["rcp_hex"], np.uint32).view(np.float32)
+    gpu_ctx.set_rcp_table(rcp)
+    g = np.load(os.path.join(GOLD, "regress_bc7_group_683856.npy"))
+    exp = oracle_lib.encode_bc7(g, pyref.make_options(), np.frombuffer(api.BC7EncodingPlan().tobytes(), np.uint8).copy(), rcp)
+    assert exp[2].tobytes().hex() == "d0f2f4e15a3ea851efaa08c23109ead3"
+    assert _diff(gpu_ctx.encode_bc7(g), exp).size == 0

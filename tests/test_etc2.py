@@ -92,3 +92,18 @@ def test_gpu_vs_reference_on_this_box(gpu_ctx, ref_lib):
     blocks = np.concatenate([content.mixed_ldr_blocks(777, 48), content.config_blocks(4, 64, 64)])
     for mode, _ in MODES:
         assert (_enc(gpu_ctx, mode)(blocks, api.Options()) == ref_lib.encode_etc2(blocks, ref_lib.default_options(), mode)).all()
+
+
+@pytest.mark.gpu
+def test_gpu_config4_full_size_hash(gpu_ctx):
+    """BASELINE configs[3]: EncodeETC2RGBA on 4096x4096 random RGBA (seed 4): SHA-256 of the output equals the reference's"""
+    import hashlib
+    import json
+    import torch
+    from convectionkernels_amd import api
+    h = json.load(open(os.path.join(GOLD, "config_hashes.json")))
+    if "config4_etc2rgba_4096_seed4" not in h:
+        pytest.skip("config 4 hash not generated")
+    t = torch.from_numpy(content.config_blocks(4, 4096, 4096)).cuda()
+    out = gpu_ctx.encode_etc2_rgba(t, api.Options()).cpu().numpy()
+    assert hashlib.sha256(out.tobytes()).hexdigest() == h["config4_etc2rgba_4096_seed4"]
