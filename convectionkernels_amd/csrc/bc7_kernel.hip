@@ -175,10 +175,13 @@ __device__ __forceinline__ void quadArgminBroadcast(ShapeBest &b, int lane)
 // pixels of the block are read from LDS (`lp`, 16 packed RGBA8 words) in ascending order of
 // the shape's members.  NRC = numRealChannels (3 for modes 0-3).  maxCount = wave-uniform
 // upper bound on popcount(mask).
-template <int NRC, bool FAST>
+// TRACE (BC7_RespectPunchThrough only): every round's error is also written to trialErr[round], and with
+// captureRound >= 0 the result is that round's instead of the best one.
+template <int NRC, bool FAST, bool TRACE>
 __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount, const ModeDesc md, const Unfinished &u,
                                           int pIter, int tweak, bool active, const CvttBc7Args &A,
-                                          const CvttDeviceTables *__restrict__ T, int numRefine, ShapeBest &best)
+                                          const CvttDeviceTables *__restrict__ T, int numRefine, ShapeBest &best,
+                                          float *trialErr = nullptr, int captureRound = -1)
 {
     const bool isRGB = (NRC == 3);
     const int range = 1 << md.indexBits;
@@ -375,7 +378,10 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
         if (isRGB)
             shapeError = shapeError + staticAlphaError;
 
-        if (active && shapeError < best.err)
+        if (TRACE && trialErr && active)
+            trialErr[refine] = shapeError;
+        const bool take = (TRACE && captureRound >= 0) ? (refine == captureRound) : (shapeError < best.err);
+        if (active && take)
         {
             best.err = shapeError;
             best.ep0 = packEP(ep[0]);
@@ -1129,7 +1135,7 @@ __device__ __forceinline__ void quadBroadcast(Unfinished &dst, const Unfinished 
     }
 }
 
-template <bool FAST>
+template <bool FAST, bool PT>
 __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
                                                         const CvttBc7Args A, const CvttDeviceTables *__restrict__ T,
                                                         const CvttBc7DevicePlan *__restrict__ dplan)
@@ -1141,6 +1147,8 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     __shared__ uint8_t s_myItems[16][8]; // the items a block offered this round
     __shared__ UnitRec s_unit[64];    // PCA seeds per (item, subset)
     __shared__ u32 s_res[96][5];      // best of every (item, subset): error, endpoints, indexes
+    // BC7_RespectPunchThrough: the error of every trial (chain x refine round) of every unit of the round
+    __shared__ float s_trialErr[PT ? 32 : 1][48];
     const cvttmi_bc7_plan *__restrict__ plan = &dplan->plan;
     const int lane = threadIdx.x;
     const u32 blockIndex = blockIdx.x * 16u + (u32)(lane >> 2);
@@ -1189,7 +1197,24 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     // RGB seeds extended with alpha = 255 (reference BC67.cpp:1113-1144)
     const bool wantPCA4 = anyBlockHasAlpha || !allowRGBModes;
     if (c == 0)
-        s_blkFlags[lane >> 2] = wantPCA4 ? 1u : 0u;
+    {
+        u32 f = wantPCA4 ? 1u : 0u;
+        if (PT)
+        {
+            // BC67.cpp:1054-1067: punch-through = every alpha is 0 or 255
+            bool isPunchThrough = true;
+            int maxAlpha = 0;
+#pragma unroll
+            for (int px = 0; px < 16; px++)
+            {
+                const int a = byteI(pix[px], 3);
+                isPunchThrough = isPunchThrough && (a == 0 || a == 255);
+                maxAlpha = a > maxAlpha ? a : maxAlpha;
+            }
+            f |= (isPunchThrough ? 2u : 0u) | (maxAlpha > 0 ? 4u : 0u) | (blockHasNonMaxAlpha ? 8u : 0u);
+        }
+        s_blkFlags[lane >> 2] = f;
+    }
 
     int numRefine = A.refineRounds;
     if (numRefine < 1)
@@ -1517,6 +1542,9 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
         }
 
         const int itemCap = (numSubsets == 3) ? 21 : 32; // items * subsets <= 64 lanes of the seed pass
+        // BC7_RespectPunchThrough couples the 8 blocks of a group in modes 6 and 7 (BC67.cpp:1283-1428): a
+        // partition one block wants is searched by its whole group, trial by trial in lock-step
+        const bool ptStage = PT && (mode == 6 || mode == 7);
         for (;;)
         {
             // ---- offers.  Pass 0: every block offers its cheapest-bound candidate.  When few blocks
@@ -1549,14 +1577,33 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                     pickLb = take ? oLb : pickLb;
                     pick = take ? oPick : pick;
                 }
-                const bool offer = pick < 64 && !(pickLb > work.err);
+                bool offer = pick < 64 && !(pickLb > work.err);
                 if (!offer)
                     aliveBits = 0; // everything left costs even more
+                if (ptStage)
+                {
+                    // the cheapest offer inside the group becomes the offer of all its blocks
+                    if (!offer)
+                    {
+                        pickLb = FLT_MAX;
+                        pick = 255;
+                    }
+#pragma unroll
+                    for (int step = 4; step <= 16; step <<= 1)
+                    {
+                        const float oLb = __shfl_xor(pickLb, step);
+                        const int oPick = __shfl_xor(pick, step);
+                        const bool take = (oLb < pickLb) || (oLb == pickLb && oPick < pick);
+                        pickLb = take ? oLb : pickLb;
+                        pick = take ? oPick : pick;
+                    }
+                    offer = pick < 64;
+                }
                 const u64 offers = __ballot(offer && c == 0);
                 const int numOffers = __popcll(offers);
                 if (numOffers == 0 || numItems + numOffers > itemCap)
                     break;
-                if (pass == 0)
+                if (pass == 0 && !ptStage)
                     maxPasses = (numOffers <= 1) ? CVTT_SPEC_1 : (numOffers <= 2) ? CVTT_SPEC_2 : (numOffers <= 4) ? CVTT_SPEC_4 : (numOffers <= 8) ? CVTT_SPEC_8 : CVTT_SPEC_16;
                 if (offer)
                 {
@@ -1595,7 +1642,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                     seeds = 4;
                 const bool rgbListed = ((dplan->rgbListed[shape >> 5] >> (shape & 31)) & 1u) != 0;
                 const bool rgbaListed = isRGB ? true : (((dplan->rgbaListed[shape >> 5] >> (shape & 31)) & 1u) != 0);
-                const bool uWantPCA4 = s_blkFlags[ublk] != 0;
+                const bool uWantPCA4 = (s_blkFlags[ublk] & 1u) != 0;
                 const bool wanted = seeds > 0;
                 // which PCA does this unit need?  (BC67.cpp:1085-1144; unlisted shapes keep zero seeds)
                 const bool do4 = wanted && !isRGB && uWantPCA4 && rgbaListed;
@@ -1703,10 +1750,18 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 PROF_COUNT(2, 64)
                 PROF_COUNT(3, __popcll(__ballot(active)))
                 ShapeBest b;
+                if (ptStage)
+                {
+                    // record every trial; the lock-step commit rule is applied below
+                    if (PT)
+                        evalChain<4, FAST, true>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b,
+                                                 &s_trialErr[inRange ? unit : 0][chain * 3], -1);
+                    continue;
+                }
                 if (isRGB)
-                    evalChain<3, FAST>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b);
+                    evalChain<3, FAST, false>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b);
                 else
-                    evalChain<4, FAST>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b);
+                    evalChain<4, FAST, false>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b);
                 groupArgminBroadcast(b, lane, CP);
                 if (inRange && chain == 0)
                 {
@@ -1728,6 +1783,93 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             }
             __syncthreads();
 
+            if (PT && ptStage)
+            {
+                __syncthreads();
+                // ---- the reference's commit rule, trial by trial, for the 8 blocks of a group together
+                // (BC67.cpp:1283-1428): lane = (group of the round, subset, block of the group) ----
+                const int perGroup = 8 * numSubsets;
+                const int gi = lane / perGroup, sub = (lane - gi * perGroup) >> 3, l8 = lane & 7;
+                const int item = gi * 8 + l8;
+                const bool scanActive = item < numItems && lane < (numItems / 8) * perGroup;
+                const int unit = scanActive ? item * numSubsets + sub : 0;
+                const UnitRec &r = s_unit[unit];
+                const u32 bf = s_blkFlags[r.blk];
+                const bool isPT = (bf & 2u) != 0, nonZeroA = (bf & 4u) != 0, nonMaxA = (bf & 8u) != 0;
+                const int slice = lane & ~7;
+                float held = FLT_MAX; // shapeBestError
+                int last = -1;        // the trial whose result the shape holds
+                for (int pI = 0; pI < 4; pI++)
+                {
+                    const bool invalid = scanActive && ((pI == 0) ? (isPT && nonZeroA) : (pI == 3) ? (isPT && nonMaxA) : isPT);
+                    const u32 invSlice = (u32)(__ballot(invalid) >> slice) & 0xffu;
+                    const bool allInvalid = invSlice == 0xffu;
+                    const bool needCheck = invSlice != 0;
+                    for (int tw = 0; tw < 4; tw++)
+                        for (int rf = 0; rf < numRefine; rf++)
+                        {
+                            const int t = (pI * 4 + tw) * 3 + rf;
+                            const bool run = scanActive && !allInvalid && tw < r.numTweak;
+                            const float e = run ? s_trialErr[unit][t] : FLT_MAX;
+                            const bool better = run && e < held;
+                            const bool anyBetter = ((u32)(__ballot(better) >> slice) & 0xffu) != 0;
+                            bool commit = better;
+                            if (needCheck)
+                            {
+                                // AndNot(punchThroughInvalid, better) = invalid & ~better (ParallelMath.h:900-905)
+                                commit = run && invalid && !better;
+                                if (((u32)(__ballot(commit) >> slice) & 0xffu) == 0)
+                                    commit = false;
+                            }
+                            if (anyBetter && commit)
+                            {
+                                held = e;
+                                last = t;
+                            }
+                        }
+                }
+                // the payload of the held trial: run that chain again up to its round
+                const bool have = scanActive && last >= 0;
+                const int hChain = have ? last / 3 : 0, hRound = have ? last - hChain * 3 : 0;
+                int maxCount = have ? __popc(r.mask) : 0;
+#pragma unroll
+                for (int step = 1; step < 64; step <<= 1)
+                {
+                    const int o = __shfl_xor(maxCount, step);
+                    maxCount = o > maxCount ? o : maxCount;
+                }
+                maxCount = __builtin_amdgcn_readfirstlane(maxCount);
+                Unfinished uu;
+#pragma unroll
+                for (int ch = 0; ch < 4; ch++)
+                {
+                    uu.base[ch] = r.base[ch];
+                    uu.offset[ch] = r.offset[ch];
+                }
+                ShapeBest b;
+                evalChain<4, FAST, true>(&s_pix[r.blk][0], r.mask, maxCount, md, uu, hChain >> 2, hChain & 3, have, A, T, numRefine, b,
+                                         nullptr, hRound);
+                if (scanActive)
+                {
+                    if (!have)
+                    {
+                        b.err = FLT_MAX;
+                        b.ep0 = b.ep1 = b.idxLo = b.idxHi = 0;
+                    }
+                    if (r.scErr < b.err)
+                    {
+                        b.err = r.scErr;
+                        b.ep0 = b.ep1 = 0xff000000u;
+                        b.idxLo = b.idxHi = 0;
+                    }
+                    u32 *dst = &s_res[r.slot][0];
+                    dst[0] = __builtin_bit_cast(u32, b.err);
+                    dst[1] = b.ep0;
+                    dst[2] = b.ep1;
+                    dst[3] = b.idxLo;
+                    dst[4] = b.idxHi;
+                }
+            }
             // ---- every offering block adds up the subsets of its items and commits ----
             for (int j = 0; j < 8; j++)
             {
@@ -1752,7 +1894,10 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                         pIdxHi |= src[4];
                     }
                     const int seq = stage * 64 + partition;
-                    if (totalError < work.err || (totalError == work.err && seq < workSeq))
+                    bool mayTake = laneRuns;
+                    if (ptStage && mode == 7 && anyBlockHasAlpha && !blockHasNonMaxAlpha && ((mode7RGB >> partition) & 1ull) == 0)
+                        mayTake = false; // searched for the group's sake only (BC67.cpp:1625-1635)
+                    if (mayTake && (totalError < work.err || (totalError == work.err && seq < workSeq)))
                     {
                         work.err = totalError;
                         workSeq = seq;
@@ -2007,11 +2152,17 @@ extern "C" hipError_t cvttmi_launch_bc7(const void *d_blocks, void *d_out, const
     const uint32_t waves = (args->numBlocks + 15u) / 16u;
     if (waves == 0)
         return hipSuccess;
-    if (args->flags & CVTTMI_FLAG_BC7_FAST_INDEXING)
-        hipLaunchKernelGGL(cvttmi_bc7_kernel<true>, dim3(waves), dim3(64), 0, stream, (const uint8_t *)d_blocks,
-                           (uint8_t *)d_out, *args, d_tables, d_plan);
+    const bool fast = (args->flags & CVTTMI_FLAG_BC7_FAST_INDEXING) != 0;
+    const bool pt = (args->flags & CVTTMI_FLAG_BC7_RESPECT_PUNCHTHROUGH) != 0;
+#define CVTT_LAUNCH(F, P) hipLaunchKernelGGL((cvttmi_bc7_kernel<F, P>), dim3(waves), dim3(64), 0, stream, (const uint8_t *)d_blocks, (uint8_t *)d_out, *args, d_tables, d_plan)
+    if (pt)
+    {
+        if (fast) CVTT_LAUNCH(true, true); else CVTT_LAUNCH(false, true);
+    }
     else
-        hipLaunchKernelGGL(cvttmi_bc7_kernel<false>, dim3(waves), dim3(64), 0, stream, (const uint8_t *)d_blocks,
-                           (uint8_t *)d_out, *args, d_tables, d_plan);
+    {
+        if (fast) CVTT_LAUNCH(true, false); else CVTT_LAUNCH(false, false);
+    }
+#undef CVTT_LAUNCH
     return hipGetLastError();
 }

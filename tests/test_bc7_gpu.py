@@ -14,7 +14,7 @@ from oracle import pyref
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
-GPU_VARIANTS = ["default", "uniform", "better", "ultra", "singlecolor", "refine1", "refine3", "weights",
+GPU_VARIANTS = ["default", "uniform", "punchthrough", "better", "ultra", "singlecolor", "refine1", "refine3", "weights",
                 "quality1", "quality20", "quality60", "quality100"]
 
 
@@ -112,7 +112,31 @@ def test_device_tensor_path_and_ragged_sizes(gpu_ctx, oracle_lib):
 def test_unsupported_flags_fail_loudly(gpu_ctx):
     api = _api()
     with pytest.raises(api.CvttError):
-        gpu_ctx.encode_bc7(np.zeros((8, 16, 4), np.uint8), api.Options(flags=api.Flags.Default | api.Flags.BC7_RespectPunchThrough))
+        gpu_ctx.encode_bc7(np.zeros((8, 16, 4), np.uint8),
+                           api.Options(flags=api.Flags.Default | api.Flags.BC7_RespectPunchThrough, refineRoundsBC7=4))
+
+
+def test_respect_punchthrough(gpu_ctx, oracle_lib):
+    """BC7_RespectPunchThrough: the reference's commit rule couples the 8 blocks of a group per trial in modes 6/7
+    (and commits NOT-better results of invalid lanes, ParallelMath.h:900-905); mixed content with binary alpha,
+    opaque and translucent blocks in the same groups, fast / slow indexing, with the single-colour flag, 1-3 refine rounds"""
+    api = _api()
+    rcp = oracle_lib.probe_rcp()
+    gpu_ctx.set_rcp_table(rcp)
+    blocks = np.concatenate([content.mixed_ldr_blocks(31337, 36), content.mixed_ldr_blocks(6, 12)[::-1]])
+    plan = api.BC7EncodingPlan()
+    PTF = api.Flags.BC7_RespectPunchThrough
+    for opt in (api.Options(flags=api.Flags.Default | PTF), api.Options(flags=api.Flags.Better | PTF),
+                api.Options(flags=api.Flags.Ultra | PTF), api.Options(flags=api.Flags.Default | PTF | api.Flags.Uniform, refineRoundsBC7=1),
+                api.Options(flags=api.Flags.Default | PTF, refineRoundsBC7=3)):
+        exp = oracle_lib.encode_bc7(blocks, np.frombuffer(opt.tobytes(), np.uint8).copy(),
+                                    np.frombuffer(plan.tobytes(), np.uint8).copy(), rcp, threads=8)
+        for exhaustive in (False, True):
+            gpu_ctx.set_exhaustive(exhaustive)
+            out = gpu_ctx.encode_bc7(blocks, opt, plan)
+            gpu_ctx.set_exhaustive(False)
+            bad = _diff(out, exp)
+            assert bad.size == 0, "flags %x refine %d exhaustive %s blocks %s" % (opt.flags, opt.refineRoundsBC7, exhaustive, bad[:8])
 
 
 def test_single_colour_flag_on_dark_content(gpu_ctx, oracle_lib):
