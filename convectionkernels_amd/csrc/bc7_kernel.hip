@@ -37,13 +37,13 @@
 
 // candidates a block may offer per round when 1 / 2 / <=4 / <=8 blocks of the wave offer at all
 #ifndef CVTT_SPEC_1
-#define CVTT_SPEC_1 8
-#define CVTT_SPEC_2 8
-#define CVTT_SPEC_4 6
-#define CVTT_SPEC_8 3
+#define CVTT_SPEC_1 32
+#define CVTT_SPEC_2 16
+#define CVTT_SPEC_4 8
+#define CVTT_SPEC_8 4
 #endif
 #ifndef CVTT_SPEC_16
-#define CVTT_SPEC_16 1
+#define CVTT_SPEC_16 2
 #endif
 
 // Developer-only phase profile (-DCVTT_BC7_PROFILE): wave cycles per phase, summed over waves.
@@ -1144,7 +1144,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     __shared__ u32 s_pix[16][16];     // the 16 blocks of this wave
     __shared__ u32 s_blkFlags[16];    // wantPCA4 of the block's group
     __shared__ u32 s_item[32];        // offers of the round: block | partition << 8
-    __shared__ uint8_t s_myItems[16][8]; // the items a block offered this round
+    __shared__ uint8_t s_myItems[16][32]; // the items a block offered this round
     __shared__ UnitRec s_unit[64];    // PCA seeds per (item, subset)
     __shared__ u32 s_res[96][5];      // best of every (item, subset): error, endpoints, indexes
     // BC7_RespectPunchThrough: the error of every trial (chain x refine round) of every unit of the round
@@ -1871,7 +1871,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 }
             }
             // ---- every offering block adds up the subsets of its items and commits ----
-            for (int j = 0; j < 8; j++)
+            for (int j = 0; j < 32; j++)
             {
                 if (__ballot(j < myCount) == 0)
                     break;
