@@ -48,8 +48,10 @@ struct EtcWaveShared
         } h;
         struct
         {
-            float err[2][kMaxAttempts];  // ETC1 differential attempts per half block
-            u32 packed[2][kMaxAttempts]; // selectors | colour << 16
+            // ETC1 differential attempts per half block: only the error is kept (5 KB); an attempt's
+            // colour is looked up again in dColors and the winners' selectors are recomputed, which
+            // keeps the workgroup at 72 KB of LDS = two workgroups per CU
+            float err[2][kMaxAttempts];
         } a;
     } u;
     unsigned short dColors[16][82];      // de-duplicated base colours per (sector, table)
@@ -835,7 +837,7 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
                     }
                     const int pos = sector == 0 ? id : id - prefix[8];
                     S.u.a.err[sector][pos] = totalError;
-                    S.u.a.packed[sector][pos] = selectors | ((u32)packed << 16);
+                    (void)selectors;
                 }
             }
             WAVE_SYNC();
@@ -867,6 +869,22 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
                         t = i;
                 return t;
             };
+            // colour (5:5:5) of attempt `pos` of a sector: which (table) list it falls in, then the list entry
+            auto colorOf = [&](int sector, int pos) -> u32 {
+                const int id = pos + (sector ? prefix[8] : 0);
+                int slot = sector * 8, base = sector ? prefix[8] : 0;
+#pragma unroll
+                for (int i = 1; i < 8; i++)
+                {
+                    const int start = sector ? prefix[8 + i] : prefix[i];
+                    if (id >= start)
+                    {
+                        slot = sector * 8 + i;
+                        base = start;
+                    }
+                }
+                return (u32)S.dColors[slot][id - base];
+            };
             auto legal = [](u32 a, u32 b) {
                 const int d2 = (int)(b >> 10) - (int)(a >> 10);
                 const int d1 = (int)((b >> 5) & 31u) - (int)((a >> 5) & 31u);
@@ -875,7 +893,7 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
             };
             if (m0 + m1 < blockBest0)
             {
-                const u32 p0 = S.u.a.packed[0][i0], p1 = S.u.a.packed[1][i1];
+                const u32 p0 = colorOf(0, i0) << 16, p1 = colorOf(1, i1) << 16;
                 if (legal(p0 >> 16, p1 >> 16))
                 {
                     etcBest = true;
@@ -919,7 +937,7 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
                         const float maxError1 = bestError - error0;
                         if (maxError1 < m1)
                             break;
-                        const u32 c0 = S.u.a.packed[0][nI] >> 16;
+                        const u32 c0 = colorOf(0, nI);
                         // the sorted scan of sector 1 stops at the first entry with error >= maxError1,
                         // so the partner is the cheapest LEGAL entry provided it is below maxError1
                         float pE = FLT_MAX;
@@ -927,7 +945,7 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
                         for (int j = lane; j < numA1; j += 64)
                         {
                             const float e = S.u.a.err[1][j];
-                            if (e < blockBest0 && legal(c0, S.u.a.packed[1][j] >> 16) && ((e < pE) || (e == pE && j < pI)))
+                            if (e < blockBest0 && legal(c0, colorOf(1, j)) && ((e < pE) || (e == pE && j < pI)))
                             {
                                 pE = e;
                                 pI = j;
@@ -940,8 +958,8 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
                             etcBest = true;
                             bestError = blockBest;
                             bFlip = flip;
-                            bPacked0 = S.u.a.packed[0][nI];
-                            bPacked1 = S.u.a.packed[1][pI];
+                            bPacked0 = c0 << 16;
+                            bPacked1 = colorOf(1, pI) << 16;
                             bTable0 = tableOf(0, nI);
                             bTable1 = tableOf(1, pI);
                         }
@@ -953,6 +971,41 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
 
         if (etcBest)
         {
+            // the winners' selectors again (TestHalfBlock, ETC.cpp:94-149): lane = sector * 8 + pixel of the half block
+            {
+                const int sector = (lane >> 3) & 1, spx = lane & 7;
+                const u32 colr = (sector ? bPacked1 : bPacked0) >> 16;
+                const int table = sector ? bTable1 : bTable0;
+                const int px = bFlip == 0 ? ((spx >> 1) * 4 + (spx & 1) + sector * 2) : (spx + sector * 8);
+                float be = FLT_MAX;
+                u32 bs = 0;
+#pragma unroll
+                for (int sel = 0; sel < 4; sel++)
+                {
+                    int m[3];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                    {
+                        const int q = (int)((colr >> (ch * 5)) & 31u);
+                        const int v = ((q << 3) | (q >> 2)) + T->etc1Modifiers[table][sel];
+                        m[ch] = v < 0 ? 0 : (v > 255 ? 255 : v);
+                    }
+                    const float e = E(m[0], m[1], m[2], S.pix[px], S.pw[px]);
+                    if (e < be)
+                        bs = (u32)sel;
+                    be = sseMin(e, be);
+                }
+                const u64 bit0 = __ballot(lane < 16 && (bs & 1u)), bit1 = __ballot(lane < 16 && (bs & 2u));
+                u32 sel0 = 0, sel1 = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                {
+                    sel0 |= (u32)(((bit0 >> i) & 1ull) | (((bit1 >> i) & 1ull) << 1)) << (2 * i);
+                    sel1 |= (u32)(((bit0 >> (8 + i)) & 1ull) | (((bit1 >> (8 + i)) & 1ull) << 1)) << (2 * i);
+                }
+                bPacked0 = (bPacked0 & 0xffff0000u) | sel0;
+                bPacked1 = (bPacked1 & 0xffff0000u) | sel1;
+            }
             // EmitETC1Block, ETC.cpp:2565-2622 (differential, opaque)
             const u32 col0 = bPacked0 >> 16, col1 = bPacked1 >> 16;
             int colors[2][3];
