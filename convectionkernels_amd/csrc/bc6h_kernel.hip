@@ -21,16 +21,36 @@
 #include "cvtt_kernel_common.h"
 #include <hip/hip_fp16.h>
 
+// Developer-only phase profile (-DCVTT_BC6H_PROFILE): wave cycles per phase, summed over waves.
+#ifdef CVTT_BC6H_PROFILE
+__device__ unsigned long long g_bc6hProf[16];
+#define PROF_DECL unsigned long long profT = __builtin_readcyclecounter(); unsigned long long profAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF_MARK(slot) { const unsigned long long now = __builtin_readcyclecounter(); profAcc[slot] += now - profT; profT = now; }
+#define PROF_FLUSH if (threadIdx.x == 0) { for (int i = 0; i < 8; i++) atomicAdd(&g_bc6hProf[i], profAcc[i]); }
+extern "C" int cvttmi_bc6h_prof_read(unsigned long long *out)
+{
+    unsigned long long zero[16] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bc6hProf), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bc6hProf), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#else
+#define PROF_DECL
+#define PROF_MARK(slot)
+#define PROF_FLUSH
+#endif
+
 namespace
 {
 // ---- per-partition "meta round" state, dwords per lane ----
-//   EPQ : 12 rounds x 2 subsets x 3 dwords (6 x int16: ep0.rgb, ep1.rgb) = 72   -> HBM/L2 scratch
-//   IDX : 12 rounds x 2 dwords (4 bits per pixel)                        = 24   -> LDS
-//   ERR : 12 rounds x 2 subsets                                          = 24   -> LDS
-// Keeping the endpoint history out of LDS leaves 12 KB of LDS per wave, so the CU can hold
-// 2-3 waves per SIMD; the scratch is [wave][entry][lane], i.e. one coalesced 256-byte line
-// per access, and stays L2 resident.
-constexpr int kIdxBase = 0, kErrBase = 24, kMetaDwords = 48, kEpqDwords = 72;
+//   ERR : 12 rounds x 2 subsets (subset error)                                         = 24  -> LDS
+//   EPQ : 12 rounds x 3 dwords (6 x int16: ep0.rgb, ep1.rgb) of the subset being searched = 36 -> LDS
+//         (duplicate-round test + legality pass); subset 0's copy moves to scratch when subset 1 starts
+//   scratch (HBM/L2, [wave][entry][lane], one coalesced 256-byte line per access):
+//         EPQ0 36 dwords + IDX 2 subsets x 12 rounds x 2 dwords (4 bits per pixel) = 84 dwords,
+//         written once per round, read only by the legality pass / at a commit
+constexpr int kErrBase = 0, kEpqBase = 24, kMetaDwords = 60;
+constexpr int kScrEpq0 = 0, kScrIdx = 36, kScratchDwords = 84;
 #ifndef CVTT_BC6H_WAVES
 #define CVTT_BC6H_WAVES 3
 #endif
@@ -181,11 +201,12 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 {
     __shared__ u32 meta[kMetaDwords][64];
     const int lane = threadIdx.x;
-    u32 *const epq = scratch + (size_t)blockIdx.x * (kEpqDwords * 64) + lane; // entry e at epq[e * 64]
+    u32 *const scr = scratch + (size_t)blockIdx.x * (kScratchDwords * 64) + lane; // entry e at scr[e * 64]
     const u32 blockIndex = blockIdx.x * 64u + (u32)lane;
     const bool valid = blockIndex < A.numBlocks;
     const bool uniformErr = (A.flags & CVTTMI_FLAG_UNIFORM) != 0;
 
+    PROF_DECL
     // ---- load + clamp to the "2CL" domain (BC67.cpp:2691-2715) ----
     u32 pk01[16], pk2[16];
     float linW[16][3]; // TwosCLHalfToFloat(pixel) * weight
@@ -245,19 +266,23 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
             if (((exists >> aPrec) & 1u) == 0)
                 continue;
 
+            // the (at most three) modes of this precision, in table order (BC67.cpp:2936-2942)
+            int numModesHere = 0, modesHere0 = 0, modesHere1 = 0, modesHere2 = 0;
+            for (int mode = 0; mode < 14; mode++)
+                if ((T->bc6hModeInfo[mode][1] != 0) == partitioned && T->bc6hModeInfo[mode][3] == aPrec)
+                {
+                    if (numModesHere == 0) modesHere0 = mode;
+                    else if (numModesHere == 1) modesHere1 = mode;
+                    else modesHere2 = mode;
+                    numModesHere++;
+                }
+
             for (int p = 0; p < numPartitions; p++)
             {
                 const u32 partitionMask = partitioned ? T->partition2[p] : 0u;
                 u32 roundValid0 = 0xfffu, roundValid1 = 0xfffu; // per group (identical in its 8 lanes)
 
-                // canonical build: the meta arrays start zeroed for every partition
-#pragma unroll 4
-                for (int e = 0; e < kMetaDwords; e++)
-                    meta[e][lane] = 0;
-#pragma unroll 4
-                for (int e = 0; e < kEpqDwords; e++)
-                    epq[e * 64] = 0;
-
+                PROF_MARK(6)
                 for (int subset = 0; subset < numSubsets; subset++)
                 {
                     const u32 subsetMask = partitioned ? (subset ? partitionMask : (~partitionMask & 0xffffu)) : 0xffffu;
@@ -275,6 +300,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                         pcaFinishT<3>(F, subsetMask, A.w, m, ufep);
                     }
 
+                    PROF_MARK(0)
                     for (int tweak = 0; tweak < 4; tweak++)
                     {
                         // EndpointRefiner<3> refiners[2]: fresh (zero in the canonical build) per tweak
@@ -290,6 +316,11 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             if (abortRemaining)
                             {
                                 if (subset == 0) roundValid0 &= ~(1u << metaRound); else roundValid1 &= ~(1u << metaRound);
+                                // never written by the reference: the canonical build's zero-initialised automatics
+                                // (fresh for every partition, BC67.cpp:2797-2801), which later rounds compare against
+                                meta[kEpqBase + metaRound * 3][lane] = 0;
+                                meta[kEpqBase + metaRound * 3 + 1][lane] = 0;
+                                meta[kEpqBase + metaRound * 3 + 2][lane] = 0;
                                 continue;
                             }
 
@@ -361,6 +392,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     }
                                 }
 
+                            PROF_MARK(1)
                             // ---- raw (un-inverted) index of every pixel of the subset ----
                             float selBest[16];
                             int selIdx[16];
@@ -432,6 +464,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 }
                             }
 
+                            PROF_MARK(2)
                             // anchor index decides the inversion (BC67.cpp:2525-2547)
                             int fixRaw = 0;
 #pragma unroll
@@ -452,33 +485,26 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             const u32 qa = ((u32)q[0][0] & 0xffffu) | ((u32)q[0][1] << 16);
                             const u32 qb = ((u32)q[0][2] & 0xffffu) | ((u32)q[1][0] << 16);
                             const u32 qc = ((u32)q[1][1] & 0xffffu) | ((u32)q[1][2] << 16);
-                            const int epqAt = (metaRound * 2 + subset) * 3;
-
-                            // ---- duplicate-round test against every earlier meta round (group-wide) ----
+                            // ---- duplicate-round test against every earlier meta round of this subset (group-wide) ----
                             bool anySame = false;
                             for (int prev = 0; prev < metaRound; prev++)
-                            {
-                                const int at = (prev * 2 + subset) * 3;
-                                anySame = anySame || (epq[at * 64] == qa && epq[(at + 1) * 64] == qb && epq[(at + 2) * 64] == qc);
-                            }
-                            epq[epqAt * 64] = qa;
-                            epq[(epqAt + 1) * 64] = qb;
-                            epq[(epqAt + 2) * 64] = qc;
+                                anySame = anySame || (meta[kEpqBase + prev * 3][lane] == qa && meta[kEpqBase + prev * 3 + 1][lane] == qb &&
+                                                      meta[kEpqBase + prev * 3 + 2][lane] == qc);
+                            meta[kEpqBase + metaRound * 3][lane] = qa;
+                            meta[kEpqBase + metaRound * 3 + 1][lane] = qb;
+                            meta[kEpqBase + metaRound * 3 + 2][lane] = qc;
+                            PROF_MARK(3)
                             const bool groupAllSame = (metaRound > 0) && (groupBits(__ballot(anySame), lane) == 0xffu);
                             if (groupAllSame)
                             {
                                 if (subset == 0) roundValid0 &= ~(1u << metaRound); else roundValid1 &= ~(1u << metaRound);
-                                // the anchor index was already stored by QuantizeEndpoints (BC67.cpp:2547)
-                                const int at = kIdxBase + metaRound * 2 + (fixupIndex >> 3);
-                                const int sh = 4 * (fixupIndex & 7);
-                                const u32 fi = (u32)(invert ? (indexRange - 1) - fixRaw : fixRaw);
-                                meta[at][lane] = (meta[at][lane] & ~(0xfu << sh)) | (fi << sh);
+                                // (its indexes are never read: only valid rounds reach the commit)
                             }
                             else
                             {
                                 // ---- error, indexes and refiner sums in pixel order (BC67.cpp:2879-2909) ----
                                 float subsetError = 0.0f;
-                                u32 idxLo = meta[kIdxBase + metaRound * 2][lane], idxHi = meta[kIdxBase + metaRound * 2 + 1][lane];
+                                u32 idxLo = 0, idxHi = 0;
 #pragma unroll
                                 for (int px = 0; px < 16; px++)
                                     if ((sm >> px) & 1u)
@@ -486,9 +512,9 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                         const int raw = selIdx[px];
                                         const int index = invert ? (indexRange - 1) - raw : raw;
                                         if (px < 8)
-                                            idxLo = (idxLo & ~(0xfu << (4 * px))) | ((u32)index << (4 * px));
+                                            idxLo |= (u32)index << (4 * px);
                                         else
-                                            idxHi = (idxHi & ~(0xfu << (4 * (px - 8)))) | ((u32)index << (4 * (px - 8)));
+                                            idxHi |= (u32)index << (4 * (px - 8));
 
                                         const int weight = mad24(weightRcp, raw, 256) >> 9;
                                         const u32 a = fetchPixel(pk01[px]), b = fetchPixel(pk2[px]);
@@ -530,11 +556,19 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                             refCount++;
                                         }
                                     }
-                                meta[kIdxBase + metaRound * 2][lane] = idxLo;
-                                meta[kIdxBase + metaRound * 2 + 1][lane] = idxHi;
+                                scr[(kScrIdx + (subset * 12 + metaRound) * 2) * 64] = idxLo;
+                                scr[(kScrIdx + (subset * 12 + metaRound) * 2 + 1) * 64] = idxHi;
                                 meta[kErrBase + metaRound * 2 + subset][lane] = __float_as_uint(subsetError);
                             }
+                            PROF_MARK(4)
                         }
+                    }
+                    if (partitioned && subset == 0)
+                    {
+                        // subset 1 reuses the LDS history; the legality pass reads subset 0's from scratch
+#pragma unroll 4
+                        for (int e = 0; e < 36; e++)
+                            scr[(kScrEpq0 + e) * 64] = meta[kEpqBase + e][lane];
                     }
                 }
 
@@ -542,6 +576,10 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                 const int numMeta1 = partitioned ? 12 : 1;
                 for (int meta0 = 0; meta0 < 12; meta0++)
                 {
+                    if (__ballot((roundValid0 >> meta0) & 1u) == 0)
+                        continue;
+                    bool haveE0 = false;
+                    int e0[2][3] = {{0, 0, 0}, {0, 0, 0}};
                     for (int meta1 = 0; meta1 < numMeta1; meta1++)
                     {
                         const bool roundsOk = ((roundValid0 >> meta0) & 1u) && (!partitioned || ((roundValid1 >> meta1) & 1u));
@@ -555,24 +593,38 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                         bool needsCommit = errorBetter;
                         bool groupDone = !groupAny; // this group's mode loop has ended (or never started)
 
-                        // quantised endpoints of the two rounds
-                        int e0[2][3], e1[2][3];
+                        // quantised endpoints of the two rounds (subset 0: once per meta0)
+                        if (!haveE0)
                         {
-                            const int at0 = (meta0 * 2 + 0) * 3, at1 = (meta1 * 2 + 1) * 3;
-                            const u32 a0 = epq[at0 * 64], b0 = epq[(at0 + 1) * 64], c0 = epq[(at0 + 2) * 64];
-                            const u32 a1 = epq[at1 * 64], b1 = epq[(at1 + 1) * 64], c1 = epq[(at1 + 2) * 64];
+                            u32 a0, b0, c0;
+                            if (partitioned)
+                            {
+                                a0 = scr[(kScrEpq0 + meta0 * 3) * 64];
+                                b0 = scr[(kScrEpq0 + meta0 * 3 + 1) * 64];
+                                c0 = scr[(kScrEpq0 + meta0 * 3 + 2) * 64];
+                            }
+                            else
+                            {
+                                a0 = meta[kEpqBase + meta0 * 3][lane];
+                                b0 = meta[kEpqBase + meta0 * 3 + 1][lane];
+                                c0 = meta[kEpqBase + meta0 * 3 + 2][lane];
+                            }
                             e0[0][0] = (int)(short)(a0 & 0xffffu); e0[0][1] = (int)(short)(a0 >> 16); e0[0][2] = (int)(short)(b0 & 0xffffu);
                             e0[1][0] = (int)(short)(b0 >> 16); e0[1][1] = (int)(short)(c0 & 0xffffu); e0[1][2] = (int)(short)(c0 >> 16);
+                            haveE0 = true;
+                        }
+                        int e1[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                        if (partitioned)
+                        {
+                            const u32 a1 = meta[kEpqBase + meta1 * 3][lane], b1 = meta[kEpqBase + meta1 * 3 + 1][lane],
+                                      c1 = meta[kEpqBase + meta1 * 3 + 2][lane];
                             e1[0][0] = (int)(short)(a1 & 0xffffu); e1[0][1] = (int)(short)(a1 >> 16); e1[0][2] = (int)(short)(b1 & 0xffffu);
                             e1[1][0] = (int)(short)(b1 >> 16); e1[1][1] = (int)(short)(c1 & 0xffffu); e1[1][2] = (int)(short)(c1 >> 16);
                         }
 
-                        for (int mode = 0; mode < 14; mode++)
+                        for (int mi = 0; mi < numModesHere; mi++)
                         {
-                            const int miPartitioned = T->bc6hModeInfo[mode][1];
-                            const int miPrec = T->bc6hModeInfo[mode][3];
-                            if ((miPartitioned != 0) != partitioned || miPrec != aPrec)
-                                continue;
+                            const int mode = (mi == 0) ? modesHere0 : (mi == 1) ? modesHere1 : modesHere2;
                             const bool transformed = T->bc6hModeInfo[mode][2] != 0;
                             const int bPrec[3] = {T->bc6hModeInfo[mode][4], T->bc6hModeInfo[mode][5], T->bc6hModeInfo[mode][6]};
 
@@ -609,33 +661,34 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 
                             const bool commit = errorBetter && legal && !groupDone;
                             const u32 gCommit = groupBits(__ballot(commit), lane);
-                            if (commit)
+                            if (__ballot(commit) != 0)
                             {
-                                bestError = combined;
-                                bestMode = mode;
-                                bestPartition = p;
-                                bestEP[0] = ((u32)enc[0][0][0] & 0xffffu) | ((u32)enc[0][0][1] << 16);
-                                bestEP[1] = ((u32)enc[0][0][2] & 0xffffu) | ((u32)enc[0][1][0] << 16);
-                                bestEP[2] = ((u32)enc[0][1][1] & 0xffffu) | ((u32)enc[0][1][2] << 16);
+                                // indexes: subset-0 pixels from round meta0, subset-1 pixels from meta1 (rare: a few commits per block)
+                                const u32 lo0 = scr[(kScrIdx + meta0 * 2) * 64], hi0 = scr[(kScrIdx + meta0 * 2 + 1) * 64];
+                                u32 lo1 = 0, hi1 = 0;
                                 if (partitioned)
                                 {
-                                    bestEP[3] = ((u32)enc[1][0][0] & 0xffffu) | ((u32)enc[1][0][1] << 16);
-                                    bestEP[4] = ((u32)enc[1][0][2] & 0xffffu) | ((u32)enc[1][1][0] << 16);
-                                    bestEP[5] = ((u32)enc[1][1][1] & 0xffffu) | ((u32)enc[1][1][2] << 16);
+                                    lo1 = scr[(kScrIdx + (12 + meta1) * 2) * 64];
+                                    hi1 = scr[(kScrIdx + (12 + meta1) * 2 + 1) * 64];
                                 }
-                                // indexes: subset-0 pixels from round meta0, subset-1 pixels from meta1
-                                const u32 lo0 = meta[kIdxBase + meta0 * 2][lane], hi0 = meta[kIdxBase + meta0 * 2 + 1][lane];
-                                const u32 lo1 = meta[kIdxBase + meta1 * 2][lane], hi1 = meta[kIdxBase + meta1 * 2 + 1][lane];
-                                u32 nLo = 0, nHi = 0;
-#pragma unroll
-                                for (int px = 0; px < 8; px++)
+                                if (commit)
                                 {
-                                    if ((partitionMask >> px) & 1u) nLo |= 0xfu << (4 * px);
-                                    if ((partitionMask >> (px + 8)) & 1u) nHi |= 0xfu << (4 * px);
+                                    bestError = combined;
+                                    bestMode = mode;
+                                    bestPartition = p;
+                                    bestEP[0] = ((u32)enc[0][0][0] & 0xffffu) | ((u32)enc[0][0][1] << 16);
+                                    bestEP[1] = ((u32)enc[0][0][2] & 0xffffu) | ((u32)enc[0][1][0] << 16);
+                                    bestEP[2] = ((u32)enc[0][1][1] & 0xffffu) | ((u32)enc[0][1][2] << 16);
+                                    if (partitioned)
+                                    {
+                                        bestEP[3] = ((u32)enc[1][0][0] & 0xffffu) | ((u32)enc[1][0][1] << 16);
+                                        bestEP[4] = ((u32)enc[1][0][2] & 0xffffu) | ((u32)enc[1][1][0] << 16);
+                                        bestEP[5] = ((u32)enc[1][1][1] & 0xffffu) | ((u32)enc[1][1][2] << 16);
+                                    }
+                                    bestIdxLo = lo0 | lo1; // the two subsets' pixels are disjoint nibbles
+                                    bestIdxHi = hi0 | hi1;
+                                    needsCommit = false;
                                 }
-                                bestIdxLo = (lo0 & ~nLo) | (lo1 & nLo);
-                                bestIdxHi = (hi0 & ~nHi) | (hi1 & nHi);
-                                needsCommit = false;
                             }
                             // `continue` when nobody of the group commits skips the needsCommit test (BC67.cpp:2954-2955)
                             if (gCommit != 0 && groupBits(__ballot(needsCommit && !groupDone), lane) == 0)
@@ -649,6 +702,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
         }
     }
 
+    PROF_MARK(5)
+    PROF_FLUSH
     // ---- header scatter + indexes (BC67.cpp:2992-3050, BC6H_IO: table from tools/gen_bc6h_layout.py) ----
     if (valid)
     {
@@ -714,7 +769,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 
 extern "C" size_t cvttmi_bc6h_scratch_bytes(uint32_t numBlocks)
 {
-    return (size_t)((numBlocks + 63u) / 64u) * kEpqDwords * 64 * sizeof(u32);
+    return (size_t)((numBlocks + 63u) / 64u) * kScratchDwords * 64 * sizeof(u32);
 }
 
 extern "C" hipError_t cvttmi_launch_bc6h(const void *d_blocks, void *d_out, const CvttBc6hArgs *args,
