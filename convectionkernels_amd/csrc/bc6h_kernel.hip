@@ -580,6 +580,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                         continue;
                     bool haveE0 = false;
                     int e0[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                    bool legal0[3] = {true, true, true}; // subset 0's own delta fits mode mi (a combination can only be legal if it does)
                     for (int meta1 = 0; meta1 < numMeta1; meta1++)
                     {
                         const bool roundsOk = ((roundValid0 >> meta0) & 1u) && (!partitioned || ((roundValid1 >> meta1) & 1u));
@@ -612,6 +613,25 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             e0[0][0] = (int)(short)(a0 & 0xffffu); e0[0][1] = (int)(short)(a0 >> 16); e0[0][2] = (int)(short)(b0 & 0xffffu);
                             e0[1][0] = (int)(short)(b0 >> 16); e0[1][1] = (int)(short)(c0 & 0xffffu); e0[1][2] = (int)(short)(c0 >> 16);
                             haveE0 = true;
+                            for (int mi = 0; mi < numModesHere; mi++)
+                            {
+                                const int mode = (mi == 0) ? modesHere0 : (mi == 1) ? modesHere1 : modesHere2;
+                                bool ok = true;
+                                if (T->bc6hModeInfo[mode][2] != 0)
+                                {
+                                    const int mask = (1 << aPrec) - 1;
+#pragma unroll
+                                    for (int ch = 0; ch < 3; ch++)
+                                    {
+                                        const int lost = 16 - T->bc6hModeInfo[mode][4 + ch];
+                                        const int bReduced = e0[1][ch] & mask & 0xffff;
+                                        const int d16 = (int)(short)(unsigned short)(e0[1][ch] - e0[0][ch]);
+                                        const int delta = (int)(short)(unsigned short)((u32)d16 << lost) >> lost;
+                                        ok = ok && (((delta + e0[0][ch]) & mask & 0xffff) == bReduced);
+                                    }
+                                }
+                                if (mi == 0) legal0[0] = ok; else if (mi == 1) legal0[1] = ok; else legal0[2] = ok;
+                            }
                         }
                         int e1[2][3] = {{0, 0, 0}, {0, 0, 0}};
                         if (partitioned)
@@ -625,6 +645,10 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                         for (int mi = 0; mi < numModesHere; mi++)
                         {
                             const int mode = (mi == 0) ? modesHere0 : (mi == 1) ? modesHere1 : modesHere2;
+                            // nobody can commit in this mode: the mode changes no state (BC67.cpp:2954-2955 `continue`)
+                            const bool l0 = (mi == 0) ? legal0[0] : (mi == 1) ? legal0[1] : legal0[2];
+                            if (__ballot(errorBetter && l0 && !groupDone) == 0)
+                                continue;
                             const bool transformed = T->bc6hModeInfo[mode][2] != 0;
                             const int bPrec[3] = {T->bc6hModeInfo[mode][4], T->bc6hModeInfo[mode][5], T->bc6hModeInfo[mode][6]};
 
