@@ -574,17 +574,71 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 
                 // ---- delta-coding legality + commit, BC67.cpp:2914-2986 ----
                 const int numMeta1 = partitioned ? 12 : 1;
+                // cheapest valid subset-1 round: no combination with meta0 can beat the best unless this one does
+                float minErr1 = 0.0f;
+                if (partitioned)
+                {
+                    minErr1 = FLT_MAX;
+                    for (int m = 0; m < 12; m++)
+                    {
+                        const float e = __uint_as_float(meta[kErrBase + m * 2 + 1][lane]);
+                        if (((roundValid1 >> m) & 1u) && e < minErr1)
+                            minErr1 = e;
+                    }
+                }
                 for (int meta0 = 0; meta0 < 12; meta0++)
                 {
-                    if (__ballot((roundValid0 >> meta0) & 1u) == 0)
+                    const bool valid0 = ((roundValid0 >> meta0) & 1u) != 0;
+                    const float err0 = __uint_as_float(meta[kErrBase + meta0 * 2][lane]);
+                    const bool canBeat = valid0 && ((partitioned ? err0 + minErr1 : err0) < bestError);
+                    if (__ballot(canBeat) == 0)
                         continue;
-                    bool haveE0 = false;
-                    int e0[2][3] = {{0, 0, 0}, {0, 0, 0}};
-                    bool legal0[3] = {true, true, true}; // subset 0's own delta fits mode mi (a combination can only be legal if it does)
+                    // quantised endpoints of subset 0's round, and whether its own delta fits each mode of this precision
+                    int e0[2][3];
+                    bool legal0[3] = {true, true, true};
+                    {
+                        u32 a0, b0, c0;
+                        if (partitioned)
+                        {
+                            a0 = scr[(kScrEpq0 + meta0 * 3) * 64];
+                            b0 = scr[(kScrEpq0 + meta0 * 3 + 1) * 64];
+                            c0 = scr[(kScrEpq0 + meta0 * 3 + 2) * 64];
+                        }
+                        else
+                        {
+                            a0 = meta[kEpqBase + meta0 * 3][lane];
+                            b0 = meta[kEpqBase + meta0 * 3 + 1][lane];
+                            c0 = meta[kEpqBase + meta0 * 3 + 2][lane];
+                        }
+                        e0[0][0] = (int)(short)(a0 & 0xffffu); e0[0][1] = (int)(short)(a0 >> 16); e0[0][2] = (int)(short)(b0 & 0xffffu);
+                        e0[1][0] = (int)(short)(b0 >> 16); e0[1][1] = (int)(short)(c0 & 0xffffu); e0[1][2] = (int)(short)(c0 >> 16);
+                        for (int mi = 0; mi < numModesHere; mi++)
+                        {
+                            const int mode = (mi == 0) ? modesHere0 : (mi == 1) ? modesHere1 : modesHere2;
+                            bool ok = true;
+                            if (T->bc6hModeInfo[mode][2] != 0)
+                            {
+                                const int mask = (1 << aPrec) - 1;
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++)
+                                {
+                                    const int lost = 16 - T->bc6hModeInfo[mode][4 + ch];
+                                    const int bReduced = e0[1][ch] & mask & 0xffff;
+                                    const int d16 = (int)(short)(unsigned short)(e0[1][ch] - e0[0][ch]);
+                                    const int delta = (int)(short)(unsigned short)((u32)d16 << lost) >> lost;
+                                    ok = ok && (((delta + e0[0][ch]) & mask & 0xffff) == bReduced);
+                                }
+                            }
+                            if (mi == 0) legal0[0] = ok; else if (mi == 1) legal0[1] = ok; else legal0[2] = ok;
+                        }
+                    }
+                    // a lane whose subset-0 delta fits no mode cannot commit with this meta0 whatever meta1 is
+                    if (__ballot(canBeat && (legal0[0] || (numModesHere > 1 && legal0[1]) || (numModesHere > 2 && legal0[2]))) == 0)
+                        continue;
                     for (int meta1 = 0; meta1 < numMeta1; meta1++)
                     {
-                        const bool roundsOk = ((roundValid0 >> meta0) & 1u) && (!partitioned || ((roundValid1 >> meta1) & 1u));
-                        float combined = __uint_as_float(meta[kErrBase + meta0 * 2][lane]);
+                        const bool roundsOk = valid0 && (!partitioned || ((roundValid1 >> meta1) & 1u));
+                        float combined = err0;
                         if (partitioned)
                             combined = combined + __uint_as_float(meta[kErrBase + meta1 * 2 + 1][lane]);
                         const bool errorBetter = roundsOk && (combined < bestError);
@@ -594,45 +648,6 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                         bool needsCommit = errorBetter;
                         bool groupDone = !groupAny; // this group's mode loop has ended (or never started)
 
-                        // quantised endpoints of the two rounds (subset 0: once per meta0)
-                        if (!haveE0)
-                        {
-                            u32 a0, b0, c0;
-                            if (partitioned)
-                            {
-                                a0 = scr[(kScrEpq0 + meta0 * 3) * 64];
-                                b0 = scr[(kScrEpq0 + meta0 * 3 + 1) * 64];
-                                c0 = scr[(kScrEpq0 + meta0 * 3 + 2) * 64];
-                            }
-                            else
-                            {
-                                a0 = meta[kEpqBase + meta0 * 3][lane];
-                                b0 = meta[kEpqBase + meta0 * 3 + 1][lane];
-                                c0 = meta[kEpqBase + meta0 * 3 + 2][lane];
-                            }
-                            e0[0][0] = (int)(short)(a0 & 0xffffu); e0[0][1] = (int)(short)(a0 >> 16); e0[0][2] = (int)(short)(b0 & 0xffffu);
-                            e0[1][0] = (int)(short)(b0 >> 16); e0[1][1] = (int)(short)(c0 & 0xffffu); e0[1][2] = (int)(short)(c0 >> 16);
-                            haveE0 = true;
-                            for (int mi = 0; mi < numModesHere; mi++)
-                            {
-                                const int mode = (mi == 0) ? modesHere0 : (mi == 1) ? modesHere1 : modesHere2;
-                                bool ok = true;
-                                if (T->bc6hModeInfo[mode][2] != 0)
-                                {
-                                    const int mask = (1 << aPrec) - 1;
-#pragma unroll
-                                    for (int ch = 0; ch < 3; ch++)
-                                    {
-                                        const int lost = 16 - T->bc6hModeInfo[mode][4 + ch];
-                                        const int bReduced = e0[1][ch] & mask & 0xffff;
-                                        const int d16 = (int)(short)(unsigned short)(e0[1][ch] - e0[0][ch]);
-                                        const int delta = (int)(short)(unsigned short)((u32)d16 << lost) >> lost;
-                                        ok = ok && (((delta + e0[0][ch]) & mask & 0xffff) == bReduced);
-                                    }
-                                }
-                                if (mi == 0) legal0[0] = ok; else if (mi == 1) legal0[1] = ok; else legal0[2] = ok;
-                            }
-                        }
                         int e1[2][3] = {{0, 0, 0}, {0, 0, 0}};
                         if (partitioned)
                         {
