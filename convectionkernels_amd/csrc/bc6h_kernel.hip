@@ -12,14 +12,18 @@
 // (BC67.cpp:2853-2877, AllSet) and the mode-commit loop (2936-2984, AnySet) -- and both are
 // evaluated in the reference's exact candidate order, so every loop here is wave-uniform and
 // the two group predicates are 8-lane slices of a wave ballot.
-//   * pixels: 2CL integers packed in 32 VGPRs, their weighted linear values in 48 VGPRs;
-//   * slow indexing walks the interpolants in the OUTER loop (one reconstruction per
-//     interpolant per round instead of a 16-entry table per lane) and keeps a running
-//     (error, index) per pixel -- same strict '<' order as IndexSelectorHDR.h:125-139;
-//   * the per-partition "meta round" results (quantised endpoints, indexes, errors of up to
-//     12 rounds x 2 subsets) live in LDS, [entry][lane] so every access is conflict free.
+//   * pixels: 2CL integers packed in 32 VGPRs; their weighted linear values are re-derived per
+//     use (one v_cvt_f32_f16 + multiply) instead of living in 48 more registers;
+//   * slow indexing: the weighted linear colours of the 8 / 16 interpolants of a round sit in
+//     registers and every pixel scans them in order (strict '<', IndexSelectorHDR.h:125-139);
+//     the anchor pixel goes first because its index decides the endpoint inversion, and a
+//     round that turns out to be a duplicate never looks at the other pixels;
+//   * the "meta round" results of a partition (errors, endpoints of the subset being searched)
+//     live in LDS, [entry][lane] so every access is conflict free; indexes and subset 0's
+//     endpoints go to an L2-resident scratch that only the commit path reads back.
 #include "cvtt_kernel_common.h"
 #include <hip/hip_fp16.h>
+#include <type_traits>
 
 // Developer-only phase profile (-DCVTT_BC6H_PROFILE): wave cycles per phase, summed over waves.
 #ifdef CVTT_BC6H_PROFILE
@@ -209,7 +213,6 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
     PROF_DECL
     // ---- load + clamp to the "2CL" domain (BC67.cpp:2691-2715) ----
     u32 pk01[16], pk2[16];
-    float linW[16][3]; // TwosCLHalfToFloat(pixel) * weight
     {
         const uint2 *src = reinterpret_cast<const uint2 *>(blocks + (size_t)(valid ? blockIndex : 0u) * 128u);
 #pragma unroll
@@ -231,7 +234,6 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                     x = x < 0 ? 0 : x;
                 x = x > 31743 ? 31743 : x;
                 v[ch] = x;
-                linW[px][ch] = twosCLHalfToFloat<SIGNED>(x) * A.w[ch];
             }
             pk01[px] = ((u32)v[0] & 0xffffu) | ((u32)v[1] << 16);
             pk2[px] = (u32)v[2] & 0xffffu;
@@ -248,13 +250,14 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
     u32 bestEP[6] = {0, 0, 0, 0, 0, 0}; // [subset][3 dwords: (e0r|e0g<<16),(e0b|e1r<<16),(e1g|e1b<<16)]
     u32 bestIdxLo = 0, bestIdxHi = 0;
 
-    for (int partitionedInt = 0; partitionedInt < 2; partitionedInt++)
-    {
-        const bool partitioned = partitionedInt == 1;
-        const int numPartitions = partitioned ? 32 : 1;
-        const int numSubsets = partitioned ? 2 : 1;
-        const int indexBits = partitioned ? 3 : 4;
-        const int indexRange = 1 << indexBits;
+    // the single-subset (4-bit indexes) and the partitioned (3-bit) search are two instantiations of the same body, so
+    // that the interpolant table is 16 or 8 entries of registers
+    auto searchAll = [&](auto partitionedTag) {
+        constexpr bool partitioned = decltype(partitionedTag)::value;
+        constexpr int numPartitions = partitioned ? 32 : 1;
+        constexpr int numSubsets = partitioned ? 2 : 1;
+        constexpr int indexBits = partitioned ? 3 : 4;
+        constexpr int indexRange = 1 << indexBits;
         const float maxValue = (float)(indexRange - 1);
         const int weightRcp = partitioned ? 4681 : 2185; // g_weightReciprocals[8], [16]
         const float rcpMaxIndex = T->rcpMaxIndex[indexBits];
@@ -393,20 +396,14 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 }
 
                             PROF_MARK(1)
-                            // ---- raw (un-inverted) index of every pixel of the subset ----
-                            float selBest[16];
-                            int selIdx[16];
-#pragma unroll
-                            for (int px = 0; px < 16; px++)
-                            {
-                                selBest[px] = 0.0f;
-                                selIdx[px] = 0;
-                            }
+                            // ---- index selection, one pixel at a time: IndexSelectorHDR.h:100-144 ----
                             const u32 sm = opaqueUniform(subsetMask);
+                            float iw[indexRange][3]; // slow: weighted linear colour of every interpolant
+                            float origin[3], axis[3]; // fast: projection axis
                             if (FAST)
                             {
                                 // IndexSelector::Init on the colour-space endpoints + SelectIndexLDR
-                                float origin[3], axis[3], epDW[3];
+                                float epDW[3];
 #pragma unroll
                                 for (int ch = 0; ch < 3; ch++)
                                 {
@@ -421,56 +418,65 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 #pragma unroll
                                 for (int ch = 0; ch < 3; ch++)
                                     axis[ch] = epDW[ch] * A.w[ch] * mvdls;
-#pragma unroll
-                                for (int px = 0; px < 16; px++)
-                                    if ((sm >> px) & 1u)
-                                    {
-                                        const u32 a = fetchPixel(pk01[px]), b = fetchPixel(pk2[px]);
-                                        float dist = ((float)(int)(short)(a & 0xffffu) - origin[0]) * axis[0];
-                                        dist = dist + ((float)(int)(short)(a >> 16) - origin[1]) * axis[1];
-                                        dist = dist + ((float)(int)(short)(b & 0xffffu) - origin[2]) * axis[2];
-                                        selIdx[px] = (int)clampRound(dist, maxValue);
-                                    }
                             }
                             else
                             {
-                                // SelectIndexHDRSlow with the interpolant in the outer loop
+#pragma unroll
                                 for (int i = 0; i < indexRange; i++)
-                                {
-                                    const int weight = mad24(weightRcp, i, 256) >> 9;
-                                    float iw[3];
+                                    {
+                                        const int weight = mad24(weightRcp, i, 256) >> 9;
 #pragma unroll
-                                    for (int ch = 0; ch < 3; ch++)
-                                        iw[ch] = twosCLHalfToFloat<SIGNED>(reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight)) * A.w[ch];
-#pragma unroll
-                                    for (int px = 0; px < 16; px++)
-                                        if ((sm >> px) & 1u)
-                                        {
-                                            float d = linW[px][0] - iw[0];
-                                            float e = d * d;
-                                            d = linW[px][1] - iw[1];
-                                            e = e + d * d;
-                                            d = linW[px][2] - iw[2];
-                                            e = e + d * d;
-                                            if (i == 0)
-                                                selBest[px] = e;
-                                            else
-                                            {
-                                                if (e < selBest[px])
-                                                    selIdx[px] = i;
-                                                selBest[px] = sseMin(selBest[px], e);
-                                            }
-                                        }
-                                }
+                                        for (int ch = 0; ch < 3; ch++)
+                                            iw[i][ch] = twosCLHalfToFloat<SIGNED>(reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight)) * A.w[ch];
+                                    }
                             }
+                            // raw (un-inverted) index of the pixel packed in (a, b); SelectIndexHDRSlow keeps the FIRST minimum
+                            auto rawIndexOf = [&](u32 a, u32 b) -> int {
+                                const int c0 = (int)(short)(a & 0xffffu), c1 = (int)(short)(a >> 16), c2 = (int)(short)(b & 0xffffu);
+                                if (FAST)
+                                {
+                                    float dist = ((float)c0 - origin[0]) * axis[0];
+                                    dist = dist + ((float)c1 - origin[1]) * axis[1];
+                                    dist = dist + ((float)c2 - origin[2]) * axis[2];
+                                    return (int)clampRound(dist, maxValue);
+                                }
+                                const float l0 = twosCLHalfToFloat<SIGNED>(c0) * A.w[0];
+                                const float l1 = twosCLHalfToFloat<SIGNED>(c1) * A.w[1];
+                                const float l2 = twosCLHalfToFloat<SIGNED>(c2) * A.w[2];
+                                float be = 0.0f;
+                                int bi = 0;
+#pragma unroll
+                                for (int i = 0; i < indexRange; i++)
+                                    {
+                                        float d = l0 - iw[i][0];
+                                        float e = d * d;
+                                        d = l1 - iw[i][1];
+                                        e = e + d * d;
+                                        d = l2 - iw[i][2];
+                                        e = e + d * d;
+                                        if (i == 0)
+                                            be = e;
+                                        else
+                                        {
+                                            if (e < be)
+                                                bi = i;
+                                            be = sseMin(be, e);
+                                        }
+                                    }
+                                return bi;
+                            };
 
-                            PROF_MARK(2)
                             // anchor index decides the inversion (BC67.cpp:2525-2547)
-                            int fixRaw = 0;
+                            u32 fa = 0, fb = 0;
 #pragma unroll
                             for (int px = 0; px < 16; px++)
                                 if (px == fixupIndex)
-                                    fixRaw = selIdx[px];
+                                {
+                                    fa = pk01[px];
+                                    fb = pk2[px];
+                                }
+                            const int fixRaw = rawIndexOf(fetchPixel(fa), fetchPixel(fb));
+                            PROF_MARK(2)
                             const bool invert = (indexRange / 2 - 1) < fixRaw;
                             if (invert)
                             {
@@ -509,7 +515,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 for (int px = 0; px < 16; px++)
                                     if ((sm >> px) & 1u)
                                     {
-                                        const int raw = selIdx[px];
+                                        const u32 a = fetchPixel(pk01[px]), b = fetchPixel(pk2[px]);
+                                        const int raw = rawIndexOf(a, b);
                                         const int index = invert ? (indexRange - 1) - raw : raw;
                                         if (px < 8)
                                             idxLo |= (u32)index << (4 * px);
@@ -517,7 +524,6 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                             idxHi |= (u32)index << (4 * (px - 8));
 
                                         const int weight = mad24(weightRcp, raw, 256) >> 9;
-                                        const u32 a = fetchPixel(pk01[px]), b = fetchPixel(pk2[px]);
                                         const int orig[3] = {(int)(short)(a & 0xffffu), (int)(short)(a >> 16), (int)(short)(b & 0xffffu)};
                                         float err = 0.0f;
 #pragma unroll
@@ -739,7 +745,9 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                 }
             }
         }
-    }
+    };
+    searchAll(std::false_type{});
+    searchAll(std::true_type{});
 
     PROF_MARK(5)
     PROF_FLUSH
