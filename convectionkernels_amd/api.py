@@ -154,6 +154,7 @@ _EXPORTS = (
     "cvttmi_encode_etc2", "cvttmi_encode_etc2_rgba", "cvttmi_encode_etc2_alpha",
     "cvttmi_tiled_block_count", "cvttmi_tile_image_device", "cvttmi_compact_rows_device",
     "cvttmi_selftest_arith",
+    "cvttmi_decode_bc7_device", "cvttmi_decode_bc7", "cvttmi_decode_bc6h_device", "cvttmi_decode_bc6h",
 )
 
 _lib = None
@@ -199,6 +200,10 @@ def load_library():
                                              ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
     lib.cvttmi_compact_rows_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
                                                ctypes.c_uint32, ctypes.c_void_p]
+    lib.cvttmi_decode_bc7_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.cvttmi_decode_bc7.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.cvttmi_decode_bc6h_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    lib.cvttmi_decode_bc6h.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     lib.cvttmi_selftest_arith.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
                                           ctypes.POINTER(ctypes.c_uint64)]
     lib.cvttmi_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -355,6 +360,48 @@ class Context:
                                    "encode_etc2_alpha", blocks, options, out, stream, 64, 8)
 
 
+    # -- decoders (cvtt::Kernels::DecodeBC7 / DecodeBC6HU / DecodeBC6HS) --
+    def _decode(self, packed, fmt, stream):
+        hdr = fmt != "bc7"
+        sg = 1 if fmt == "bc6hs" else 0
+        if isinstance(packed, np.ndarray):
+            b = np.ascontiguousarray(packed, np.uint8)
+            n = b.size // 16
+            if b.size % 16 or n % NumParallelBlocks:
+                raise CvttError("packed must hold a multiple of 8 16-byte blocks")
+            res = np.empty((n, 16, 4), np.int16 if hdr else np.uint8)
+            rc = (self._lib.cvttmi_decode_bc6h(self._h, res.ctypes.data, b.ctypes.data, n, sg) if hdr
+                  else self._lib.cvttmi_decode_bc7(self._h, res.ctypes.data, b.ctypes.data, n))
+            self._check(rc, "decode")
+            return res
+        import torch
+        b = packed.contiguous()
+        n = b.numel() * b.element_size() // 16
+        if n % NumParallelBlocks:
+            raise CvttError("packed must hold a multiple of 8 16-byte blocks")
+        res = torch.empty((n, 16, 4), dtype=torch.int16 if hdr else torch.uint8, device=b.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(b.device).cuda_stream
+        rc = (self._lib.cvttmi_decode_bc6h_device(self._h, res.data_ptr(), b.data_ptr(), n, sg, ctypes.c_void_p(stream)) if hdr
+              else self._lib.cvttmi_decode_bc7_device(self._h, res.data_ptr(), b.data_ptr(), n, ctypes.c_void_p(stream)))
+        self._check(rc, "decode")
+        return res
+
+    def decode_bc7(self, packed, stream=None):
+        """(N,16) uint8 packed BC7 blocks (numpy or CUDA tensor) -> (N,16,4) uint8 PixelBlockU8"""
+        return self._decode(packed, "bc7", stream)
+
+    def decode_bc6h(self, packed, signed=False, stream=None):
+        """(N,16) uint8 packed BC6H blocks -> (N,16,4) int16 half bit patterns (alpha = 0x3C00)"""
+        return self._decode(packed, "bc6hs" if signed else "bc6hu", stream)
+
+    def psnr_bc7(self, blocks, packed):
+        """PSNR (dB, over the four channels) of the decoded `packed` blocks against the source PixelBlockU8 tensor, on the device"""
+        import torch
+        d = self.decode_bc7(packed).to(torch.float32) - blocks.reshape(-1, 16, 4).to(torch.float32)
+        mse = float((d * d).mean().item())
+        return float("inf") if mse == 0.0 else 10.0 * float(np.log10(255.0 * 255.0 / mse))
+
     def selftest_arith(self, count=1 << 22, seed=1):
         """(divide mismatches, sqrt mismatches) of the device against the host's IEEE results"""
         d, q = ctypes.c_uint64(0), ctypes.c_uint64(0)
@@ -430,6 +477,19 @@ def EncodeBC7(pBlocks, options=None, encodingPlan=None, device=0):
     """cvtt::Kernels::EncodeBC7 (reference ConvectionKernels_API.cpp:41-54): any multiple of
     NumParallelBlocks blocks; returns the packed 16-byte blocks."""
     return default_context(device).encode_bc7(pBlocks, options, encodingPlan)
+
+
+def DecodeBC7(pBC, device=0):
+    """cvtt::Kernels::DecodeBC7 (reference ConvectionKernels_API.cpp:305-310), batched"""
+    return default_context(device).decode_bc7(pBC)
+
+
+def DecodeBC6HU(pBC, device=0):
+    return default_context(device).decode_bc6h(pBC, signed=False)
+
+
+def DecodeBC6HS(pBC, device=0):
+    return default_context(device).decode_bc6h(pBC, signed=True)
 
 
 def EncodeBC1(pBlocks, options=None, device=0):

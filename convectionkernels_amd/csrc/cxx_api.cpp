@@ -103,6 +103,25 @@ namespace cvtt
             check(cvttmi_encode_etc2_alpha(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeETC2Alpha");
         }
 
+        void DecodeBC7Batch(PixelBlockU8 *pBlocks, const uint8_t *pBC, size_t numBlocks)
+        {
+            std::lock_guard<std::mutex> g(g_lock);
+            check(cvttmi_decode_bc7(context(), reinterpret_cast<uint8_t *>(pBlocks), pBC, numBlocks), "DecodeBC7");
+        }
+        void DecodeBC6HUBatch(PixelBlockF16 *pBlocks, const uint8_t *pBC, size_t numBlocks)
+        {
+            std::lock_guard<std::mutex> g(g_lock);
+            check(cvttmi_decode_bc6h(context(), reinterpret_cast<uint8_t *>(pBlocks), pBC, numBlocks, 0), "DecodeBC6HU");
+        }
+        void DecodeBC6HSBatch(PixelBlockF16 *pBlocks, const uint8_t *pBC, size_t numBlocks)
+        {
+            std::lock_guard<std::mutex> g(g_lock);
+            check(cvttmi_decode_bc6h(context(), reinterpret_cast<uint8_t *>(pBlocks), pBC, numBlocks, 1), "DecodeBC6HS");
+        }
+        void DecodeBC7(PixelBlockU8 *pBlocks, const uint8_t *pBC) { DecodeBC7Batch(pBlocks, pBC, NumParallelBlocks); }
+        void DecodeBC6HU(PixelBlockF16 *pBlocks, const uint8_t *pBC) { DecodeBC6HUBatch(pBlocks, pBC, NumParallelBlocks); }
+        void DecodeBC6HS(PixelBlockF16 *pBlocks, const uint8_t *pBC) { DecodeBC6HSBatch(pBlocks, pBC, NumParallelBlocks); }
+
         void EncodeBC7(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, const BC7EncodingPlan &plan) { EncodeBC7Batch(pBC, pBlocks, NumParallelBlocks, options, plan); }
         void EncodeBC1(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options) { EncodeBC1Batch(pBC, pBlocks, NumParallelBlocks, options); }
         void EncodeBC6HU(uint8_t *pBC, const PixelBlockF16 *pBlocks, const Options &options) { EncodeBC6HUBatch(pBC, pBlocks, NumParallelBlocks, options); }

@@ -31,6 +31,8 @@ extern "C" hipError_t cvttmi_launch_compact_rows(const void *d_packed, void *d_o
                                                  uint32_t bytesPerBlock, hipStream_t stream);
 extern "C" hipError_t cvttmi_launch_selftest(uint64_t seed, uint64_t first, uint32_t count, void *d_operands, void *d_results,
                                              hipStream_t stream);
+extern "C" hipError_t cvttmi_launch_decode(const void *d_bc, void *d_out, uint32_t numBlocks, int format,
+                                           const CvttDeviceTables *d_tables, hipStream_t stream);
 extern "C" hipError_t cvttmi_launch_bc1(const void *d_blocks, void *d_out, const CvttBc1Args *args,
                                         const CvttDeviceTables *d_tables, hipStream_t stream);
 
@@ -438,6 +440,70 @@ extern "C"
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_HIP, "compact kernel launch", e);
         return CVTTMI_OK;
+    }
+
+    // format: 0 = BC7 -> PixelBlockU8 (64 B), 1 = BC6HU, 2 = BC6HS -> PixelBlockF16 (128 B)
+    static int decodeDevice(cvttmi_context *ctx, void *d_blocks, const void *d_bc, size_t numBlocks, int format, void *hipStream)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        if (!d_blocks || !d_bc || (numBlocks % 8) != 0 || numBlocks > 0xfffffff0u)
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        if (numBlocks == 0)
+            return CVTTMI_OK;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        e = cvttmi_launch_decode(d_bc, d_blocks, static_cast<uint32_t>(numBlocks), format, ctx->dTables, static_cast<hipStream_t>(hipStream));
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "decode kernel launch", e);
+        return CVTTMI_OK;
+    }
+
+    static int decodeHost(cvttmi_context *ctx, uint8_t *blocks, const uint8_t *bc, size_t numBlocks, int format)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        if (!blocks || !bc || (numBlocks % 8) != 0)
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        if (numBlocks == 0)
+            return CVTTMI_OK;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        const size_t inBytes = numBlocks * 16, outBytes = numBlocks * (format == 0 ? 64 : 128);
+        int rc = ensureStaging(ctx, inBytes, outBytes);
+        if (rc != CVTTMI_OK)
+            return rc;
+        memcpy(ctx->pinnedIn, bc, inBytes);
+        if ((e = hipMemcpyAsync(ctx->dIn, ctx->pinnedIn, inBytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "H2D", e);
+        rc = decodeDevice(ctx, ctx->dOut, ctx->dIn, numBlocks, format, ctx->stream);
+        if (rc != CVTTMI_OK)
+            return rc;
+        if ((e = hipMemcpyAsync(ctx->pinnedOut, ctx->dOut, outBytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "D2H", e);
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "kernel execution", e);
+        memcpy(blocks, ctx->pinnedOut, outBytes);
+        return CVTTMI_OK;
+    }
+
+    int cvttmi_decode_bc7_device(cvttmi_context *ctx, void *d_blocks, const void *d_bc, size_t numBlocks, void *hipStream)
+    {
+        return decodeDevice(ctx, d_blocks, d_bc, numBlocks, 0, hipStream);
+    }
+    int cvttmi_decode_bc6h_device(cvttmi_context *ctx, void *d_blocksF16, const void *d_bc, size_t numBlocks, int isSigned, void *hipStream)
+    {
+        return decodeDevice(ctx, d_blocksF16, d_bc, numBlocks, isSigned ? 2 : 1, hipStream);
+    }
+    int cvttmi_decode_bc7(cvttmi_context *ctx, uint8_t *blocks, const uint8_t *bc, size_t numBlocks)
+    {
+        return decodeHost(ctx, blocks, bc, numBlocks, 0);
+    }
+    int cvttmi_decode_bc6h(cvttmi_context *ctx, uint8_t *blocksF16, const uint8_t *bc, size_t numBlocks, int isSigned)
+    {
+        return decodeHost(ctx, blocksF16, bc, numBlocks, isSigned ? 2 : 1);
     }
 
     int cvttmi_selftest_arith(cvttmi_context *ctx, uint64_t count, uint64_t seed, uint64_t *divMismatches, uint64_t *sqrtMismatches)

@@ -188,6 +188,15 @@ int cvttmi_tile_image_device(cvttmi_context *ctx, void *d_blocks, const void *d_
 int cvttmi_compact_rows_device(cvttmi_context *ctx, void *d_out, const void *d_packed, uint32_t width, uint32_t height,
                                uint32_t bytesPerBlock, void *hipStream);
 
+/* ---- decoders: cvtt::Kernels::DecodeBC7 / DecodeBC6HU / DecodeBC6HS (reference
+ * ConvectionKernels_API.cpp:288-310, ConvectionKernels_BC67.cpp:2206-2423, 3058-3289), batched:
+ * numBlocks (multiple of 8) packed 16-byte blocks -> PixelBlockU8 (64 B) / PixelBlockF16 (128 B,
+ * half bit patterns, alpha = 1.0).  Reserved modes decode like the reference (zeros). ---- */
+int cvttmi_decode_bc7_device(cvttmi_context *ctx, void *d_blocks, const void *d_bc, size_t numBlocks, void *hipStream);
+int cvttmi_decode_bc7(cvttmi_context *ctx, uint8_t *blocks, const uint8_t *bc, size_t numBlocks);
+int cvttmi_decode_bc6h_device(cvttmi_context *ctx, void *d_blocksF16, const void *d_bc, size_t numBlocks, int isSigned, void *hipStream);
+int cvttmi_decode_bc6h(cvttmi_context *ctx, uint8_t *blocksF16, const uint8_t *bc, size_t numBlocks, int isSigned);
+
 /* Arithmetic self-test: evaluates binary32 divide and square root on `count` pseudo-random finite
  * operand patterns (zeros, denormals and both signs included) with the expressions and compiler
  * flags the encoders use, and counts results that differ from the host's DIVSS / SQRTSS -- the

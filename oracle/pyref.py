@@ -120,6 +120,14 @@ class RefLib:
         assert rc == 0
         return out.reshape(n, per)
 
+    def decode_bc6h(self, bc, signed=False):
+        bc, pb = _u8(bc)
+        n = bc.size // 16
+        assert n % 8 == 0
+        out = np.zeros(n * 64, np.int16)
+        self.lib.ref_decode_bc6h(out.ctypes.data_as(ctypes.c_void_p), pb, ctypes.c_size_t(n), ctypes.c_int(int(signed)))
+        return out.reshape(n, 16, 4)
+
     def decode_bc7(self, bc):
         bc, pb = _u8(bc)
         n = bc.size // 16

@@ -139,6 +139,20 @@ def main():
                         hdr_blocks=content.known_answer_group_hdr(),
                         bc6hu=ref.encode_bc6h(content.known_answer_group_hdr(), opt, False))
 
+    # ---- decoders: the reference's DecodeBC7 / DecodeBC6HU / DecodeBC6HS on encoder output and on random bytes
+    # (every mode, reserved modes, arbitrary field values) ----
+    rng = np.random.Generator(np.random.PCG64(777))
+    g7 = np.load(os.path.join(HERE, "bc7_mixed.npz"))
+    bc7_in = np.concatenate([g7["out_default"], g7["out_better"], g7["out_quality20"], rng.integers(0, 256, (2048, 16), dtype=np.uint8)])
+    bc7_in[-8:, 0] = 0  # reserved mode
+    g6 = np.load(os.path.join(HERE, "bc6h_mixed.npz"))
+    rnd6 = rng.integers(0, 256, (2048, 16), dtype=np.uint8)
+    bc6u_in = np.concatenate([g6["out_default"], g6["out_fast"], rnd6])
+    bc6s_in = np.concatenate([g6["outs_default"], rnd6])
+    np.savez_compressed(os.path.join(HERE, "decode.npz"), bc7_in=bc7_in, bc7_out=ref.decode_bc7(bc7_in),
+                        bc6u_in=bc6u_in, bc6u_out=ref.decode_bc6h(bc6u_in, False),
+                        bc6s_in=bc6s_in, bc6s_out=ref.decode_bc6h(bc6s_in, True))
+
     if "--skip-images" in sys.argv:
         return
     plan = ref.default_plan()
