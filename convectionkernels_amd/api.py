@@ -154,6 +154,7 @@ _EXPORTS = (
     "cvttmi_encode_etc2", "cvttmi_encode_etc2_rgba", "cvttmi_encode_etc2_alpha",
     "cvttmi_tiled_block_count", "cvttmi_tile_image_device", "cvttmi_compact_rows_device",
     "cvttmi_selftest_arith",
+    "cvttmi_encode_etc2_alpha11_device", "cvttmi_encode_etc2_alpha11",
     "cvttmi_decode_bc7_device", "cvttmi_decode_bc7", "cvttmi_decode_bc6h_device", "cvttmi_decode_bc6h",
 )
 
@@ -200,6 +201,9 @@ def load_library():
                                              ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
     lib.cvttmi_compact_rows_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
                                                ctypes.c_uint32, ctypes.c_void_p]
+    lib.cvttmi_encode_etc2_alpha11_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                                      ctypes.c_void_p, ctypes.c_void_p]
+    lib.cvttmi_encode_etc2_alpha11.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
     lib.cvttmi_decode_bc7_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.cvttmi_decode_bc7.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     lib.cvttmi_decode_bc6h_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
@@ -360,6 +364,15 @@ class Context:
                                    "encode_etc2_alpha", blocks, options, out, stream, 64, 8)
 
 
+    def encode_etc2_alpha11(self, blocks, signed=False, options=None, out=None, stream=None):
+        """Batched cvtt::Kernels::EncodeETC2Alpha11 (EAC R11): (N,16) int16 PixelBlockScalarS16 -> (N,8) uint8."""
+        sg = 1 if signed else 0
+        host = lambda h, o, b, n, opt: self._lib.cvttmi_encode_etc2_alpha11(h, o, b, n, sg, opt)
+        dev = lambda h, o, b, n, opt, st: self._lib.cvttmi_encode_etc2_alpha11_device(h, o, b, n, sg, opt, st)
+        if isinstance(blocks, np.ndarray):
+            blocks = np.ascontiguousarray(blocks, np.int16)
+        return self._encode_simple(host, dev, "encode_etc2_alpha11", blocks, options, out, stream, 32, 8)
+
     # -- decoders (cvtt::Kernels::DecodeBC7 / DecodeBC6HU / DecodeBC6HS) --
     def _decode(self, packed, fmt, stream):
         hdr = fmt != "bc7"
@@ -477,6 +490,11 @@ def EncodeBC7(pBlocks, options=None, encodingPlan=None, device=0):
     """cvtt::Kernels::EncodeBC7 (reference ConvectionKernels_API.cpp:41-54): any multiple of
     NumParallelBlocks blocks; returns the packed 16-byte blocks."""
     return default_context(device).encode_bc7(pBlocks, options, encodingPlan)
+
+
+def EncodeETC2Alpha11(pBlocks, isSigned=False, options=None, device=0):
+    """cvtt::Kernels::EncodeETC2Alpha11 (reference ConvectionKernels_API.cpp:258-268)."""
+    return default_context(device).encode_etc2_alpha11(pBlocks, isSigned, options)
 
 
 def DecodeBC7(pBC, device=0):

@@ -1482,7 +1482,9 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                     // rounding the projected points moves each by at most sqrt(2)/2 grid units
                     const float delta = (use4 ? A.delta4 : A.delta3) + 0.7072f / scale;
                     Proj2D P;
+                    PROF_MARK(2)
                     makeProjection(pix, bs, A, use4, scale, P);
+                    PROF_MARK(7)
                     for (int k = 0; k < 16; k++)
                     {
                         const int partition = 4 * k + c;

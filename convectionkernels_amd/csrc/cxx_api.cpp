@@ -103,6 +103,16 @@ namespace cvtt
             check(cvttmi_encode_etc2_alpha(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeETC2Alpha");
         }
 
+        void EncodeETC2Alpha11Batch(uint8_t *pBC, const PixelBlockScalarS16 *pBlocks, size_t numBlocks, bool isSigned, const Options &options)
+        {
+            std::lock_guard<std::mutex> g(g_lock);
+            check(cvttmi_encode_etc2_alpha11(context(), pBC, reinterpret_cast<const int16_t *>(pBlocks), numBlocks, isSigned ? 1 : 0, opt(options)),
+                  "EncodeETC2Alpha11");
+        }
+        void EncodeETC2Alpha11(uint8_t *pBC, const PixelBlockScalarS16 *pBlocks, bool isSigned, const Options &options)
+        {
+            EncodeETC2Alpha11Batch(pBC, pBlocks, NumParallelBlocks, isSigned, options);
+        }
         void DecodeBC7Batch(PixelBlockU8 *pBlocks, const uint8_t *pBC, size_t numBlocks)
         {
             std::lock_guard<std::mutex> g(g_lock);

@@ -1066,28 +1066,59 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
 
 // ------------------------------------------------------------------------------------------
 // EAC 8-bit alpha: CompressETC2AlphaBlockInternal (ETC.cpp:1902-2085), QuantizeETC2Alpha 2366-2411.
+// KIND 0: 8-bit alpha of PixelBlockU8 (EncodeETC2Alpha / the alpha half of EncodeETC2RGBA);
+// KIND 1 / 2: unsigned / signed 11-bit EAC of PixelBlockScalarS16 (EncodeETC2Alpha11, CompressEACBlock ETC.cpp:2087-2114)
+template <int KIND>
 __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
                                                              const CvttEtcArgs A, const CvttDeviceTables *__restrict__ T)
 {
+    constexpr bool is11 = KIND != 0, isSigned = KIND == 2;
     const u32 blockIndex = blockIdx.x * 64u + threadIdx.x;
     const bool valid = blockIndex < A.numBlocks;
-    u32 pk[4]; // 16 alpha bytes
+    int pixel[16];
+    if (!is11)
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(blocks + (size_t)(valid ? blockIndex : 0u) * 64u);
 #pragma unroll
         for (int i = 0; i < 4; i++)
         {
             const uint4 v = src[i];
-            pk[i] = (v.x >> 24) | ((v.y >> 24) << 8) | ((v.z >> 24) << 16) | ((v.w >> 24) << 24);
+            pixel[4 * i + 0] = (int)(v.x >> 24);
+            pixel[4 * i + 1] = (int)(v.y >> 24);
+            pixel[4 * i + 2] = (int)(v.z >> 24);
+            pixel[4 * i + 3] = (int)(v.w >> 24);
         }
     }
-    int minAlpha = 255, maxAlpha = 0;
+    else
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(blocks + (size_t)(valid ? blockIndex : 0u) * 32u);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+        {
+            const uint4 v = src[i];
+            const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+            {
+                int x = (int)(short)((w[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+                // shifted ranges: signed 1..2047, unsigned 0..2047
+                if (isSigned)
+                {
+                    x = (x > 1023 ? 1023 : x) + 1024;
+                    x = x < 1 ? 1 : x;
+                }
+                else
+                    x = x > 2047 ? 2047 : (x < 0 ? 0 : x);
+                pixel[8 * i + j] = x;
+            }
+        }
+    }
+    int minAlpha = is11 ? 2047 : 255, maxAlpha = 0;
 #pragma unroll
     for (int px = 0; px < 16; px++)
     {
-        const int a = (int)((pk[px >> 2] >> (8 * (px & 3))) & 0xffu);
-        minAlpha = a < minAlpha ? a : minAlpha;
-        maxAlpha = a > maxAlpha ? a : maxAlpha;
+        minAlpha = pixel[px] < minAlpha ? pixel[px] : minAlpha;
+        maxAlpha = pixel[px] > maxAlpha ? pixel[px] : maxAlpha;
     }
     const int alphaSpan = maxAlpha - minAlpha;
     const int midTimes2 = maxAlpha + minAlpha;
@@ -1106,24 +1137,55 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
             const int minOffset = -(int)T->eacPositive[tableIndex][3 - mainRange - ((subrange >> 1) & 1)] - 1;
             const int offsetSpan = maxOffset - minOffset;
             int minMultiplier = udivSmall(alphaSpan, offsetSpan);
-            minMultiplier = minMultiplier > 14 ? 14 : minMultiplier;
-            minMultiplier = minMultiplier < 1 ? 1 : minMultiplier;
+            if (is11)
+            {
+                minMultiplier = minMultiplier > 112 ? 112 : minMultiplier;
+                minMultiplier &= 120;
+            }
+            else
+            {
+                minMultiplier = minMultiplier > 14 ? 14 : minMultiplier;
+                minMultiplier = minMultiplier < 1 ? 1 : minMultiplier;
+            }
             for (int mo = 0; mo < 2; mo++)
             {
-                const int multiplier = minMultiplier + mo;
-                int base2 = midTimes2 - multiplier * maxOffset - multiplier * minOffset;
-                base2 = base2 < 0 ? 0 : (base2 > 510 ? 510 : base2);
-                const int baseAlpha = (base2 + 1) >> 1;
+                int multiplier = minMultiplier;
+                if (is11)
+                {
+                    if (mo == 1)
+                        multiplier += 8;
+                    else
+                        multiplier = multiplier < 1 ? 1 : multiplier;
+                }
+                else
+                    multiplier += mo;
+                int base2 = midTimes2 - multiplier * maxOffset - multiplier * minOffset; // all lanes stay inside 16 bits
+                int baseAlpha;
+                if (is11)
+                {
+                    if (isSigned)
+                        base2 += 8;
+                    const int lo2 = isSigned ? 16 : 0;
+                    base2 = base2 < lo2 ? lo2 : (base2 > 4095 ? 4095 : base2);
+                    baseAlpha = (base2 >> 1) & 2040;
+                    if (!isSigned)
+                        baseAlpha += 4;
+                }
+                else
+                {
+                    base2 = base2 < 0 ? 0 : (base2 > 510 ? 510 : base2);
+                    baseAlpha = (base2 + 1) >> 1;
+                }
                 const float rcpMul = __frcp_rn((float)multiplier);
                 u32 idxLo = 0, idxHi = 0, totalError = 0;
 #pragma unroll
                 for (int px = 0; px < 16; px++)
                 {
-                    const int a = (int)((pk[px >> 2] >> (8 * (px & 3))) & 0xffu);
+                    const int a = pixel[px];
                     const int refl2 = (a - baseAlpha) * 2 + multiplier;
                     const int absv = refl2 < 0 ? -refl2 : refl2;
                     const int lookup = absv >> 1;
-                    // lookup / multiplier (lookup < 2^10, multiplier <= 15)
+                    // lookup / multiplier (lookup < 2^12, multiplier <= 128)
                     int li = (int)((float)lookup * rcpMul);
                     const int rem = lookup - li * multiplier;
                     if (rem < 0) li--;
@@ -1134,7 +1196,8 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
                     const int sign = refl2 < 0 ? -1 : 0;
                     const int quantizedOffset = (pOff ^ sign) * multiplier;
                     int q = baseAlpha + quantizedOffset;
-                    q = q < 0 ? 0 : (q > 255 ? 255 : q);
+                    const int qLo = (is11 && isSigned) ? 1 : 0, qHi = is11 ? 2047 : 255;
+                    q = q < qLo ? qLo : (q > qHi ? qHi : q);
                     const int d = q - a;
                     totalError += (u32)(d * d);
                     const u32 code = (u32)(index + 4 - (sign & 4));
@@ -1155,6 +1218,12 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
             }
         }
     }
+    if (is11)
+    {
+        bestMultiplier >>= 3;
+        if (isSigned)
+            bestBase ^= 0x80;
+    }
     if (valid)
     {
         // 16 x 3-bit indexes, column-major pixel order, MSB first (ETC.cpp:2049-2084)
@@ -1167,7 +1236,7 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
             bits = (bits << 3) | code;
         }
         uint8_t *o = out + (size_t)blockIndex * A.outStride + A.outOffset;
-        const u32 w0 = (u32)bestBase | ((u32)((bestMultiplier << 4) | bestTable) << 8) | ((u32)((bits >> 40) & 0xff) << 16) | ((u32)((bits >> 32) & 0xff) << 24);
+        const u32 w0 = ((u32)bestBase & 0xffu) | ((u32)(((bestMultiplier << 4) | bestTable) & 0xff) << 8) | ((u32)((bits >> 40) & 0xff) << 16) | ((u32)((bits >> 32) & 0xff) << 24);
         const u32 w1 = bswap32((u32)bits);
         uint2 v;
         v.x = w0;
@@ -1193,8 +1262,26 @@ extern "C" hipError_t cvttmi_launch_etc2(const void *d_blocks, void *d_out, cons
     if (mode != 0)
     {
         a.outOffset = 0u;
-        hipLaunchKernelGGL(cvttmi_eac_alpha_kernel, dim3((a.numBlocks + 63u) / 64u), dim3(64), 0, stream, (const uint8_t *)d_blocks,
+        hipLaunchKernelGGL(cvttmi_eac_alpha_kernel<0>, dim3((a.numBlocks + 63u) / 64u), dim3(64), 0, stream, (const uint8_t *)d_blocks,
                            (uint8_t *)d_out, a, d_tables);
     }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t cvttmi_launch_eac11(const void *d_blocksS16, void *d_out, uint32_t numBlocks, int isSigned,
+                                          const CvttDeviceTables *d_tables, hipStream_t stream)
+{
+    if (numBlocks == 0)
+        return hipSuccess;
+    CvttEtcArgs a = {};
+    a.numBlocks = numBlocks;
+    a.outStride = 8u;
+    a.outOffset = 0u;
+    if (isSigned)
+        hipLaunchKernelGGL(cvttmi_eac_alpha_kernel<2>, dim3((numBlocks + 63u) / 64u), dim3(64), 0, stream, (const uint8_t *)d_blocksS16,
+                           (uint8_t *)d_out, a, d_tables);
+    else
+        hipLaunchKernelGGL(cvttmi_eac_alpha_kernel<1>, dim3((numBlocks + 63u) / 64u), dim3(64), 0, stream, (const uint8_t *)d_blocksS16,
+                           (uint8_t *)d_out, a, d_tables);
     return hipGetLastError();
 }

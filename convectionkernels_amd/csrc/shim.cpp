@@ -33,6 +33,8 @@ extern "C" hipError_t cvttmi_launch_selftest(uint64_t seed, uint64_t first, uint
                                              hipStream_t stream);
 extern "C" hipError_t cvttmi_launch_decode(const void *d_bc, void *d_out, uint32_t numBlocks, int format,
                                            const CvttDeviceTables *d_tables, hipStream_t stream);
+extern "C" hipError_t cvttmi_launch_eac11(const void *d_blocksS16, void *d_out, uint32_t numBlocks, int isSigned,
+                                          const CvttDeviceTables *d_tables, hipStream_t stream);
 extern "C" hipError_t cvttmi_launch_bc1(const void *d_blocks, void *d_out, const CvttBc1Args *args,
                                         const CvttDeviceTables *d_tables, hipStream_t stream);
 
@@ -738,6 +740,56 @@ extern "C"
     { return etc2Host(ctx, out, blocks, numBlocks, options, 1); }
     int cvttmi_encode_etc2_alpha(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options)
     { return etc2Host(ctx, out, blocks, numBlocks, options, 2); }
+
+    // EncodeETC2Alpha11 (reference ConvectionKernels_API.cpp:258-268): PixelBlockScalarS16 (32 B) -> 8 B; `options` is unused by
+    // the reference's integer search but kept in the signature
+    int cvttmi_encode_etc2_alpha11_device(cvttmi_context *ctx, void *d_out, const void *d_blocksS16, size_t numBlocks, int isSigned,
+                                          const cvttmi_options *options, void *hipStream)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        if (!d_out || !d_blocksS16 || !options || (numBlocks % 8) != 0 || numBlocks > 0xfffffff0u)
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        if (numBlocks == 0)
+            return CVTTMI_OK;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        e = cvttmi_launch_eac11(d_blocksS16, d_out, static_cast<uint32_t>(numBlocks), isSigned, ctx->dTables, static_cast<hipStream_t>(hipStream));
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "eac11 kernel launch", e);
+        return CVTTMI_OK;
+    }
+
+    int cvttmi_encode_etc2_alpha11(cvttmi_context *ctx, uint8_t *out, const int16_t *blocksS16, size_t numBlocks, int isSigned,
+                                   const cvttmi_options *options)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        if (!out || !blocksS16 || !options || (numBlocks % 8) != 0)
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        if (numBlocks == 0)
+            return CVTTMI_OK;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        const size_t inBytes = numBlocks * 32, outBytes = numBlocks * 8;
+        int rc = ensureStaging(ctx, inBytes, outBytes);
+        if (rc != CVTTMI_OK)
+            return rc;
+        memcpy(ctx->pinnedIn, blocksS16, inBytes);
+        if ((e = hipMemcpyAsync(ctx->dIn, ctx->pinnedIn, inBytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "H2D", e);
+        rc = cvttmi_encode_etc2_alpha11_device(ctx, ctx->dOut, ctx->dIn, numBlocks, isSigned, options, ctx->stream);
+        if (rc != CVTTMI_OK)
+            return rc;
+        if ((e = hipMemcpyAsync(ctx->pinnedOut, ctx->dOut, outBytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "D2H", e);
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "kernel execution", e);
+        memcpy(out, ctx->pinnedOut, outBytes);
+        return CVTTMI_OK;
+    }
 
     int cvttmi_encode_bc6h_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
                                   const cvttmi_options *options, int isSigned, void *hipStream)

@@ -9,8 +9,8 @@
 // blocks is only there for compatibility; throughput comes from the *Batch overloads below (or
 // the C ABI directly), which take any multiple of 8 blocks.
 //
-// Not provided (outside the hot path): BC2-BC5, ETC1, punch-through ETC2,
-// EAC R11 and the ConfigureBC7EncodingPlan* helpers (plans produced by the
+// Not provided (outside the hot path): BC2-BC5, ETC1, punch-through ETC2
+// and the ConfigureBC7EncodingPlan* helpers (plans produced by the
 // reference can be passed as they are).
 //
 // Error behaviour: the reference's functions return void and assert.  These abort() with a
@@ -100,6 +100,7 @@ namespace cvtt
         void EncodeETC2RGBA(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC2CompressionData *compressionData);
         void EncodeETC2Alpha(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options);
 
+        void EncodeETC2Alpha11(uint8_t *pBC, const PixelBlockScalarS16 *pBlocks, bool isSigned, const Options &options);
         void DecodeBC7(PixelBlockU8 *pBlocks, const uint8_t *pBC);
         void DecodeBC6HU(PixelBlockF16 *pBlocks, const uint8_t *pBC);
         void DecodeBC6HS(PixelBlockF16 *pBlocks, const uint8_t *pBC);
@@ -115,6 +116,7 @@ namespace cvtt
         void EncodeETC2Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options);
         void EncodeETC2RGBABatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options);
         void EncodeETC2AlphaBatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options);
+        void EncodeETC2Alpha11Batch(uint8_t *pBC, const PixelBlockScalarS16 *pBlocks, size_t numBlocks, bool isSigned, const Options &options);
         void DecodeBC7Batch(PixelBlockU8 *pBlocks, const uint8_t *pBC, size_t numBlocks);
         void DecodeBC6HUBatch(PixelBlockF16 *pBlocks, const uint8_t *pBC, size_t numBlocks);
         void DecodeBC6HSBatch(PixelBlockF16 *pBlocks, const uint8_t *pBC, size_t numBlocks);

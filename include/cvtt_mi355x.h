@@ -188,6 +188,14 @@ int cvttmi_tile_image_device(cvttmi_context *ctx, void *d_blocks, const void *d_
 int cvttmi_compact_rows_device(cvttmi_context *ctx, void *d_out, const void *d_packed, uint32_t width, uint32_t height,
                                uint32_t bytesPerBlock, void *hipStream);
 
+/* EAC R11: cvtt::Kernels::EncodeETC2Alpha11 (reference ConvectionKernels_API.cpp:258-268 -> CompressEACBlock,
+ * ConvectionKernels_ETC.cpp:2087-2114).  blocksS16: numBlocks x PixelBlockScalarS16 (16 int16: unsigned 0..2047,
+ * signed -1023..1023, clamped like the reference) -> 8 bytes per block. */
+int cvttmi_encode_etc2_alpha11_device(cvttmi_context *ctx, void *d_out, const void *d_blocksS16, size_t numBlocks, int isSigned,
+                                      const cvttmi_options *options, void *hipStream);
+int cvttmi_encode_etc2_alpha11(cvttmi_context *ctx, uint8_t *out, const int16_t *blocksS16, size_t numBlocks, int isSigned,
+                               const cvttmi_options *options);
+
 /* ---- decoders: cvtt::Kernels::DecodeBC7 / DecodeBC6HU / DecodeBC6HS (reference
  * ConvectionKernels_API.cpp:288-310, ConvectionKernels_BC67.cpp:2206-2423, 3058-3289), batched:
  * numBlocks (multiple of 8) packed 16-byte blocks -> PixelBlockU8 (64 B) / PixelBlockF16 (128 B,

@@ -120,6 +120,16 @@ class RefLib:
         assert rc == 0
         return out.reshape(n, per)
 
+    def encode_eac11(self, blocks_s16, options, signed=False):
+        """EncodeETC2Alpha11: (N,16) int16 -> (N,8) uint8"""
+        b = np.ascontiguousarray(blocks_s16, dtype=np.int16)
+        n = b.size // 16
+        assert n % 8 == 0
+        out = np.zeros(n * 8, np.uint8)
+        self.lib.ref_encode_eac11(out.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n),
+                                  options.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(int(signed)))
+        return out.reshape(n, 8)
+
     def decode_bc6h(self, bc, signed=False):
         bc, pb = _u8(bc)
         n = bc.size // 16
@@ -219,6 +229,17 @@ class OracleLib:
         if rc != 0:
             raise RuntimeError("orc_encode_etc2 rc=%d" % rc)
         return out.reshape(n, per)
+
+    def encode_eac11(self, blocks_s16, signed=False):
+        b = np.ascontiguousarray(blocks_s16, dtype=np.int16)
+        n = b.size // 16
+        assert n % 8 == 0
+        out = np.zeros(n * 8, np.uint8)
+        rc = self.lib.orc_encode_eac11(out.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n),
+                                       ctypes.c_int(int(signed)))
+        if rc != 0:
+            raise RuntimeError("orc_encode_eac11 rc=%d" % rc)
+        return out.reshape(n, 8)
 
     def encode_bc1(self, blocks, options, rcp=None, threads=1):
         blocks, pb = _u8(blocks)

@@ -157,6 +157,15 @@ extern "C"
         cvtt::BC6H_IO::g_writeFuncs[modeIndex](out3, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], f[9], f[10], f[11], f[12], f[13]);
     }
 
+    void ref_encode_eac11(uint8_t *out, const int16_t *blocksS16, size_t numBlocks, const void *optionsBytes, int isSigned)
+    {
+        cvtt::Options o;
+        memcpy(&o, optionsBytes, sizeof(o));
+        const cvtt::PixelBlockScalarS16 *in = reinterpret_cast<const cvtt::PixelBlockScalarS16 *>(blocksS16);
+        for (size_t b = 0; b + cvtt::NumParallelBlocks <= numBlocks; b += cvtt::NumParallelBlocks)
+            cvtt::Kernels::EncodeETC2Alpha11(out + b * 8, in + b, isSigned != 0, o);
+    }
+
     void ref_decode_bc6h(uint8_t *outBlocksF16, const uint8_t *bc, size_t numBlocks, int isSigned)
     {
         cvtt::PixelBlockF16 *o = reinterpret_cast<cvtt::PixelBlockF16 *>(outBlocksF16);

@@ -173,3 +173,29 @@ def compact_rows(packed, w, h):
     real = (w + 3) // 4
     per_row = (real + 7) // 8 * 8
     return np.ascontiguousarray(packed.reshape(rows, per_row, -1)[:, :real].reshape(rows * real, -1))
+
+
+def mixed_r11_blocks(seed, groups):
+    """(groups*8, 16) int16 PixelBlockScalarS16 content for EAC R11: in-range noise, narrow ranges, flat, ramps,
+    boundary values and arbitrary int16 (the reference clamps to 0..2047 / -1023..1023)"""
+    rng = _rng(seed)
+    out = np.zeros((groups * 8, 16), np.int16)
+    for b in range(groups * 8):
+        k = b % 8
+        if k == 0:
+            out[b] = rng.integers(-1500, 2600, 16)
+        elif k == 1:
+            out[b] = rng.integers(0, 2048, 16)
+        elif k == 2:
+            out[b] = rng.integers(-1024, 1024, 16)
+        elif k == 3:
+            out[b] = rng.integers(0, 2048) + rng.integers(-20, 21, 16)
+        elif k == 4:
+            out[b] = rng.integers(-1000, 1000)
+        elif k == 5:
+            out[b] = np.linspace(rng.integers(-1024, 2048), rng.integers(-1024, 2048), 16)
+        elif k == 6:
+            out[b] = rng.choice(np.array([-32768, -1025, -1024, -1, 0, 1, 1023, 1024, 2047, 2048, 32767], np.int16), 16)
+        else:
+            out[b] = rng.integers(-32768, 32768, 16)
+    return out

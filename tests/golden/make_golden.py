@@ -127,6 +127,10 @@ def main():
         e2["opt_" + name] = o
         for mode, tag in ((0, "rgb"), (1, "rgba"), (2, "alpha")):
             e2["out_%s_%s" % (tag, name)] = ref.encode_etc2(etc_blocks, o, mode)
+    # EAC R11 (EncodeETC2Alpha11), unsigned and signed, incl. out-of-range inputs (the reference clamps)
+    e2["r11_blocks"] = content.mixed_r11_blocks(11, 64)
+    e2["r11_unsigned"] = ref.encode_eac11(e2["r11_blocks"], P.make_options(), False)
+    e2["r11_signed"] = ref.encode_eac11(e2["r11_blocks"], P.make_options(), True)
     np.savez_compressed(os.path.join(HERE, "etc2_mixed.npz"), **e2)
 
     # ---- known answers (App. H) ----

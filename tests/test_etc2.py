@@ -107,3 +107,29 @@ def test_gpu_config4_full_size_hash(gpu_ctx):
     t = torch.from_numpy(content.config_blocks(4, 4096, 4096)).cuda()
     out = gpu_ctx.encode_etc2_rgba(t, api.Options()).cpu().numpy()
     assert hashlib.sha256(out.tobytes()).hexdigest() == h["config4_etc2rgba_4096_seed4"]
+
+
+def test_oracle_eac11_golden(oracle_lib):
+    g = np.load(os.path.join(GOLD, "etc2_mixed.npz"))
+    assert (g["r11_blocks"] == content.mixed_r11_blocks(11, 64)).all()
+    assert (oracle_lib.encode_eac11(g["r11_blocks"], False) == g["r11_unsigned"]).all()
+    assert (oracle_lib.encode_eac11(g["r11_blocks"], True) == g["r11_signed"]).all()
+
+
+def test_oracle_eac11_vs_reference(oracle_lib, ref_lib):
+    b = content.mixed_r11_blocks(12, 256)
+    for sg in (False, True):
+        assert (oracle_lib.encode_eac11(b, sg) == ref_lib.encode_eac11(b, pyref.make_options(), sg)).all()
+
+
+@pytest.mark.gpu
+def test_gpu_eac11(gpu_ctx, oracle_lib):
+    """EAC R11 unsigned / signed: golden (reference) and oracle on fresh content; host and device path"""
+    import torch
+    g = np.load(os.path.join(GOLD, "etc2_mixed.npz"))
+    assert (gpu_ctx.encode_etc2_alpha11(g["r11_blocks"], signed=False) == g["r11_unsigned"]).all()
+    assert (gpu_ctx.encode_etc2_alpha11(g["r11_blocks"], signed=True) == g["r11_signed"]).all()
+    b = content.mixed_r11_blocks(77, 512)
+    t = torch.from_numpy(b).cuda()
+    for sg in (False, True):
+        assert (gpu_ctx.encode_etc2_alpha11(t, signed=sg).cpu().numpy() == oracle_lib.encode_eac11(b, sg)).all()

@@ -9,7 +9,7 @@ from convectionkernels_amd import api, synth
 
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 opaque = len(sys.argv) > 2 and sys.argv[2] == "opaque"
-names = ["dual seeds", "dual-plane search", "partition bounds", "seed PCA", "single-plane search", "pack", "load+block bounds", "-"]
+names = ["dual seeds", "dual-plane search", "partition bounds", "seed PCA", "single-plane search", "pack", "load+block bounds", "projection"]
 ctx = api.Context(0)
 lib = api.load_library()
 t = torch.from_numpy(synth.tile_blocks(synth.image_rgba8(2, size, size, opaque=opaque))).cuda()
@@ -20,7 +20,7 @@ for exhaustive in (False, True):
     ctx.encode_bc7(t); torch.cuda.synchronize()
     lib.cvttmi_bc7_prof_read(buf)
     tot = float(sum(buf[:8]))
-    print("exhaustive" if exhaustive else "pruned", {names[i]: round(buf[i] / tot, 4) for i in range(7)}, "cycles/wave", tot / (t.shape[0] / 16))
+    print("exhaustive" if exhaustive else "pruned", {names[i]: round(buf[i] / tot, 4) for i in range(8)}, "cycles/wave", tot / (t.shape[0] / 16))
     print("   wave-cycle histogram (log2 buckets from 2^12):", list(buf[16:32]))
     print("   dual configs: quad-evaluations executed", buf[32], "needed by the block itself", buf[33],
           "| single-plane shapes: executed", buf[34], "needed", buf[35])
