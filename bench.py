@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096, help="image edge in pixels (default: BASELINE config 2)")
     ap.add_argument("--opaque", action="store_true", help="variant 2b: alpha forced to 255 (modes 0-3 run)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the exhaustive-search comparison launch (profiling runs)")
     ap.add_argument("--exhaustive", action="store_true",
                     help="evaluate every candidate like the reference (default: exact branch-and-bound, same output)")
     args = ap.parse_args()
@@ -219,7 +220,7 @@ def main():
             result["valu_issue"] = {"insts_per_wave": pmc["valu_insts_per_wave"], "achieved": waves * pmc["valu_insts_per_wave"] / (k_ms * 1e-3),
                                     "peak": peak, "unit": "wave-instructions/s",
                                     "frac": waves * pmc["valu_insts_per_wave"] / (k_ms * 1e-3) / peak, "source": pmc["source"]}
-        if world == 1 and not args.exhaustive:
+        if world == 1 and not args.exhaustive and not args.no_extra:
             # the same workload with pruning off, for reference (not the headline value)
             ctx.set_exhaustive(True)
             ctx.encode_bc7(d_in, opt, plan, out=d_out)

@@ -53,7 +53,8 @@ __device__ unsigned long long g_bc7Prof[48];
 #define PROF_MARK(slot) { const unsigned long long now = __builtin_readcyclecounter(); profAcc[slot] += now - profT; profT = now; }
 #define PROF_FLUSH if (threadIdx.x == 0) { unsigned long long tot = 0; for (int i = 0; i < 8; i++) { atomicAdd(&g_bc7Prof[i], profAcc[i]); tot += profAcc[i]; } \
     int bucket = 63 - __builtin_clzll(tot | 1ull) - 12; bucket = bucket < 0 ? 0 : (bucket > 15 ? 15 : bucket); atomicAdd(&g_bc7Prof[16 + bucket], 1ull); \
-    for (int i = 0; i < 8; i++) atomicAdd(&g_bc7Prof[32 + i], profCnt[i]); }
+    } { unsigned long long wsum[8]; for (int i = 0; i < 8; i++) { unsigned long long v = profCnt[i]; if (i >= 4) { for (int st = 1; st < 64; st <<= 1) v += __shfl_xor(v, st); } wsum[i] = v; } \
+    if (threadIdx.x == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_bc7Prof[32 + i], wsum[i]); }
 #define PROF_COUNT(slot, n) { profCnt[slot] += (unsigned long long)(n); }
 extern "C" int cvttmi_bc7_prof_read(unsigned long long *out)
 {
@@ -1543,6 +1544,8 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             aliveBits |= alive ? (1u << k) : 0u;
         }
 
+        PROF_COUNT(4, __popc(aliveBits))
+        PROF_COUNT(5, (c == 0 && valid) ? 1 : 0)
         const int itemCap = (numSubsets == 3) ? 21 : 32; // items * subsets <= 64 lanes of the seed pass
         // BC7_RespectPunchThrough couples the 8 blocks of a group in modes 6 and 7 (BC67.cpp:1283-1428): a
         // partition one block wants is searched by its whole group, trial by trial in lock-step

@@ -24,3 +24,4 @@ for exhaustive in (False, True):
     print("   wave-cycle histogram (log2 buckets from 2^12):", list(buf[16:32]))
     print("   dual configs: quad-evaluations executed", buf[32], "needed by the block itself", buf[33],
           "| single-plane shapes: executed", buf[34], "needed", buf[35])
+    print("   candidate partitions alive at stage start (all stages):", buf[36], "block-stages:", buf[37])
