@@ -1503,5 +1503,6 @@ int orc_encode_bc7(uint8_t *out, const uint8_t *blocks, size_t numBlocks, const 
 }
 
 #include "cvtt_oracle_bc1.inc"
+#include "cvtt_oracle_s3tc.inc"
 #include "cvtt_oracle_bc6h.inc"
 #include "cvtt_oracle_etc2.inc"

@@ -82,6 +82,10 @@ int orc_encode_bc6h(uint8_t *out, const uint8_t *blocksF16, size_t numBlocks,
 int orc_encode_etc2(uint8_t *out, const uint8_t *blocks, size_t numBlocks,
                     const orc_options *options, int mode, int threads);
 
+/* BC2 / BC3 / BC4U / BC4S / BC5U / BC5S (format 2..7; signed formats take PixelBlockS8): 8 B (BC4) or 16 B per block */
+int orc_encode_s3tc(uint8_t *out, const uint8_t *blocks, size_t numBlocks, const orc_options *options, int format,
+                    const float *rcp17, int threads);
+
 /* EAC R11 (cvtt::Kernels::EncodeETC2Alpha11): numBlocks * 16 int16 (PixelBlockScalarS16) -> 8 B/block */
 int orc_encode_eac11(uint8_t *out, const int16_t *blocksS16, size_t numBlocks, int isSigned);
 

@@ -120,6 +120,17 @@ class RefLib:
         assert rc == 0
         return out.reshape(n, per)
 
+    def encode_s3tc(self, blocks, options, fmt):
+        """fmt 2..7 = BC2, BC3, BC4U, BC4S, BC5U, BC5S; (N,16,4) uint8 (int8 bit patterns for the signed formats)"""
+        blocks, pb = _u8(blocks)
+        n = blocks.size // 64
+        assert n % 8 == 0
+        per = 8 if fmt in (4, 5) else 16
+        out = np.zeros(n * per, np.uint8)
+        self.lib.ref_encode_s3tc(out.ctypes.data_as(ctypes.c_void_p), pb, ctypes.c_size_t(n),
+                                 options.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(fmt))
+        return out.reshape(n, per)
+
     def encode_eac11(self, blocks_s16, options, signed=False):
         """EncodeETC2Alpha11: (N,16) int16 -> (N,8) uint8"""
         b = np.ascontiguousarray(blocks_s16, dtype=np.int16)
@@ -228,6 +239,22 @@ class OracleLib:
                                       options.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(mode), ctypes.c_int(threads))
         if rc != 0:
             raise RuntimeError("orc_encode_etc2 rc=%d" % rc)
+        return out.reshape(n, per)
+
+    def encode_s3tc(self, blocks, options, fmt, rcp=None, threads=1):
+        blocks, pb = _u8(blocks)
+        n = blocks.size // 64
+        assert n % 8 == 0
+        per = 8 if fmt in (4, 5) else 16
+        out = np.zeros(n * per, np.uint8)
+        rcp_p = None
+        if rcp is not None:
+            rcp = np.ascontiguousarray(rcp, np.float32)
+            rcp_p = rcp.ctypes.data_as(ctypes.c_void_p)
+        rc = self.lib.orc_encode_s3tc(out.ctypes.data_as(ctypes.c_void_p), pb, ctypes.c_size_t(n),
+                                      options.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(fmt), rcp_p, ctypes.c_int(threads))
+        if rc != 0:
+            raise RuntimeError("orc_encode_s3tc rc=%d" % rc)
         return out.reshape(n, per)
 
     def encode_eac11(self, blocks_s16, signed=False):

@@ -157,6 +157,29 @@ extern "C"
         cvtt::BC6H_IO::g_writeFuncs[modeIndex](out3, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], f[9], f[10], f[11], f[12], f[13]);
     }
 
+    // format: 2 = BC2, 3 = BC3, 4 = BC4U, 5 = BC4S, 6 = BC5U, 7 = BC5S
+    void ref_encode_s3tc(uint8_t *out, const uint8_t *blocks, size_t numBlocks, const void *optionsBytes, int format)
+    {
+        cvtt::Options o;
+        memcpy(&o, optionsBytes, sizeof(o));
+        const cvtt::PixelBlockU8 *in = reinterpret_cast<const cvtt::PixelBlockU8 *>(blocks);
+        const cvtt::PixelBlockS8 *ins = reinterpret_cast<const cvtt::PixelBlockS8 *>(blocks);
+        const size_t per = (format == 4 || format == 5) ? 8 : 16;
+        for (size_t b = 0; b + cvtt::NumParallelBlocks <= numBlocks; b += cvtt::NumParallelBlocks)
+        {
+            uint8_t *dst = out + b * per;
+            switch (format)
+            {
+            case 2: cvtt::Kernels::EncodeBC2(dst, in + b, o); break;
+            case 3: cvtt::Kernels::EncodeBC3(dst, in + b, o); break;
+            case 4: cvtt::Kernels::EncodeBC4U(dst, in + b, o); break;
+            case 5: cvtt::Kernels::EncodeBC4S(dst, ins + b, o); break;
+            case 6: cvtt::Kernels::EncodeBC5U(dst, in + b, o); break;
+            default: cvtt::Kernels::EncodeBC5S(dst, ins + b, o); break;
+            }
+        }
+    }
+
     void ref_encode_eac11(uint8_t *out, const int16_t *blocksS16, size_t numBlocks, const void *optionsBytes, int isSigned)
     {
         cvtt::Options o;
