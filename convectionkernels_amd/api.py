@@ -155,6 +155,8 @@ _EXPORTS = (
     "cvttmi_tiled_block_count", "cvttmi_tile_image_device", "cvttmi_compact_rows_device",
     "cvttmi_selftest_arith",
     "cvttmi_encode_etc2_alpha11_device", "cvttmi_encode_etc2_alpha11",
+    "cvttmi_encode_bc2_device", "cvttmi_encode_bc3_device", "cvttmi_encode_bc4_device", "cvttmi_encode_bc5_device",
+    "cvttmi_encode_bc2", "cvttmi_encode_bc3", "cvttmi_encode_bc4", "cvttmi_encode_bc5",
     "cvttmi_decode_bc7_device", "cvttmi_decode_bc7", "cvttmi_decode_bc6h_device", "cvttmi_decode_bc6h",
 )
 
@@ -201,6 +203,13 @@ def load_library():
                                              ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
     lib.cvttmi_compact_rows_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
                                                ctypes.c_uint32, ctypes.c_void_p]
+    for n in ("cvttmi_encode_bc2", "cvttmi_encode_bc3"):
+        getattr(lib, n).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        getattr(lib, n + "_device").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    for n in ("cvttmi_encode_bc4", "cvttmi_encode_bc5"):
+        getattr(lib, n).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+        getattr(lib, n + "_device").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int,
+                                                 ctypes.c_void_p]
     lib.cvttmi_encode_etc2_alpha11_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                                       ctypes.c_void_p, ctypes.c_void_p]
     lib.cvttmi_encode_etc2_alpha11.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
@@ -336,6 +345,33 @@ class Context:
         return self._encode_simple(self._lib.cvttmi_encode_bc1, self._lib.cvttmi_encode_bc1_device, "encode_bc1",
                                    blocks, options, out, stream, 64, 8)
 
+
+    # -- BC2 / BC3 / BC4 / BC5 --
+    def encode_bc2(self, blocks, options=None, out=None, stream=None):
+        """Batched cvtt::Kernels::EncodeBC2: (N,16,4) uint8 -> (N,16) uint8 [explicit alpha | colour]."""
+        return self._encode_simple(self._lib.cvttmi_encode_bc2, self._lib.cvttmi_encode_bc2_device, "encode_bc2", blocks, options, out, stream, 64, 16)
+
+    def encode_bc3(self, blocks, options=None, out=None, stream=None):
+        """Batched cvtt::Kernels::EncodeBC3: (N,16,4) uint8 -> (N,16) uint8 [interpolated alpha | colour]."""
+        return self._encode_simple(self._lib.cvttmi_encode_bc3, self._lib.cvttmi_encode_bc3_device, "encode_bc3", blocks, options, out, stream, 64, 16)
+
+    def encode_bc4(self, blocks, options=None, signed=False, out=None, stream=None):
+        """Batched cvtt::Kernels::EncodeBC4U / EncodeBC4S (red channel; signed: int8 PixelBlockS8): -> (N,8) uint8."""
+        sg = 1 if signed else 0
+        host = lambda h, o, b, n, opt: self._lib.cvttmi_encode_bc4(h, o, b, n, opt, sg)
+        dev = lambda h, o, b, n, opt, st: self._lib.cvttmi_encode_bc4_device(h, o, b, n, opt, sg, st)
+        if isinstance(blocks, np.ndarray) and blocks.dtype == np.int8:
+            blocks = blocks.view(np.uint8)
+        return self._encode_simple(host, dev, "encode_bc4", blocks, options, out, stream, 64, 8)
+
+    def encode_bc5(self, blocks, options=None, signed=False, out=None, stream=None):
+        """Batched cvtt::Kernels::EncodeBC5U / EncodeBC5S (red, green): -> (N,16) uint8."""
+        sg = 1 if signed else 0
+        host = lambda h, o, b, n, opt: self._lib.cvttmi_encode_bc5(h, o, b, n, opt, sg)
+        dev = lambda h, o, b, n, opt, st: self._lib.cvttmi_encode_bc5_device(h, o, b, n, opt, sg, st)
+        if isinstance(blocks, np.ndarray) and blocks.dtype == np.int8:
+            blocks = blocks.view(np.uint8)
+        return self._encode_simple(host, dev, "encode_bc5", blocks, options, out, stream, 64, 16)
 
     # -- BC6H --
     def encode_bc6h(self, blocks, options=None, signed=False, out=None, stream=None):
@@ -490,6 +526,31 @@ def EncodeBC7(pBlocks, options=None, encodingPlan=None, device=0):
     """cvtt::Kernels::EncodeBC7 (reference ConvectionKernels_API.cpp:41-54): any multiple of
     NumParallelBlocks blocks; returns the packed 16-byte blocks."""
     return default_context(device).encode_bc7(pBlocks, options, encodingPlan)
+
+
+def EncodeBC2(pBlocks, options=None, device=0):
+    """cvtt::Kernels::EncodeBC2 (reference ConvectionKernels_API.cpp:101-115)."""
+    return default_context(device).encode_bc2(pBlocks, options)
+
+
+def EncodeBC3(pBlocks, options=None, device=0):
+    return default_context(device).encode_bc3(pBlocks, options)
+
+
+def EncodeBC4U(pBlocks, options=None, device=0):
+    return default_context(device).encode_bc4(pBlocks, options, signed=False)
+
+
+def EncodeBC4S(pBlocks, options=None, device=0):
+    return default_context(device).encode_bc4(pBlocks, options, signed=True)
+
+
+def EncodeBC5U(pBlocks, options=None, device=0):
+    return default_context(device).encode_bc5(pBlocks, options, signed=False)
+
+
+def EncodeBC5S(pBlocks, options=None, device=0):
+    return default_context(device).encode_bc5(pBlocks, options, signed=True)
 
 
 def EncodeETC2Alpha11(pBlocks, isSigned=False, options=None, device=0):

@@ -1,4 +1,4 @@
-// BC1 (DXT1, alpha-test variant) endpoint search for gfx950.
+// BC1 (DXT1, alpha-test variant) endpoint search for gfx950; also the colour half of BC2 / BC3 (alphaTest = 0).
 //
 // Replaces cvtt::Internal::S3TCComputer::PackRGB(alphaTest = true) as reached from
 // cvtt::Kernels::EncodeBC1 (reference ConvectionKernels_API.cpp:86-99,
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void cvttmi_bc1_kernel(const uint8_t *__restric
     u32 opaqueMask = 0;
 #pragma unroll
     for (int px = 0; px < 16; px++)
-        if (!(byteI(pix[px], 3) < A.threshold))
+        if (!A.alphaTest || !(byteI(pix[px], 3) < A.threshold))
             opaqueMask |= 1u << px;
 
     // weighted PCA (S3TC.cpp:764-784): passes 0/1 over the opaque pixels, min/max pass over all
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void cvttmi_bc1_kernel(const uint8_t *__restric
     u32 bestEP0 = 0, bestEP1 = 0, bestIdx = 0; // indexes: 2 bits per pixel
     int bestRange = 0;
 
-    for (int range = 3; range <= 4; range++)
+    for (int range = A.alphaTest ? 3 : 4; range <= 4; range++) // S3TC.cpp:939
     {
         int tweakRounds = (range == 3) ? 3 : 4; // BCCommon::TweakRoundsForRange
         if (tweakRounds > maxTweak)
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64) void cvttmi_bc1_kernel(const uint8_t *__restric
         uint2 o;
         o.x = c0 | (c1 << 16);
         o.y = packedIdx;
-        *reinterpret_cast<uint2 *>(out + (size_t)blockIndex * 8u) = o;
+        *reinterpret_cast<uint2 *>(out + (size_t)blockIndex * A.outStride + A.outOffset) = o;
     }
 }
 

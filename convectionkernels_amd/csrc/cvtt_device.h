@@ -76,6 +76,9 @@ struct CvttBc1Args
     int32_t seedPoints;   // Options::seedPoints
     int32_t threshold;    // floor(threshold * 255 + 0.5) as a signed 16-bit lane value (S3TC.cpp:748)
     uint32_t numBlocks;
+    uint32_t alphaTest;   // 1: BC1 (EncodeBC1); 0: the colour half of BC2 / BC3 (range 4 only, every pixel weighs 1)
+    uint32_t outStride;   // bytes between output blocks (8, or 16 inside BC2 / BC3)
+    uint32_t outOffset;
 };
 
 // BC6H per-launch parameters.

@@ -77,6 +77,21 @@ namespace cvtt
             std::lock_guard<std::mutex> g(g_lock);
             check(cvttmi_encode_bc1(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeBC1");
         }
+#define CVTT_S3TC_BATCH(NAME, PIXELTYPE, CALL)                                                                                  \
+        void NAME##Batch(uint8_t *pBC, const PIXELTYPE *pBlocks, size_t numBlocks, const Options &options)                      \
+        {                                                                                                                       \
+            std::lock_guard<std::mutex> g(g_lock);                                                                              \
+            check(CALL, #NAME);                                                                                                 \
+        }                                                                                                                       \
+        void NAME(uint8_t *pBC, const PIXELTYPE *pBlocks, const Options &options) { NAME##Batch(pBC, pBlocks, NumParallelBlocks, options); }
+        CVTT_S3TC_BATCH(EncodeBC2, PixelBlockU8, cvttmi_encode_bc2(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)))
+        CVTT_S3TC_BATCH(EncodeBC3, PixelBlockU8, cvttmi_encode_bc3(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)))
+        CVTT_S3TC_BATCH(EncodeBC4U, PixelBlockU8, cvttmi_encode_bc4(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), 0))
+        CVTT_S3TC_BATCH(EncodeBC4S, PixelBlockS8, cvttmi_encode_bc4(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), 1))
+        CVTT_S3TC_BATCH(EncodeBC5U, PixelBlockU8, cvttmi_encode_bc5(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), 0))
+        CVTT_S3TC_BATCH(EncodeBC5S, PixelBlockS8, cvttmi_encode_bc5(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), 1))
+#undef CVTT_S3TC_BATCH
+
         void EncodeBC6HUBatch(uint8_t *pBC, const PixelBlockF16 *pBlocks, size_t numBlocks, const Options &options)
         {
             std::lock_guard<std::mutex> g(g_lock);

@@ -35,6 +35,9 @@ extern "C" hipError_t cvttmi_launch_decode(const void *d_bc, void *d_out, uint32
                                            const CvttDeviceTables *d_tables, hipStream_t stream);
 extern "C" hipError_t cvttmi_launch_eac11(const void *d_blocksS16, void *d_out, uint32_t numBlocks, int isSigned,
                                           const CvttDeviceTables *d_tables, hipStream_t stream);
+extern "C" hipError_t cvttmi_launch_s3tc_alpha(const void *d_blocks, void *d_out, uint32_t numBlocks, uint32_t channel, uint32_t outStride,
+                                               uint32_t outOffset, int isSigned, int explicitAlpha, int seedPoints, int refineRounds,
+                                               const CvttDeviceTables *d_tables, hipStream_t stream);
 extern "C" hipError_t cvttmi_launch_bc1(const void *d_blocks, void *d_out, const CvttBc1Args *args,
                                         const CvttDeviceTables *d_tables, hipStream_t stream);
 
@@ -902,6 +905,9 @@ extern "C"
         // S3TC.cpp:748: MakeUInt15(static_cast<uint16_t>(floor(alphaThreshold * 255.0f + 0.5f)))
         args.threshold = static_cast<int16_t>(static_cast<uint16_t>(static_cast<int32_t>(floor(options->threshold * 255.0f + 0.5f))));
         args.numBlocks = static_cast<uint32_t>(numBlocks);
+        args.alphaTest = 1u;
+        args.outStride = 8u;
+        args.outOffset = 0u;
         if (ctx->timing)
             hipEventRecord(ctx->evStart, stream);
         e = cvttmi_launch_bc1(d_blocks, d_out, &args, ctx->dTables, stream);
@@ -918,6 +924,99 @@ extern "C"
         }
         return CVTTMI_OK;
     }
+
+    // BC2 / BC3 / BC4 / BC5 (reference ConvectionKernels_API.cpp:101-199).  format: 2 = BC2, 3 = BC3, 4 = BC4U, 5 = BC4S,
+    // 6 = BC5U, 7 = BC5S; signed formats read PixelBlockS8.
+    static int s3tcDevice(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options,
+                          int format, void *hipStream)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        if (!d_out || !d_blocks || !options || (numBlocks % 8) != 0 || numBlocks > 0xfffffff0u || format < 2 || format > 7)
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        if ((format == 2 || format == 3) && (options->flags & CVTTMI_FLAG_S3TC_EXHAUSTIVE))
+            return fail(ctx, CVTTMI_E_UNSUPPORTED, "S3TC_Exhaustive is not implemented on the GPU path");
+        if (numBlocks == 0)
+            return CVTTMI_OK;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        hipStream_t stream = static_cast<hipStream_t>(hipStream);
+        const uint32_t n = static_cast<uint32_t>(numBlocks);
+        if (format == 2 || format == 3)
+        {
+            CvttBc1Args args;
+            fillWeightArgs(options, args.w, args.wSq, args.rcpW);
+            args.flags = options->flags;
+            args.refineRounds = options->refineRoundsS3TC;
+            args.seedPoints = options->seedPoints;
+            args.threshold = 0;
+            args.numBlocks = n;
+            args.alphaTest = 0u;
+            args.outStride = 16u;
+            args.outOffset = 8u;
+            if ((e = cvttmi_launch_bc1(d_blocks, d_out, &args, ctx->dTables, stream)) != hipSuccess)
+                return fail(ctx, CVTTMI_E_HIP, "s3tc colour kernel launch", e);
+            e = cvttmi_launch_s3tc_alpha(d_blocks, d_out, n, 3, 16, 0, 0, format == 2, options->seedPoints, options->refineRoundsIIC, ctx->dTables, stream);
+        }
+        else if (format == 4 || format == 5)
+            e = cvttmi_launch_s3tc_alpha(d_blocks, d_out, n, 0, 8, 0, format == 5, 0, options->seedPoints, options->refineRoundsIIC, ctx->dTables, stream);
+        else
+        {
+            e = cvttmi_launch_s3tc_alpha(d_blocks, d_out, n, 0, 16, 0, format == 7, 0, options->seedPoints, options->refineRoundsIIC, ctx->dTables, stream);
+            if (e == hipSuccess)
+                e = cvttmi_launch_s3tc_alpha(d_blocks, d_out, n, 1, 16, 8, format == 7, 0, options->seedPoints, options->refineRoundsIIC, ctx->dTables, stream);
+        }
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "s3tc alpha kernel launch", e);
+        return CVTTMI_OK;
+    }
+
+    static int s3tcHost(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options, int format)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        if (!out || !blocks || !options || (numBlocks % 8) != 0)
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        if (numBlocks == 0)
+            return CVTTMI_OK;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        const size_t inBytes = numBlocks * 64, outBytes = numBlocks * ((format == 4 || format == 5) ? 8 : 16);
+        int rc = ensureStaging(ctx, inBytes, outBytes);
+        if (rc != CVTTMI_OK)
+            return rc;
+        memcpy(ctx->pinnedIn, blocks, inBytes);
+        if ((e = hipMemcpyAsync(ctx->dIn, ctx->pinnedIn, inBytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "H2D", e);
+        rc = s3tcDevice(ctx, ctx->dOut, ctx->dIn, numBlocks, options, format, ctx->stream);
+        if (rc != CVTTMI_OK)
+            return rc;
+        if ((e = hipMemcpyAsync(ctx->pinnedOut, ctx->dOut, outBytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "D2H", e);
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "kernel execution", e);
+        memcpy(out, ctx->pinnedOut, outBytes);
+        return CVTTMI_OK;
+    }
+
+    int cvttmi_encode_bc2_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, void *hipStream)
+    { return s3tcDevice(ctx, d_out, d_blocks, numBlocks, options, 2, hipStream); }
+    int cvttmi_encode_bc3_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, void *hipStream)
+    { return s3tcDevice(ctx, d_out, d_blocks, numBlocks, options, 3, hipStream); }
+    int cvttmi_encode_bc4_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, int isSigned, void *hipStream)
+    { return s3tcDevice(ctx, d_out, d_blocks, numBlocks, options, isSigned ? 5 : 4, hipStream); }
+    int cvttmi_encode_bc5_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, int isSigned, void *hipStream)
+    { return s3tcDevice(ctx, d_out, d_blocks, numBlocks, options, isSigned ? 7 : 6, hipStream); }
+    int cvttmi_encode_bc2(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options)
+    { return s3tcHost(ctx, out, blocks, numBlocks, options, 2); }
+    int cvttmi_encode_bc3(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options)
+    { return s3tcHost(ctx, out, blocks, numBlocks, options, 3); }
+    int cvttmi_encode_bc4(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options, int isSigned)
+    { return s3tcHost(ctx, out, blocks, numBlocks, options, isSigned ? 5 : 4); }
+    int cvttmi_encode_bc5(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options, int isSigned)
+    { return s3tcHost(ctx, out, blocks, numBlocks, options, isSigned ? 7 : 6); }
 
     int cvttmi_encode_bc1(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
                           const cvttmi_options *options)

@@ -9,7 +9,7 @@
 // blocks is only there for compatibility; throughput comes from the *Batch overloads below (or
 // the C ABI directly), which take any multiple of 8 blocks.
 //
-// Not provided (outside the hot path): BC2-BC5, ETC1, punch-through ETC2
+// Not provided (outside the hot path): ETC1, punch-through ETC2
 // and the ConfigureBC7EncodingPlan* helpers (plans produced by the
 // reference can be passed as they are).
 //
@@ -93,6 +93,12 @@ namespace cvtt
 
         // 8 blocks in, 8 blocks out -- the reference's call convention
         void EncodeBC1(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options);
+        void EncodeBC2(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options);
+        void EncodeBC3(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options);
+        void EncodeBC4U(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options);
+        void EncodeBC4S(uint8_t *pBC, const PixelBlockS8 *pBlocks, const Options &options);
+        void EncodeBC5U(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options);
+        void EncodeBC5S(uint8_t *pBC, const PixelBlockS8 *pBlocks, const Options &options);
         void EncodeBC6HU(uint8_t *pBC, const PixelBlockF16 *pBlocks, const Options &options);
         void EncodeBC6HS(uint8_t *pBC, const PixelBlockF16 *pBlocks, const Options &options);
         void EncodeBC7(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, const BC7EncodingPlan &encodingPlan);
@@ -110,6 +116,12 @@ namespace cvtt
 
         // numBlocks (a multiple of NumParallelBlocks) blocks per call; group g = blocks [8g, 8g+8)
         void EncodeBC1Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options);
+        void EncodeBC2Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options);
+        void EncodeBC3Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options);
+        void EncodeBC4UBatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options);
+        void EncodeBC4SBatch(uint8_t *pBC, const PixelBlockS8 *pBlocks, size_t numBlocks, const Options &options);
+        void EncodeBC5UBatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options);
+        void EncodeBC5SBatch(uint8_t *pBC, const PixelBlockS8 *pBlocks, size_t numBlocks, const Options &options);
         void EncodeBC6HUBatch(uint8_t *pBC, const PixelBlockF16 *pBlocks, size_t numBlocks, const Options &options);
         void EncodeBC6HSBatch(uint8_t *pBC, const PixelBlockF16 *pBlocks, size_t numBlocks, const Options &options);
         void EncodeBC7Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options, const BC7EncodingPlan &encodingPlan);

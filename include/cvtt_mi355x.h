@@ -188,6 +188,20 @@ int cvttmi_tile_image_device(cvttmi_context *ctx, void *d_blocks, const void *d_
 int cvttmi_compact_rows_device(cvttmi_context *ctx, void *d_out, const void *d_packed, uint32_t width, uint32_t height,
                                uint32_t bytesPerBlock, void *hipStream);
 
+/* BC2 / BC3 / BC4 / BC5: cvtt::Kernels::EncodeBC2, EncodeBC3, EncodeBC4U/S, EncodeBC5U/S (reference
+ * ConvectionKernels_API.cpp:101-199 -> S3TCComputer::PackRGB without alpha test, PackExplicitAlpha,
+ * PackInterpolatedAlpha, ConvectionKernels_S3TC.cpp:306-715).  Input PixelBlockU8 (isSigned: PixelBlockS8, biased
+ * like Util::BiasSignedInput); output 16 B per block (BC4: 8 B): BC2/BC3 = [alpha 8 B | colour 8 B], BC4 = red,
+ * BC5 = [red | green].  Options used: seedPoints, refineRoundsIIC (alpha), refineRoundsS3TC + weights (colour). */
+int cvttmi_encode_bc2_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, void *hipStream);
+int cvttmi_encode_bc3_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, void *hipStream);
+int cvttmi_encode_bc4_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, int isSigned, void *hipStream);
+int cvttmi_encode_bc5_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, int isSigned, void *hipStream);
+int cvttmi_encode_bc2(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options);
+int cvttmi_encode_bc3(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options);
+int cvttmi_encode_bc4(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options, int isSigned);
+int cvttmi_encode_bc5(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options, int isSigned);
+
 /* EAC R11: cvtt::Kernels::EncodeETC2Alpha11 (reference ConvectionKernels_API.cpp:258-268 -> CompressEACBlock,
  * ConvectionKernels_ETC.cpp:2087-2114).  blocksS16: numBlocks x PixelBlockScalarS16 (16 int16: unsigned 0..2047,
  * signed -1023..1023, clamped like the reference) -> 8 bytes per block. */

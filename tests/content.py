@@ -199,3 +199,32 @@ def mixed_r11_blocks(seed, groups):
         else:
             out[b] = rng.integers(-32768, 32768, 16)
     return out
+
+
+def alpha_structure_blocks(seed, n):
+    """(n,16,4) uint8: per-channel structures that exercise the interpolated-alpha heuristics of BC3/4/5 -- narrow
+    ranges, only the terminals, values next to the terminals, ranges with a few terminal outliers, flat, ramps"""
+    rng = _rng(seed)
+    out = np.zeros((n, 16, 4), np.uint8)
+    for b in range(n):
+        k = b % 8
+        base = rng.integers(0, 256, 4)
+        if k == 0:
+            v = np.clip(base[None] + rng.integers(-3, 4, (16, 4)), 0, 255)
+        elif k == 1:
+            v = rng.choice(np.array([0, 255]), (16, 4))
+        elif k == 2:
+            v = rng.choice(np.array([0, 1, 2, 253, 254, 255]), (16, 4))
+        elif k == 3:
+            v = np.where(rng.integers(0, 4, (16, 4)) == 0, rng.choice(np.array([0, 255]), (16, 4)),
+                         np.clip(base[None] + rng.integers(-20, 21, (16, 4)), 0, 255))
+        elif k == 4:
+            v = np.repeat(base[None], 16, 0)
+        elif k == 5:
+            v = np.clip(np.linspace(base, rng.integers(0, 256, 4), 16), 0, 255)
+        elif k == 6:
+            v = rng.integers(100, 156, (16, 4))
+        else:
+            v = rng.integers(0, 256, (16, 4))
+        out[b] = v
+    return out

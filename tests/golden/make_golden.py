@@ -100,6 +100,19 @@ def main():
     b1["names"] = np.array(b1names)
     np.savez_compressed(os.path.join(HERE, "bc1_mixed.npz"), **b1)
 
+    # ---- BC2 / BC3 / BC4 / BC5: mixed content + alpha structures x option variants ----
+    sblocks = np.concatenate([content.mixed_ldr_blocks(2345, 24), content.alpha_structure_blocks(6, 256)])
+    s3 = {"blocks": sblocks, "rcp": rcp}
+    for name, o in {
+        "default": P.make_options(),
+        "uniform_seeds2_refine1": P.make_options(flags=P.FLAGS_DEFAULT | P.FLAG_UNIFORM, seed_points=2, refine_iic=1, refine_s3tc=1),
+        "refine3_seeds3": P.make_options(refine_iic=3, seed_points=3),
+    }.items():
+        s3["opt_" + name] = o
+        for fmt, tag in ((2, "bc2"), (3, "bc3"), (4, "bc4u"), (5, "bc4s"), (6, "bc5u"), (7, "bc5s")):
+            s3["out_%s_%s" % (tag, name)] = ref.encode_s3tc(sblocks, o, fmt)
+    np.savez_compressed(os.path.join(HERE, "s3tc_mixed.npz"), **s3)
+
     # ---- BC6H: mixed HDR content x option variants (canonical -O1 build only: hazard H1) ----
     hdr = content.mixed_hdr_blocks(606, 16)
     hdrs = content.mixed_hdr_blocks(607, 8, signed=True)
