@@ -9,6 +9,7 @@
 #include "cvtt_oracle.h"
 #include "cvtt_oracle_tables.h"
 #include "cvtt_oracle_bc7sc.h"
+#include "cvtt_oracle_s3tcsc.h"
 
 #include <float.h>
 #include <math.h>
