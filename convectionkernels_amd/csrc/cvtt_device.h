@@ -37,6 +37,8 @@ struct CvttDeviceTables
     // pixel bitmasks of subsets 1 and 2 of every three-subset partition (subset 1 of a
     // two-subset partition is partition2 itself)
     uint16_t subsetMask3[64][2];
+    // BC1-family single-colour end points (tools/gen_s3tc_single_color.py): [paranoid*4 + (range==3)*2 + green][value] = {min, max, colour, span}
+    uint8_t s3tcSingleColor[8][256][4];
 };
 
 // The caller's plan plus two bitmaps derived on the host: which shapes the plan's

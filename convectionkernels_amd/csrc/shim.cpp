@@ -18,6 +18,7 @@
 
 #include "cvtt_device.h"
 #include "bc7_tables.h"
+#include "s3tc_sc_tables.h"
 #include "bc6h_layout.h"
 #include "etc_tables.h"
 
@@ -130,6 +131,7 @@ namespace
             t.anchor3[i][0] = k_anchor3[i * 2 + 0];
             t.anchor3[i][1] = k_anchor3[i * 2 + 1];
         }
+        memcpy(t.s3tcSingleColor, k_s3tcsc, sizeof(t.s3tcSingleColor));
         for (int r = 0; r < 3; r++)
             for (int tw = 0; tw < 4; tw++)
                 tweakFactors(tw, 4 << r, t.tweakFactors[r][tw]);
@@ -889,8 +891,6 @@ extern "C"
             return CVTTMI_E_INVALID;
         if (!d_out || !d_blocks || !options || (numBlocks % 8) != 0 || numBlocks > 0xfffffff0u)
             return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
-        if (options->flags & CVTTMI_FLAG_S3TC_EXHAUSTIVE)
-            return fail(ctx, CVTTMI_E_UNSUPPORTED, "S3TC_Exhaustive is not implemented on the GPU path");
         if (numBlocks == 0)
             return CVTTMI_OK;
         hipError_t e = hipSetDevice(ctx->device);
@@ -934,8 +934,6 @@ extern "C"
             return CVTTMI_E_INVALID;
         if (!d_out || !d_blocks || !options || (numBlocks % 8) != 0 || numBlocks > 0xfffffff0u || format < 2 || format > 7)
             return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
-        if ((format == 2 || format == 3) && (options->flags & CVTTMI_FLAG_S3TC_EXHAUSTIVE))
-            return fail(ctx, CVTTMI_E_UNSUPPORTED, "S3TC_Exhaustive is not implemented on the GPU path");
         if (numBlocks == 0)
             return CVTTMI_OK;
         hipError_t e = hipSetDevice(ctx->device);

@@ -93,6 +93,10 @@ def main():
         "refine1_seeds2": P.make_options(refine_s3tc=1, seed_points=2),
         "refine3": P.make_options(refine_s3tc=3),
         "weights": P.make_options(weights=(0.5, 1.0, 0.25, 2.0)),
+        # S3TC_Exhaustive: Flags::Better (with S3TC_Paranoid), and without the paranoid error metric
+        "better": P.make_options(flags=P.FLAGS_BETTER),
+        "exhaustive_plain": P.make_options(flags=P.FLAG_S3TC_EXHAUSTIVE | P.FLAG_UNIFORM),
+        "exhaustive_weights": P.make_options(flags=P.FLAG_S3TC_EXHAUSTIVE, weights=(0.5, 1.0, 0.25, 2.0), threshold=0.3),
     }.items():
         b1["opt_" + name] = o
         b1["out_" + name] = ref.encode_bc1(bc1_blocks, o)
@@ -107,6 +111,8 @@ def main():
         "default": P.make_options(),
         "uniform_seeds2_refine1": P.make_options(flags=P.FLAGS_DEFAULT | P.FLAG_UNIFORM, seed_points=2, refine_iic=1, refine_s3tc=1),
         "refine3_seeds3": P.make_options(refine_iic=3, seed_points=3),
+        "better": P.make_options(flags=P.FLAGS_BETTER),
+        "exhaustive_plain": P.make_options(flags=P.FLAG_S3TC_EXHAUSTIVE | P.FLAG_UNIFORM),
     }.items():
         s3["opt_" + name] = o
         for fmt, tag in ((2, "bc2"), (3, "bc3"), (4, "bc4u"), (5, "bc4s"), (6, "bc5u"), (7, "bc5s")):

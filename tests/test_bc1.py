@@ -10,7 +10,8 @@ import content
 from oracle import pyref
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-NAMES = ["default", "plain", "uniform", "threshold09", "threshold0", "refine1_seeds2", "refine3", "weights"]
+NAMES = ["default", "plain", "uniform", "threshold09", "threshold0", "refine1_seeds2", "refine3", "weights",
+         "better", "exhaustive_plain", "exhaustive_weights"]  # the last three: S3TC_Exhaustive
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -37,9 +38,23 @@ def test_oracle_vs_reference(oracle_lib, ref_lib):
         assert (oracle_lib.encode_bc1(blocks, opt, ref_lib.probe_rcp(), 4) == ref_lib.encode_bc1(blocks, opt)).all()
 
 
-def test_oracle_rejects_exhaustive(oracle_lib):
-    with pytest.raises(RuntimeError):
-        oracle_lib.encode_bc1(np.zeros((8, 16, 4), np.uint8), pyref.make_options(flags=pyref.FLAGS_BETTER))
+def test_oracle_exhaustive_vs_reference(oracle_lib, ref_lib):
+    """S3TC_Exhaustive (Flags::Better): sorted-cluster enumeration + single-colour tables, incl. the group-coupled
+    TestCounts escape (groups mixing transparent and opaque blocks under the alpha test)"""
+    blocks = np.concatenate([content.mixed_ldr_blocks(1357, 10), content.alpha_structure_blocks(12, 96)])
+    for opt in (pyref.make_options(flags=pyref.FLAGS_BETTER), pyref.make_options(flags=pyref.FLAG_S3TC_EXHAUSTIVE, threshold=0.7)):
+        assert (oracle_lib.encode_bc1(blocks, opt, ref_lib.probe_rcp(), 4) == ref_lib.encode_bc1(blocks, opt)).all()
+
+
+def test_single_colour_tables_follow_the_rule():
+    """oracle/cvtt_oracle_s3tcsc.h and csrc/s3tc_sc_tables.h are what tools/gen_s3tc_single_color.py emits"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_s3sc", os.path.join(root, "tools", "gen_s3tc_single_color.py"))
+    sc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sc)
+    for target, text in sc.render().items():
+        assert open(os.path.join(root, target)).read() == text, target
 
 
 # ------------------------------------------------------------------ GPU
@@ -72,8 +87,22 @@ def test_gpu_config1_and_device_path(gpu_ctx, oracle_lib):
     assert (out == exp).all()
     for n in (8, 72):  # ragged tails of a 64-block wave
         assert (gpu_ctx.encode_bc1(big[:n].copy(), api.Options()) == exp[:n]).all()
-    with pytest.raises(api.CvttError):
-        gpu_ctx.encode_bc1(big[:8].copy(), api.Options(flags=api.Flags.Better))
+
+
+@pytest.mark.gpu
+def test_gpu_exhaustive_vs_oracle(gpu_ctx, oracle_lib):
+    """Flags::Better / S3TC_Exhaustive on the device: ~1100 end-point pairs per block"""
+    import torch
+    from convectionkernels_amd import api
+    rcp = oracle_lib.probe_rcp()
+    gpu_ctx.set_rcp_table(rcp)
+    blocks = np.concatenate([content.config_blocks(3, 256, 256), content.alpha_structure_blocks(77, 1024), content.mixed_ldr_blocks(15, 24)])
+    for flags, thr in ((pyref.FLAGS_BETTER, 0.5), (pyref.FLAG_S3TC_EXHAUSTIVE | pyref.FLAG_UNIFORM, 0.25)):
+        exp = oracle_lib.encode_bc1(blocks, pyref.make_options(flags=flags, threshold=thr), rcp, threads=8)
+        out = gpu_ctx.encode_bc1(torch.from_numpy(blocks).cuda(), api.Options(flags=flags, threshold=thr)).cpu().numpy()
+        bad = np.nonzero((out != exp).any(axis=1))[0]
+        assert bad.size == 0, bad[:8]
+        assert (gpu_ctx.encode_bc1(blocks[:72].copy(), api.Options(flags=flags, threshold=thr)) == exp[:72]).all()
 
 
 @pytest.mark.gpu

@@ -10,7 +10,7 @@ from oracle import pyref
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 FORMATS = ((2, "bc2"), (3, "bc3"), (4, "bc4u"), (5, "bc4s"), (6, "bc5u"), (7, "bc5s"))
-VARIANTS = ("default", "uniform_seeds2_refine1", "refine3_seeds3")
+VARIANTS = ("default", "uniform_seeds2_refine1", "refine3_seeds3", "better", "exhaustive_plain")
 
 
 @pytest.mark.parametrize("name", VARIANTS)
@@ -65,5 +65,7 @@ def test_gpu_vs_oracle_and_device_path(gpu_ctx, oracle_lib):
         out = _gpu_encode(gpu_ctx, fmt, t, api.Options()).cpu().numpy()
         bad = np.nonzero((out != exp).any(axis=1))[0]
         assert bad.size == 0, (tag, bad[:8])
-    with pytest.raises(api.CvttError):
-        gpu_ctx.encode_bc3(blocks[:8].copy(), api.Options(flags=api.Flags.Better))  # S3TC_Exhaustive
+    for fmt, tag in FORMATS[:2]:  # Flags::Better only changes the colour half of BC2 / BC3
+        exp = oracle_lib.encode_s3tc(blocks[:4096], pyref.make_options(flags=pyref.FLAGS_BETTER), fmt, rcp, threads=8)
+        out = _gpu_encode(gpu_ctx, fmt, t[:4096], api.Options(flags=api.Flags.Better)).cpu().numpy()
+        assert (out == exp).all(), tag

@@ -44,6 +44,7 @@ def main():
         print("%-20s %5d entries  %s" % (name, len(ref), "OK" if ok else "MISMATCH"))
         bad += not ok
     bad += check_single_colour()
+    bad += check_s3tc_single_colour()
     return bad
 
 
@@ -73,6 +74,25 @@ def check_single_colour():
         if not ok:
             print("single-colour table %s MISMATCH" % n)
     print("%-20s %5d tables   %s" % ("BC7 single colour", len(names), "OK" if not bad else "MISMATCH"))
+    return bad
+
+
+def check_s3tc_single_colour():
+    """BC1-family single-colour tables (ConvectionKernels_S3TC_SingleColor.h) vs tools/gen_s3tc_single_color.py"""
+    import gen_s3tc_single_color as SC
+    txt = open("/root/reference/ConvectionKernels_S3TC_SingleColor.h").read()
+    names = ["g_singleColor5_3", "g_singleColor6_3", "g_singleColor5_2", "g_singleColor6_2",
+             "g_singleColor5_3_p", "g_singleColor6_3_p", "g_singleColor5_2_p", "g_singleColor6_2_p"]
+    bad = 0
+    for n, ours in zip(names, SC.build()):
+        m = re.search(r"\b%s\[256\]\s*=\s*\{(.*?)\};" % n, txt, re.S)
+        nums = [int(x) for x in re.findall(r"\d+", m.group(1))]
+        ref = [tuple(nums[i:i + 4]) for i in range(0, 1024, 4)]
+        ok = ref == ours
+        bad += not ok
+        if not ok:
+            print("S3TC single-colour table %s MISMATCH" % n)
+    print("%-20s %5d tables   %s" % ("S3TC single colour", len(names), "OK" if not bad else "MISMATCH"))
     return bad
 
 
