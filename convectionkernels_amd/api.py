@@ -136,8 +136,37 @@ class BC7EncodingPlan(ctypes.Structure):
         return o
 
 
+class BC7FineTuningParams(ctypes.Structure):
+    """cvtt::BC7FineTuningParams (285 bytes): seed points (0 = off) per mode and partition / rotation / index selector;
+    default = 4 everywhere."""
+    _fields_ = [
+        ("mode0SP", ctypes.c_uint8 * 16),
+        ("mode1SP", ctypes.c_uint8 * 64),
+        ("mode2SP", ctypes.c_uint8 * 64),
+        ("mode3SP", ctypes.c_uint8 * 64),
+        ("mode4SP", (ctypes.c_uint8 * 2) * 4),
+        ("mode5SP", ctypes.c_uint8 * 4),
+        ("mode6SP", ctypes.c_uint8),
+        ("mode7SP", ctypes.c_uint8 * 64),
+    ]
+
+    def __init__(self):
+        super().__init__()
+        ctypes.memset(ctypes.addressof(self), 4, ctypes.sizeof(self))
+
+    def tobytes(self):
+        return bytes(self)
+
+    @classmethod
+    def frombytes(cls, b):
+        o = cls()
+        ctypes.memmove(ctypes.addressof(o), bytes(b), ctypes.sizeof(cls))
+        return o
+
+
 assert ctypes.sizeof(Options) == 44
 assert ctypes.sizeof(BC7EncodingPlan) == 808
+assert ctypes.sizeof(BC7FineTuningParams) == 285
 
 
 class CvttError(RuntimeError):
@@ -158,6 +187,7 @@ _EXPORTS = (
     "cvttmi_encode_bc2_device", "cvttmi_encode_bc3_device", "cvttmi_encode_bc4_device", "cvttmi_encode_bc5_device",
     "cvttmi_encode_bc2", "cvttmi_encode_bc3", "cvttmi_encode_bc4", "cvttmi_encode_bc5",
     "cvttmi_decode_bc7_device", "cvttmi_decode_bc7", "cvttmi_decode_bc6h_device", "cvttmi_decode_bc6h",
+    "cvttmi_default_bc7_fine_tuning", "cvttmi_bc7_plan_from_quality", "cvttmi_bc7_plan_from_fine_tuning",
 )
 
 _lib = None
@@ -219,6 +249,9 @@ def load_library():
     lib.cvttmi_decode_bc6h.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     lib.cvttmi_selftest_arith.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
                                           ctypes.POINTER(ctypes.c_uint64)]
+    lib.cvttmi_bc7_plan_from_quality.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.cvttmi_bc7_plan_from_fine_tuning.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.cvttmi_default_bc7_fine_tuning.argtypes = [ctypes.c_void_p]
     lib.cvttmi_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_set_exhaustive.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_timing_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
@@ -522,6 +555,21 @@ def default_context(device=0):
 
 
 # ---- cvtt::Kernels-style free functions (8-block call convention of the reference) ----
+def ConfigureBC7EncodingPlanFromQuality(encodingPlan, quality):
+    """cvtt::Kernels::ConfigureBC7EncodingPlanFromQuality (BC67.cpp:3291-3352): fills `encodingPlan` in place for quality
+    1..100 (clamped).  Host-side; needs no device."""
+    if load_library().cvttmi_bc7_plan_from_quality(ctypes.byref(encodingPlan), int(quality)) != 0:
+        raise CvttError("cvttmi_bc7_plan_from_quality failed")
+    return encodingPlan
+
+
+def ConfigureBC7EncodingPlanFromFineTuningParams(encodingPlan, params):
+    """cvtt::Kernels::ConfigureBC7EncodingPlanFromFineTuningParams (BC67.cpp:3355-3483); returns True like the reference."""
+    if load_library().cvttmi_bc7_plan_from_fine_tuning(ctypes.byref(encodingPlan), ctypes.byref(params)) != 0:
+        raise CvttError("cvttmi_bc7_plan_from_fine_tuning failed")
+    return True
+
+
 def EncodeBC7(pBlocks, options=None, encodingPlan=None, device=0):
     """cvtt::Kernels::EncodeBC7 (reference ConvectionKernels_API.cpp:41-54): any multiple of
     NumParallelBlocks blocks; returns the packed 16-byte blocks."""

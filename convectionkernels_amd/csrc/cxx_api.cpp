@@ -13,6 +13,7 @@
 
 static_assert(sizeof(cvtt::Options) == sizeof(cvttmi_options), "cvtt::Options layout");
 static_assert(sizeof(cvtt::BC7EncodingPlan) == sizeof(cvttmi_bc7_plan), "cvtt::BC7EncodingPlan layout");
+static_assert(sizeof(cvtt::BC7FineTuningParams) == sizeof(cvttmi_bc7_fine_tuning), "cvtt::BC7FineTuningParams layout");
 static_assert(sizeof(cvtt::PixelBlockU8) == 64 && sizeof(cvtt::PixelBlockF16) == 128, "pixel block layout");
 
 namespace
@@ -62,10 +63,26 @@ cvtt::BC7EncodingPlan::BC7EncodingPlan()
     cvttmi_default_bc7_plan(reinterpret_cast<cvttmi_bc7_plan *>(this));
 }
 
+cvtt::BC7FineTuningParams::BC7FineTuningParams()
+{
+    cvttmi_default_bc7_fine_tuning(reinterpret_cast<cvttmi_bc7_fine_tuning *>(this));
+}
+
 namespace cvtt
 {
     namespace Kernels
     {
+        void ConfigureBC7EncodingPlanFromQuality(BC7EncodingPlan &encodingPlan, int quality)
+        {
+            cvttmi_bc7_plan_from_quality(reinterpret_cast<cvttmi_bc7_plan *>(&encodingPlan), quality);
+        }
+
+        bool ConfigureBC7EncodingPlanFromFineTuningParams(BC7EncodingPlan &encodingPlan, const BC7FineTuningParams &params)
+        {
+            cvttmi_bc7_plan_from_fine_tuning(reinterpret_cast<cvttmi_bc7_plan *>(&encodingPlan), reinterpret_cast<const cvttmi_bc7_fine_tuning *>(&params));
+            return true; // like the reference (BC67.cpp:3482)
+        }
+
         void EncodeBC7Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options, const BC7EncodingPlan &plan)
         {
             std::lock_guard<std::mutex> g(g_lock);

@@ -19,6 +19,7 @@
 #include "cvtt_device.h"
 #include "bc7_tables.h"
 #include "s3tc_sc_tables.h"
+#include "bc7_quality_events.h"
 #include "bc6h_layout.h"
 #include "etc_tables.h"
 
@@ -311,6 +312,110 @@ extern "C"
             p->rgbaShapeList[i] = static_cast<uint8_t>(i);
         p->rgbNumShapesToEvaluate = 243;
         p->rgbaNumShapesToEvaluate = 129;
+    }
+
+    void cvttmi_default_bc7_fine_tuning(cvttmi_bc7_fine_tuning *p)
+    {
+        memset(p, 4, sizeof(*p)); // cvtt::BC7FineTuningParams(), ConvectionKernels.h:117-139: four seed points everywhere
+    }
+
+    // Shape lists, counts and the mode-7 RGB mask follow from the enables and per-shape seed points
+    // (tail of ConfigureBC7EncodingPlanFromFineTuningParams, ConvectionKernels_BC67.cpp:3460-3480).
+    static void finishPlan(cvttmi_bc7_plan *plan)
+    {
+        plan->rgbNumShapesToEvaluate = plan->rgbaNumShapesToEvaluate = 0;
+        memset(plan->rgbShapeList, 0, sizeof(plan->rgbShapeList));
+        memset(plan->rgbaShapeList, 0, sizeof(plan->rgbaShapeList));
+        for (int shape = 0; shape < 243; shape++)
+            if (plan->seedPointsForShapeRGB[shape])
+                plan->rgbShapeList[plan->rgbNumShapesToEvaluate++] = static_cast<uint8_t>(shape);
+        for (int shape = 0; shape < 129; shape++)
+            if (plan->seedPointsForShapeRGBA[shape])
+                plan->rgbaShapeList[plan->rgbaNumShapesToEvaluate++] = static_cast<uint8_t>(shape);
+        plan->mode7RGBPartitionEnabled = plan->mode7RGBAPartitionEnabled & ~plan->mode3PartitionEnabled;
+    }
+
+    int cvttmi_bc7_plan_from_fine_tuning(cvttmi_bc7_plan *plan, const cvttmi_bc7_fine_tuning *params)
+    {
+        if (!plan || !params)
+            return CVTTMI_E_INVALID;
+        memset(plan, 0, sizeof(*plan));
+        // one row per partitioned mode: seed points per partition, number of partitions, subsets, where the enable bit
+        // and the per-shape seed points live (modes 0-3 feed the RGB shape set, mode 7 the RGBA set)
+        uint64_t m0 = 0;
+        const struct
+        {
+            const uint8_t *sp;
+            int numPartitions, numSubsets;
+            uint64_t *enable;
+            uint8_t *shapeSeeds;
+        } rows[5] = {
+            {params->mode0SP, 16, 3, &m0, plan->seedPointsForShapeRGB},
+            {params->mode1SP, 64, 2, &plan->mode1PartitionEnabled, plan->seedPointsForShapeRGB},
+            {params->mode2SP, 64, 3, &plan->mode2PartitionEnabled, plan->seedPointsForShapeRGB},
+            {params->mode3SP, 64, 2, &plan->mode3PartitionEnabled, plan->seedPointsForShapeRGB},
+            {params->mode7SP, 64, 2, &plan->mode7RGBAPartitionEnabled, plan->seedPointsForShapeRGBA},
+        };
+        for (const auto &row : rows)
+            for (int partition = 0; partition < row.numPartitions; partition++)
+            {
+                const uint8_t sp = row.sp[partition];
+                if (!sp)
+                    continue;
+                *row.enable |= 1ull << partition;
+                for (int subset = 0; subset < row.numSubsets; subset++)
+                {
+                    const int shape = (row.numSubsets == 3) ? k_shapes3[partition * 3 + subset] : k_shapes2[partition * 2 + subset];
+                    if (row.shapeSeeds[shape] < sp)
+                        row.shapeSeeds[shape] = sp;
+                }
+            }
+        plan->mode0PartitionEnabled = static_cast<uint16_t>(m0);
+        memcpy(plan->mode4SP, params->mode4SP, sizeof(plan->mode4SP));
+        memcpy(plan->mode5SP, params->mode5SP, sizeof(plan->mode5SP));
+        if (params->mode6SP)
+        {
+            plan->mode6Enabled = 1;
+            if (plan->seedPointsForShapeRGBA[0] < params->mode6SP) // the whole block is shape 0
+                plan->seedPointsForShapeRGBA[0] = params->mode6SP;
+        }
+        finishPlan(plan);
+        return CVTTMI_OK;
+    }
+
+    int cvttmi_bc7_plan_from_quality(cvttmi_bc7_plan *plan, int quality)
+    {
+        if (!plan)
+            return CVTTMI_E_INVALID;
+        quality = quality < 1 ? 1 : quality > 100 ? 100 : quality; // BC67.cpp:3295-3298
+        memset(plan, 0, sizeof(*plan));
+        uint64_t *masks[5] = {NULL, &plan->mode1PartitionEnabled, &plan->mode2PartitionEnabled, &plan->mode3PartitionEnabled,
+                              &plan->mode7RGBAPartitionEnabled};
+        uint64_t m0 = 0;
+        masks[0] = &m0;
+        for (int i = 0; i < CVTT_BC7_NUM_QUALITY_EVENTS; i++)
+        {
+            const unsigned e = k_bc7QualityEvents[i];
+            if (static_cast<int>(e >> 24) > quality)
+                break;
+            const unsigned kind = (e >> 16) & 255u, index = (e >> 8) & 255u;
+            const uint8_t value = static_cast<uint8_t>(e & 255u);
+            if (kind < 5)
+                *masks[kind] = (*masks[kind] & ~(1ull << index)) | (static_cast<uint64_t>(value & 1u) << index);
+            else if (kind == 5)
+                plan->mode4SP[index >> 1][index & 1] = value;
+            else if (kind == 6)
+                plan->mode5SP[index] = value;
+            else if (kind == 7)
+                plan->mode6Enabled = value;
+            else if (kind == 8)
+                plan->seedPointsForShapeRGB[index] = value;
+            else
+                plan->seedPointsForShapeRGBA[index] = value;
+        }
+        plan->mode0PartitionEnabled = static_cast<uint16_t>(m0);
+        finishPlan(plan);
+        return CVTTMI_OK;
     }
 
     int cvttmi_create(cvttmi_context **out, int device)

@@ -9,9 +9,7 @@
 // blocks is only there for compatibility; throughput comes from the *Batch overloads below (or
 // the C ABI directly), which take any multiple of 8 blocks.
 //
-// Not provided (outside the hot path): ETC1, punch-through ETC2
-// and the ConfigureBC7EncodingPlan* helpers (plans produced by the
-// reference can be passed as they are).
+// Not provided (outside the hot path): ETC1 and punch-through ETC2.
 //
 // Error behaviour: the reference's functions return void and assert.  These abort() with a
 // message on stderr when no gfx950 device is present or a call fails -- there is no CPU path.
@@ -56,6 +54,20 @@ namespace cvtt
         int refineRoundsBC7, refineRoundsBC6H, refineRoundsIIC, refineRoundsS3TC;
         int seedPoints;
         Options(); // Default flags, threshold 0.5, Rec.709-derived weights, 2/3/8/2 refine rounds, 4 seed points
+    };
+
+    struct BC7FineTuningParams
+    {
+        // seed points (0 = off) per mode and partition / rotation / index selector
+        uint8_t mode0SP[16];
+        uint8_t mode1SP[64];
+        uint8_t mode2SP[64];
+        uint8_t mode3SP[64];
+        uint8_t mode4SP[4][2];
+        uint8_t mode5SP[4];
+        uint8_t mode6SP;
+        uint8_t mode7SP[64];
+        BC7FineTuningParams(); // four seed points everywhere
     };
 
     struct BC7EncodingPlan
@@ -110,6 +122,10 @@ namespace cvtt
         void DecodeBC7(PixelBlockU8 *pBlocks, const uint8_t *pBC);
         void DecodeBC6HU(PixelBlockF16 *pBlocks, const uint8_t *pBC);
         void DecodeBC6HS(PixelBlockF16 *pBlocks, const uint8_t *pBC);
+
+        // quality 1..100 (clamped); byte-identical plans to the reference's.  Host-side, need no device.
+        void ConfigureBC7EncodingPlanFromQuality(BC7EncodingPlan &encodingPlan, int quality);
+        bool ConfigureBC7EncodingPlanFromFineTuningParams(BC7EncodingPlan &encodingPlan, const BC7FineTuningParams &params);
 
         ETC2CompressionData *AllocETC2Data(allocFunc_t allocFunc, void *context, const Options &options);
         void ReleaseETC2Data(ETC2CompressionData *compressionData, freeFunc_t freeFunc);

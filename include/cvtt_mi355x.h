@@ -87,11 +87,33 @@ typedef struct cvttmi_bc7_plan
     uint8_t rgbNumShapesToEvaluate;
 } cvttmi_bc7_plan;
 
+/* byte image of cvtt::BC7FineTuningParams, ConvectionKernels.h:105-140: seed points (0 = off) per mode and
+ * partition / rotation / index selector */
+typedef struct cvttmi_bc7_fine_tuning
+{
+    uint8_t mode0SP[16];
+    uint8_t mode1SP[64];
+    uint8_t mode2SP[64];
+    uint8_t mode3SP[64];
+    uint8_t mode4SP[4][2];
+    uint8_t mode5SP[4];
+    uint8_t mode6SP;
+    uint8_t mode7SP[64];
+} cvttmi_bc7_fine_tuning;
+
 typedef struct cvttmi_context cvttmi_context;
 
 /* Default-constructed PODs (cvtt::Options(), cvtt::BC7EncodingPlan()). */
 void cvttmi_default_options(cvttmi_options *out);
 void cvttmi_default_bc7_plan(cvttmi_bc7_plan *out);
+void cvttmi_default_bc7_fine_tuning(cvttmi_bc7_fine_tuning *out);
+
+/* replace cvtt::Kernels::ConfigureBC7EncodingPlanFromQuality (ConvectionKernels_BC67.cpp:3291-3352; quality is
+ * clamped to 1..100) and ConfigureBC7EncodingPlanFromFineTuningParams (BC67.cpp:3355-3483).  Host-side, once per job;
+ * need no device.  The quality ladder is the reference's empirical ranking, carried as the observed plan changes per
+ * quality step (csrc/bc7_quality_events.h, tools/gen_bc7_quality_events.py); plans are byte-identical to the reference's. */
+int cvttmi_bc7_plan_from_quality(cvttmi_bc7_plan *plan, int quality);
+int cvttmi_bc7_plan_from_fine_tuning(cvttmi_bc7_plan *plan, const cvttmi_bc7_fine_tuning *params);
 
 /* Create a context on HIP device `device`: uploads the constant tables to HBM and
  * probes the host's RCPPS table (the reference's EndpointRefiner uses _mm_rcp_ps,

@@ -79,6 +79,16 @@ def main():
     arrays["names"] = np.array(names)
     np.savez_compressed(os.path.join(HERE, "bc7_mixed.npz"), **arrays)
 
+    # ---- BC7 plan configuration: every quality, and random fine-tuning parameter sets ----
+    rngp = np.random.Generator(np.random.PCG64(4242))
+    fts = rngp.integers(0, 5, (48, pyref.SIZEOF_BC7_FINETUNE)).astype(np.uint8)
+    fts[::3][rngp.random((16, pyref.SIZEOF_BC7_FINETUNE)) < 0.7] = 0
+    fts[0] = 0
+    fts[1] = 4
+    np.savez_compressed(os.path.join(HERE, "bc7_plans.npz"),
+                        quality=np.stack([ref.plan_from_quality(q) for q in range(1, 101)]),
+                        finetune=fts, finetune_plans=np.stack([ref.plan_from_finetune(f) for f in fts]))
+
     # ---- BC1: mixed content + config 1 image x option variants ----
     P = pyref
     bc1_blocks = np.concatenate([content.mixed_ldr_blocks(777, 24), content.config_blocks(1, 64, 64)])
