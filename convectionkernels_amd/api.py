@@ -187,6 +187,7 @@ _EXPORTS = (
     "cvttmi_encode_bc2_device", "cvttmi_encode_bc3_device", "cvttmi_encode_bc4_device", "cvttmi_encode_bc5_device",
     "cvttmi_encode_bc2", "cvttmi_encode_bc3", "cvttmi_encode_bc4", "cvttmi_encode_bc5",
     "cvttmi_decode_bc7_device", "cvttmi_decode_bc7", "cvttmi_decode_bc6h_device", "cvttmi_decode_bc6h",
+    "cvttmi_encode_etc1_device", "cvttmi_encode_etc1",
     "cvttmi_default_bc7_fine_tuning", "cvttmi_bc7_plan_from_quality", "cvttmi_bc7_plan_from_fine_tuning",
 )
 
@@ -223,7 +224,7 @@ def load_library():
                                               ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     lib.cvttmi_encode_bc6h.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                        ctypes.c_void_p, ctypes.c_int]
-    for n in ("cvttmi_encode_etc2", "cvttmi_encode_etc2_rgba", "cvttmi_encode_etc2_alpha"):
+    for n in ("cvttmi_encode_etc2", "cvttmi_encode_etc2_rgba", "cvttmi_encode_etc2_alpha", "cvttmi_encode_etc1"):
         getattr(lib, n).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         getattr(lib, n + "_device").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                                  ctypes.c_void_p, ctypes.c_void_p]
@@ -416,7 +417,12 @@ class Context:
         return self._encode_simple(host, dev, "encode_bc6h", blocks, options, out, stream, 128, 16)
 
 
-    # -- ETC2 --
+    # -- ETC1 / ETC2 --
+    def encode_etc1(self, blocks, options=None, out=None, stream=None):
+        """Batched cvtt::Kernels::EncodeETC1: (N,16,4) uint8 -> (N,8) uint8."""
+        return self._encode_simple(self._lib.cvttmi_encode_etc1, self._lib.cvttmi_encode_etc1_device, "encode_etc1",
+                                   blocks, options, out, stream, 64, 8)
+
     def encode_etc2(self, blocks, options=None, out=None, stream=None):
         """Batched cvtt::Kernels::EncodeETC2 (RGB): (N,16,4) uint8 -> (N,8) uint8."""
         return self._encode_simple(self._lib.cvttmi_encode_etc2, self._lib.cvttmi_encode_etc2_device, "encode_etc2",
@@ -632,6 +638,12 @@ def EncodeBC6HU(pBlocks, options=None, device=0):
 def EncodeBC6HS(pBlocks, options=None, device=0):
     """cvtt::Kernels::EncodeBC6HS (reference ConvectionKernels_API.cpp:71-84)."""
     return default_context(device).encode_bc6h(pBlocks, options, signed=True)
+
+
+def EncodeETC1(pBlocks, options=None, compressionData=None, device=0):
+    """cvtt::Kernels::EncodeETC1 (reference ConvectionKernels_API.cpp:201-214); the ETC1CompressionData scratch
+    argument is accepted and ignored."""
+    return default_context(device).encode_etc1(pBlocks, options)
 
 
 def EncodeETC2(pBlocks, options=None, compressionData=None, device=0):

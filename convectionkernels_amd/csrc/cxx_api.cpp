@@ -51,6 +51,10 @@ namespace
     {
         void *context;
     };
+    struct Etc1Marker : public cvtt::ETC1CompressionData
+    {
+        void *context;
+    };
 }
 
 cvtt::Options::Options()
@@ -119,6 +123,11 @@ namespace cvtt
             std::lock_guard<std::mutex> g(g_lock);
             check(cvttmi_encode_bc6h(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), 1), "EncodeBC6HS");
         }
+        void EncodeETC1Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
+        {
+            std::lock_guard<std::mutex> g(g_lock);
+            check(cvttmi_encode_etc1(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeETC1");
+        }
         void EncodeETC2Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
         {
             std::lock_guard<std::mutex> g(g_lock);
@@ -168,6 +177,7 @@ namespace cvtt
         void EncodeBC1(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options) { EncodeBC1Batch(pBC, pBlocks, NumParallelBlocks, options); }
         void EncodeBC6HU(uint8_t *pBC, const PixelBlockF16 *pBlocks, const Options &options) { EncodeBC6HUBatch(pBC, pBlocks, NumParallelBlocks, options); }
         void EncodeBC6HS(uint8_t *pBC, const PixelBlockF16 *pBlocks, const Options &options) { EncodeBC6HSBatch(pBC, pBlocks, NumParallelBlocks, options); }
+        void EncodeETC1(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC1CompressionData *) { EncodeETC1Batch(pBC, pBlocks, NumParallelBlocks, options); }
         void EncodeETC2(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC2CompressionData *) { EncodeETC2Batch(pBC, pBlocks, NumParallelBlocks, options); }
         void EncodeETC2RGBA(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC2CompressionData *) { EncodeETC2RGBABatch(pBC, pBlocks, NumParallelBlocks, options); }
         void EncodeETC2Alpha(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options) { EncodeETC2AlphaBatch(pBC, pBlocks, NumParallelBlocks, options); }
@@ -188,6 +198,21 @@ namespace cvtt
             Etc2Marker *m = static_cast<Etc2Marker *>(data);
             void *ctx = m->context;
             freeFunc(ctx, data, sizeof(Etc2Marker));
+        }
+        ETC1CompressionData *AllocETC1Data(allocFunc_t allocFunc, void *ctx) // ETC.cpp:3083-3098
+        {
+            void *buffer = allocFunc(ctx, sizeof(Etc1Marker));
+            if (!buffer)
+                return NULL;
+            Etc1Marker *m = new (buffer) Etc1Marker();
+            m->context = ctx;
+            return m;
+        }
+        void ReleaseETC1Data(ETC1CompressionData *data, freeFunc_t freeFunc)
+        {
+            Etc1Marker *m = static_cast<Etc1Marker *>(data);
+            void *ctx = m->context;
+            freeFunc(ctx, data, sizeof(Etc1Marker));
         }
     }
 }

@@ -141,6 +141,7 @@ __device__ __forceinline__ void emitT(u32 &hi, u32 &lo, const int (&lineColor)[3
 } // namespace
 
 // ------------------------------------------------------------------------------------------
+template <bool ETC1>
 __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
                                                                const CvttEtcArgs A, const CvttDeviceTables *__restrict__ T)
 {
@@ -176,6 +177,8 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
 #define DBG_TAP(i) do {} while (0)
 #endif
 
+    if (!ETC1) // EncodeETC1 is the cluster fit alone (CompressETC1Block, ETC.cpp:2116-2126)
+    {
     // =================================== planar ===================================
     {
         // closed-form least squares per channel (lanes 0..2), ETC.cpp:1291-1413
@@ -732,14 +735,18 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
     }
 
     DBG_TAP(3);
-    // ====================== ETC1 differential cluster fit (d = 1 only) ======================
+    } // !ETC1
+    // ====================== ETC1 cluster fit ======================
+    // ETC2 reaches it through CompressETC2Block, which asks for the differential mode only (d = 1, ETC.cpp:1862);
+    // EncodeETC1 also tries the individual 4:4:4 + 4:4:4 mode (d = 0) of each flip first
     {
         bool etcBest = false;
-        int bFlip = 0;
+        int bFlip = 0, bD = 1;
         u32 bPacked0 = 0, bPacked1 = 0; // selectors | colour << 16
         int bTable0 = 0, bTable1 = 0;
 
         for (int flip = 0; flip < 2; flip++)
+        for (int d = ETC1 ? 0 : 1; d < 2; d++)
         {
             // half-block membership: flip 0 = left/right 2x4 columns, flip 1 = top/bottom (g_flipTables, ETC.cpp:47-57)
             // pixel list of (flip, sector): computed on the fly
@@ -771,7 +778,8 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
                     {
                         int cu = (int)(short)(cumulative[ch] + off);
                         cu = cu < 0 ? 0 : (cu > 2040 ? 2040 : cu);
-                        const u32 q = ((((u32)cu << 5) - (u32)cu + ((u32)cu >> 3) + 1024u) & 0xffffu) >> 11;
+                        const u32 q = d == 1 ? ((((u32)cu << 5) - (u32)cu + ((u32)cu >> 3) + 1024u) & 0xffffu) >> 11
+                                             : ((((u32)cu << 5) - ((u32)cu << 1) + ((u32)cu >> 3) + 2048u) & 0xffffu) >> 12;
                         packed |= (int)q << (ch * 5);
                     }
                     if (n == 0 || packed != last)
@@ -808,7 +816,7 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
                     for (int ch = 0; ch < 3; ch++)
                     {
                         const int q = (packed >> (ch * 5)) & 31;
-                        const int u = (q << 3) | (q >> 2);
+                        const int u = d == 1 ? ((q << 3) | (q >> 2)) : ((q << 4) | q);
 #pragma unroll
                         for (int s = 0; s < 4; s++)
                         {
@@ -894,11 +902,12 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
             if (m0 + m1 < blockBest0)
             {
                 const u32 p0 = colorOf(0, i0) << 16, p1 = colorOf(1, i1) << 16;
-                if (legal(p0 >> 16, p1 >> 16))
+                if (d == 0 || legal(p0 >> 16, p1 >> 16)) // individual mode: the halves are unconstrained (ETC.cpp:2831-2851)
                 {
                     etcBest = true;
                     bestError = m0 + m1;
                     bFlip = flip;
+                    bD = d;
                     bPacked0 = p0;
                     bPacked1 = p1;
                     bTable0 = tableOf(0, i0);
@@ -958,6 +967,7 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
                             etcBest = true;
                             bestError = blockBest;
                             bFlip = flip;
+                            bD = 1;
                             bPacked0 = c0 << 16;
                             bPacked1 = colorOf(1, pI) << 16;
                             bTable0 = tableOf(0, nI);
@@ -987,7 +997,7 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
                     for (int ch = 0; ch < 3; ch++)
                     {
                         const int q = (int)((colr >> (ch * 5)) & 31u);
-                        const int v = ((q << 3) | (q >> 2)) + T->etc1Modifiers[table][sel];
+                        const int v = (bD == 1 ? ((q << 3) | (q >> 2)) : ((q << 4) | q)) + T->etc1Modifiers[table][sel];
                         m[ch] = v < 0 ? 0 : (v > 255 ? 255 : v);
                     }
                     const float e = E(m[0], m[1], m[2], S.pix[px], S.pw[px]);
@@ -1006,7 +1016,7 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
                 bPacked0 = (bPacked0 & 0xffff0000u) | sel0;
                 bPacked1 = (bPacked1 & 0xffff0000u) | sel1;
             }
-            // EmitETC1Block, ETC.cpp:2565-2622 (differential, opaque)
+            // EmitETC1Block, ETC.cpp:2565-2622 (opaque)
             const u32 col0 = bPacked0 >> 16, col1 = bPacked1 >> 16;
             int colors[2][3];
 #pragma unroll
@@ -1016,15 +1026,27 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
                 colors[1][ch] = (int)((col1 >> (ch * 5)) & 31u);
             }
             u32 hi = 0, lo = 0;
-            hi |= (u32)colors[0][0] << 27;
-            hi |= (u32)((colors[1][0] - colors[0][0]) & 7) << 24;
-            hi |= (u32)colors[0][1] << 19;
-            hi |= (u32)((colors[1][1] - colors[0][1]) & 7) << 16;
-            hi |= (u32)colors[0][2] << 11;
-            hi |= (u32)((colors[1][2] - colors[0][2]) & 7) << 8;
+            if (bD == 0)
+            {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    hi |= (u32)colors[0][ch] << (28 - 8 * ch);
+                    hi |= (u32)colors[1][ch] << (24 - 8 * ch);
+                }
+            }
+            else
+            {
+                hi |= (u32)colors[0][0] << 27;
+                hi |= (u32)((colors[1][0] - colors[0][0]) & 7) << 24;
+                hi |= (u32)colors[0][1] << 19;
+                hi |= (u32)((colors[1][1] - colors[0][1]) & 7) << 16;
+                hi |= (u32)colors[0][2] << 11;
+                hi |= (u32)((colors[1][2] - colors[0][2]) & 7) << 8;
+            }
             hi |= (u32)bTable0 << 5;
             hi |= (u32)bTable1 << 2;
-            hi |= 1u << 1;
+            hi |= (u32)bD << 1;
             hi |= (u32)bFlip;
             // selector -> modifier code {3, 2, 0, 1}, scattered through the flip table then column-major
             u32 codes = 0; // 2 bits per pixel position
@@ -1248,15 +1270,22 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
 extern "C" hipError_t cvttmi_launch_etc2(const void *d_blocks, void *d_out, const CvttEtcArgs *args,
                                          const CvttDeviceTables *d_tables, int mode, hipStream_t stream)
 {
-    // mode 0: RGB (8 B), 1: RGBA = [alpha | colour] (16 B), 2: alpha only (8 B)
+    // mode 0: RGB (8 B), 1: RGBA = [alpha | colour] (16 B), 2: alpha only (8 B), 3: ETC1 (8 B)
     if (args->numBlocks == 0)
         return hipSuccess;
     CvttEtcArgs a = *args;
     a.outStride = (mode == 1) ? 16u : 8u;
+    if (mode == 3)
+    {
+        a.outOffset = 0u;
+        hipLaunchKernelGGL(cvttmi_etc2_color_kernel<true>, dim3(a.numBlocks / 8u), dim3(512), 0, stream, (const uint8_t *)d_blocks,
+                           (uint8_t *)d_out, a, d_tables);
+        return hipGetLastError();
+    }
     if (mode != 2)
     {
         a.outOffset = (mode == 1) ? 8u : 0u;
-        hipLaunchKernelGGL(cvttmi_etc2_color_kernel, dim3(a.numBlocks / 8u), dim3(512), 0, stream, (const uint8_t *)d_blocks,
+        hipLaunchKernelGGL(cvttmi_etc2_color_kernel<false>, dim3(a.numBlocks / 8u), dim3(512), 0, stream, (const uint8_t *)d_blocks,
                            (uint8_t *)d_out, a, d_tables);
     }
     if (mode != 0)

@@ -844,6 +844,10 @@ extern "C"
     { return etc2Device(ctx, d_out, d_blocks, numBlocks, options, 1, hipStream); }
     int cvttmi_encode_etc2_alpha_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, void *hipStream)
     { return etc2Device(ctx, d_out, d_blocks, numBlocks, options, 2, hipStream); }
+    int cvttmi_encode_etc1_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, void *hipStream)
+    { return etc2Device(ctx, d_out, d_blocks, numBlocks, options, 3, hipStream); }
+    int cvttmi_encode_etc1(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options)
+    { return etc2Host(ctx, out, blocks, numBlocks, options, 3); }
     int cvttmi_encode_etc2(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options)
     { return etc2Host(ctx, out, blocks, numBlocks, options, 0); }
     int cvttmi_encode_etc2_rgba(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options)

@@ -9,7 +9,7 @@
 // blocks is only there for compatibility; throughput comes from the *Batch overloads below (or
 // the C ABI directly), which take any multiple of 8 blocks.
 //
-// Not provided (outside the hot path): ETC1 and punch-through ETC2.
+// Not provided (outside the hot path): punch-through ETC2.
 //
 // Error behaviour: the reference's functions return void and assert.  These abort() with a
 // message on stderr when no gfx950 device is present or a call fails -- there is no CPU path.
@@ -97,6 +97,7 @@ namespace cvtt
     // Kept so that AllocETC2Data / ReleaseETC2Data call sites compile: the GPU kernels hold their
     // scratch in LDS, so the object only remembers the allocator context.
     class ETC2CompressionData { protected: ETC2CompressionData() {} };
+    class ETC1CompressionData { protected: ETC1CompressionData() {} };
 
     namespace Kernels
     {
@@ -114,6 +115,7 @@ namespace cvtt
         void EncodeBC6HU(uint8_t *pBC, const PixelBlockF16 *pBlocks, const Options &options);
         void EncodeBC6HS(uint8_t *pBC, const PixelBlockF16 *pBlocks, const Options &options);
         void EncodeBC7(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, const BC7EncodingPlan &encodingPlan);
+        void EncodeETC1(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC1CompressionData *compressionData);
         void EncodeETC2(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC2CompressionData *compressionData);
         void EncodeETC2RGBA(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC2CompressionData *compressionData);
         void EncodeETC2Alpha(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options);
@@ -129,6 +131,8 @@ namespace cvtt
 
         ETC2CompressionData *AllocETC2Data(allocFunc_t allocFunc, void *context, const Options &options);
         void ReleaseETC2Data(ETC2CompressionData *compressionData, freeFunc_t freeFunc);
+        ETC1CompressionData *AllocETC1Data(allocFunc_t allocFunc, void *context);
+        void ReleaseETC1Data(ETC1CompressionData *compressionData, freeFunc_t freeFunc);
 
         // numBlocks (a multiple of NumParallelBlocks) blocks per call; group g = blocks [8g, 8g+8)
         void EncodeBC1Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options);
@@ -141,6 +145,7 @@ namespace cvtt
         void EncodeBC6HUBatch(uint8_t *pBC, const PixelBlockF16 *pBlocks, size_t numBlocks, const Options &options);
         void EncodeBC6HSBatch(uint8_t *pBC, const PixelBlockF16 *pBlocks, size_t numBlocks, const Options &options);
         void EncodeBC7Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options, const BC7EncodingPlan &encodingPlan);
+        void EncodeETC1Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options);
         void EncodeETC2Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options);
         void EncodeETC2RGBABatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options);
         void EncodeETC2AlphaBatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options);

@@ -167,6 +167,15 @@ int cvttmi_encode_etc2_rgba_device(cvttmi_context *ctx, void *d_out, const void 
 int cvttmi_encode_etc2_alpha_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
                                     const cvttmi_options *options, void *hipStream);
 
+/* replaces cvtt::Kernels::EncodeETC1 (ConvectionKernels_API.cpp:201-214 -> ETCComputer::CompressETC1Block,
+ * ConvectionKernels_ETC.cpp:2116-2126, CompressETC1BlockInternal 2624-2882 with both the individual and the
+ * differential mode): numBlocks * 64 B of PixelBlockU8 in, 8 B per block out.  The ETC1CompressionData scratch
+ * (AllocETC1Data / ReleaseETC1Data) has no counterpart.  Same flags as ETC2. */
+int cvttmi_encode_etc1_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
+                              const cvttmi_options *options, void *hipStream);
+int cvttmi_encode_etc1(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
+                       const cvttmi_options *options);
+
 /* ---- host-buffer convenience entry points: stage through pinned memory, launch, copy
  * back, synchronise.  Same semantics as the *_device calls. ---- */
 int cvttmi_encode_bc7(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,

@@ -121,12 +121,22 @@ extern "C"
         }
     }
 
-    // mode: 0 = ETC2 RGB (8 B/block), 1 = ETC2 RGBA (16 B/block), 2 = EAC alpha only (8 B/block)
+    // mode: 0 = ETC2 RGB (8 B/block), 1 = ETC2 RGBA (16 B/block), 2 = EAC alpha only (8 B/block), 3 = ETC1 (8 B/block)
     int ref_encode_etc2(uint8_t *out, const uint8_t *blocks, size_t numBlocks, const void *optionsBytes, int mode)
     {
         cvtt::Options o;
         memcpy(&o, optionsBytes, sizeof(o));
         const cvtt::PixelBlockU8 *in = reinterpret_cast<const cvtt::PixelBlockU8 *>(blocks);
+        if (mode == 3)
+        {
+            cvtt::ETC1CompressionData *data1 = cvtt::Kernels::AllocETC1Data(shimAlloc, NULL);
+            if (!data1)
+                return -1;
+            for (size_t b = 0; b + cvtt::NumParallelBlocks <= numBlocks; b += cvtt::NumParallelBlocks)
+                cvtt::Kernels::EncodeETC1(out + b * 8, in + b, o, data1);
+            cvtt::Kernels::ReleaseETC1Data(data1, shimFree);
+            return 0;
+        }
         cvtt::ETC2CompressionData *data = NULL;
         if (mode != 2)
         {

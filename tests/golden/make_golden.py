@@ -154,7 +154,7 @@ def main():
         "weights": P.make_options(weights=(0.5, 1.0, 0.25, 2.0)),
     }.items():
         e2["opt_" + name] = o
-        for mode, tag in ((0, "rgb"), (1, "rgba"), (2, "alpha")):
+        for mode, tag in ((0, "rgb"), (1, "rgba"), (2, "alpha"), (3, "etc1")):
             e2["out_%s_%s" % (tag, name)] = ref.encode_etc2(etc_blocks, o, mode)
     # EAC R11 (EncodeETC2Alpha11), unsigned and signed, incl. out-of-range inputs (the reference clamps)
     e2["r11_blocks"] = content.mixed_r11_blocks(11, 64)

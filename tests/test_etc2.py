@@ -1,4 +1,4 @@
-"""ETC2 RGB / RGBA / EAC alpha: oracle vs golden vectors / reference on CPU; HIP path on GPU."""
+"""ETC2 RGB / RGBA / EAC alpha and ETC1: oracle vs golden vectors / reference on CPU; HIP path on GPU."""
 import os
 
 import numpy as np
@@ -9,7 +9,7 @@ from oracle import pyref
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 NAMES = ["default", "uniform", "weights"]
-MODES = [(0, "rgb"), (1, "rgba"), (2, "alpha")]
+MODES = [(0, "rgb"), (1, "rgba"), (2, "alpha"), (3, "etc1")]  # 3 = EncodeETC1: individual + differential modes only
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -51,7 +51,7 @@ def test_t_mode_group_coupling(oracle_lib):
 
 # ------------------------------------------------------------------ GPU
 def _enc(ctx, mode):
-    return {0: ctx.encode_etc2, 1: ctx.encode_etc2_rgba, 2: ctx.encode_etc2_alpha}[mode]
+    return {0: ctx.encode_etc2, 1: ctx.encode_etc2_rgba, 2: ctx.encode_etc2_alpha, 3: ctx.encode_etc1}[mode]
 
 
 @pytest.mark.gpu
@@ -78,6 +78,15 @@ def test_gpu_known_answers_and_config4(gpu_ctx, oracle_lib):
     out = gpu_ctx.encode_etc2_rgba(torch.from_numpy(blocks).cuda(), api.Options()).cpu().numpy()
     bad = np.nonzero((out != exp).any(axis=1))[0]
     assert bad.size == 0, bad[:8]
+    # ETC1 on the same content: both the individual (diff bit 0) and the differential mode must occur
+    exp1 = oracle_lib.encode_etc2(blocks, pyref.make_options(), 3, threads=8)
+    out1 = gpu_ctx.encode_etc1(torch.from_numpy(blocks).cuda(), api.Options()).cpu().numpy()
+    assert (out1 == exp1).all()
+    smooth = content.mixed_ldr_blocks(90, 64)
+    exp2 = oracle_lib.encode_etc2(smooth, pyref.make_options(), 3, threads=8)
+    assert (gpu_ctx.encode_etc1(smooth, api.Options()) == exp2).all()
+    diff = np.concatenate([out1[:, 3], exp2[:, 3]]) & 2
+    assert (diff == 0).any() and (diff != 0).any()
     smooth = content.mixed_ldr_blocks(99, 96)
     for mode, _ in MODES:
         exp = oracle_lib.encode_etc2(smooth, pyref.make_options(), mode, threads=8)
