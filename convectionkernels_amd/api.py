@@ -530,22 +530,24 @@ class Context:
         return out
 
     def encode_image(self, fmt, image, options=None, plan=None, stream=None):
-        """linear image in HBM -> packed blocks of format `fmt` in ("bc7","bc1","bc6hu","bc6hs","etc2","etc2rgba","eac"),
-        row-major, ceil(W/4) blocks per row: tiling, encode and row compaction all on the device."""
+        """linear image in HBM -> packed blocks of format `fmt`, row-major, ceil(W/4) blocks per row: tiling, encode and
+        row compaction all on the device.  fmt: "bc7", "bc1", "bc2", "bc3", "bc4u", "bc4s", "bc5u", "bc5s", "etc1",
+        "etc2" (= "etc2rgb"), "etc2rgba", "eac" (8-bit EAC alpha block alone) from an (H,W,4) uint8 image;
+        "bc6hu", "bc6hs" from an (H,W,4) half-float image."""
         h, w = int(image.shape[0]), int(image.shape[1])
         blocks = self.tile_image(image, stream)
+        simple = {"bc1": self.encode_bc1, "bc2": self.encode_bc2, "bc3": self.encode_bc3, "etc1": self.encode_etc1,
+                  "etc2": self.encode_etc2, "etc2rgb": self.encode_etc2, "etc2rgba": self.encode_etc2_rgba, "eac": self.encode_etc2_alpha}
         if fmt == "bc7":
             packed = self.encode_bc7(blocks, options, plan, stream=stream)
-        elif fmt == "bc1":
-            packed = self.encode_bc1(blocks, options, stream=stream)
+        elif fmt in simple:
+            packed = simple[fmt](blocks, options, stream=stream)
+        elif fmt in ("bc4u", "bc4s"):
+            packed = self.encode_bc4(blocks, options, signed=(fmt == "bc4s"), stream=stream)
+        elif fmt in ("bc5u", "bc5s"):
+            packed = self.encode_bc5(blocks, options, signed=(fmt == "bc5s"), stream=stream)
         elif fmt in ("bc6hu", "bc6hs"):
             packed = self.encode_bc6h(blocks, options, signed=(fmt == "bc6hs"), stream=stream)
-        elif fmt == "etc2":
-            packed = self.encode_etc2(blocks, options, stream=stream)
-        elif fmt == "etc2rgba":
-            packed = self.encode_etc2_rgba(blocks, options, stream=stream)
-        elif fmt == "eac":
-            packed = self.encode_etc2_alpha(blocks, options, stream=stream)
         else:
             raise CvttError("unknown format %r" % (fmt,))
         return packed if w % 32 == 0 else self.compact_rows(packed, w, h, stream)

@@ -1,0 +1,105 @@
+"""KTX / DDS containers and the packer command line (the caller side, etc2packer.cpp:57-293)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import content
+from convectionkernels_amd import container, synth
+
+
+def test_ktx_header_is_the_reference_packers():
+    """field by field what etc2packer.cpp:116-197 writes for an ETC2 RGBA texture"""
+    blocks = np.arange(3 * 2 * 16, dtype=np.uint8).reshape(6, 16)
+    raw = container.ktx_bytes("etc2rgba", 10, 7, blocks)
+    assert raw[:12] == bytes([0xAB, 0x4B, 0x54, 0x58, 0x20, 0x31, 0x31, 0xBB, 0x0D, 0x0A, 0x1A, 0x0A])
+    f = struct.unpack_from("<13I", raw, 12)
+    assert f == (0x04030201, 0, 1, 0, 0x9278, 0x1908, 10, 7, 0, 0, 1, 1, 0)
+    assert struct.unpack_from("<I", raw, 64)[0] == 3 * 2 * 16 and raw[68:] == blocks.tobytes()
+    assert len(raw) == 64 + 4 + 96
+
+
+@pytest.mark.parametrize("fmt", sorted(container.FORMATS))
+def test_roundtrip(fmt, tmp_path):
+    per = container.FORMATS[fmt][0]
+    w, h = 37, 10
+    n = 10 * 3
+    blocks = np.random.default_rng(3).integers(0, 256, (n, per)).astype(np.uint8)
+    p = str(tmp_path / "t.ktx")
+    container.write_ktx(p, fmt, w, h, blocks)
+    name, rw, rh, rb = container.read_ktx(p)
+    assert (name, rw, rh) == (fmt, w, h) and (rb == blocks).all()
+    if container.FORMATS[fmt][3] is not None:
+        p = str(tmp_path / "t.dds")
+        container.write_dds(p, fmt, w, h, blocks)
+        name, rw, rh, rb = container.read_dds(p)
+        assert (name, rw, rh) == (fmt, w, h) and (rb == blocks).all()
+        assert os.path.getsize(p) == 4 + 124 + 20 + n * per
+    else:
+        with pytest.raises(ValueError):
+            container.dds_bytes(fmt, w, h, blocks)
+
+
+def test_rejects_wrong_payload_and_names():
+    with pytest.raises(ValueError):
+        container.ktx_bytes("bc7", 16, 16, np.zeros((15, 16), np.uint8))
+    with pytest.raises(ValueError):
+        container.canonical("bc8")
+    assert container.canonical("etc2rgb") == "etc2"
+
+
+def test_r11_tiles_follow_the_reference_packer():
+    from convectionkernels_amd import packer
+    img = synth.image_rgba8(21, 40, 12)[:10, :37].copy()
+    blocks, bw, bh, gw = packer.r11_blocks(img, signed=False)
+    assert (bw, bh, gw) == (10, 3, 16) and blocks.shape == (48, 16) and blocks.dtype == np.int16
+    r, g, b = (int(v) for v in img[5, 6, :3])
+    assert blocks[1 * 16 + 1, 1 * 4 + 2] == int(np.floor((r + g + b) / 765.0 * 2047.0 + 0.5))
+    s, _, _, _ = packer.r11_blocks(img, signed=True)
+    assert s[1 * 16 + 1, 1 * 4 + 2] == int(np.floor((r + g + b) / 765.0 * 1023.0 + 0.5))
+    assert (blocks[9, 3] == blocks[9, 0]).all()  # block 9 starts at x = 36, the last column: clamped
+
+
+@pytest.mark.gpu
+def test_packer_cli(gpu_ctx, oracle_lib, tmp_path):
+    """PNG -> KTX / DDS through the command line; payload == oracle on the clamped tiles of the same image"""
+    from PIL import Image
+    from oracle import pyref
+    from convectionkernels_amd import api, packer
+    rcp = oracle_lib.probe_rcp()
+    api.default_context().set_rcp_table(rcp)
+    w, h = 75, 22
+    img = synth.image_rgba8(31, 76, 24)[:h, :w].copy()
+    src = str(tmp_path / "in.png")
+    Image.fromarray(img, "RGBA").save(src)
+    tiles = content.tile_clamped(img)
+
+    out = str(tmp_path / "o.ktx")
+    assert packer.main([src, out]) == 0  # default format: ETC2 RGB, like the reference packer
+    name, rw, rh, blocks = container.read_ktx(out)
+    assert (name, rw, rh) == ("etc2", w, h)
+    assert (blocks == content.compact_rows(oracle_lib.encode_etc2(tiles, pyref.make_options(), 0, threads=4), w, h)).all()
+
+    assert packer.main(["-format", "etc1", "-uniform", src, out]) == 0
+    exp = oracle_lib.encode_etc2(tiles, pyref.make_options(flags=pyref.FLAGS_DEFAULT | pyref.FLAG_UNIFORM), 3, threads=4)
+    assert (container.read_ktx(out)[3] == content.compact_rows(exp, w, h)).all()
+
+    assert packer.main(["-format", "r11u", src, out]) == 0
+    r11, bw, bh, gw = packer.r11_blocks(img, False)
+    exp = oracle_lib.encode_eac11(r11, False)
+    assert (container.read_ktx(out)[3] == exp.reshape(bh, gw, 8)[:, :bw].reshape(-1, 8)).all()
+
+    dds = str(tmp_path / "o.dds")
+    assert packer.main(["-format", "bc7", "-quality", "20", "-dds", src, dds]) == 0
+    plan = api.BC7EncodingPlan()
+    api.ConfigureBC7EncodingPlanFromQuality(plan, 20)
+    exp = oracle_lib.encode_bc7(tiles, pyref.make_options(), np.frombuffer(plan.tobytes(), np.uint8).copy(), rcp, threads=4)
+    name, rw, rh, blocks = container.read_dds(dds)
+    assert name == "bc7" and (blocks == content.compact_rows(exp, w, h)).all()
+
+    assert packer.main(["-format", "bc3", "-dds", src, dds]) == 0
+    exp = oracle_lib.encode_s3tc(tiles, pyref.make_options(), 3, rcp, threads=4)
+    assert (container.read_dds(dds)[3] == content.compact_rows(exp, w, h)).all()
+
+    assert packer.main(["-fakebt709", src, out]) == 2 and packer.main([src]) == 2
