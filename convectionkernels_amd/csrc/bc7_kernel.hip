@@ -1385,6 +1385,14 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
 #endif
             const float combined = b.err + bA.err; // reference BC67.cpp:1942
             const int seq = 384 + cfg;
+#ifdef CVTT_BC7_PROFILE
+            {
+                const float lbp = (rotation == 0) ? lbRot[0] : (rotation == 1) ? lbRot[1] : (rotation == 2) ? lbRot[2] : lbRot[3];
+                const bool needed = valid && c == 0 && !(lbp > work.err);
+                PROF_COUNT(6, (needed && (bA.err + lbp > work.err)) ? 1 : 0)
+                PROF_COUNT(7, (needed && combined < work.err) ? 1 : 0)
+            }
+#endif
             if (combined < work.err || (combined == work.err && seq < workSeq))
             {
                 work.err = combined;

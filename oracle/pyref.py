@@ -109,7 +109,7 @@ class RefLib:
         return out.reshape(n, 16)
 
     def encode_etc2(self, blocks, options, mode):
-        """mode 0: ETC2 RGB (8 B), 1: ETC2 RGBA (16 B), 2: EAC alpha (8 B), 3: ETC1 (8 B)."""
+        """mode 0: ETC2 RGB (8 B), 1: ETC2 RGBA (16 B), 2: EAC alpha (8 B), 3: ETC1 (8 B), 4: ETC2 punch-through alpha (8 B)."""
         blocks, pb = _u8(blocks)
         n = blocks.size // 64
         assert n % 8 == 0
@@ -229,7 +229,7 @@ class OracleLib:
         return out.reshape(n, 16)
 
     def encode_etc2(self, blocks, options, mode, threads=1):
-        """mode 0: ETC2 RGB (8 B), 1: ETC2 RGBA (16 B), 2: EAC alpha (8 B), 3: ETC1 (8 B)."""
+        """mode 0: ETC2 RGB (8 B), 1: ETC2 RGBA (16 B), 2: EAC alpha (8 B), 3: ETC1 (8 B), 4: ETC2 punch-through alpha (8 B)."""
         blocks, pb = _u8(blocks)
         n = blocks.size // 64
         assert n % 8 == 0

@@ -121,7 +121,7 @@ extern "C"
         }
     }
 
-    // mode: 0 = ETC2 RGB (8 B/block), 1 = ETC2 RGBA (16 B/block), 2 = EAC alpha only (8 B/block), 3 = ETC1 (8 B/block)
+    // mode: 0 = ETC2 RGB (8 B/block), 1 = ETC2 RGBA (16 B/block), 2 = EAC alpha only (8 B/block), 3 = ETC1 (8 B/block), 4 = ETC2 punch-through alpha (8 B/block)
     int ref_encode_etc2(uint8_t *out, const uint8_t *blocks, size_t numBlocks, const void *optionsBytes, int mode)
     {
         cvtt::Options o;
@@ -150,6 +150,8 @@ extern "C"
                 cvtt::Kernels::EncodeETC2(out + b * 8, in + b, o, data);
             else if (mode == 1)
                 cvtt::Kernels::EncodeETC2RGBA(out + b * 16, in + b, o, data);
+            else if (mode == 4)
+                cvtt::Kernels::EncodeETC2PunchthroughAlpha(out + b * 8, in + b, o, data);
             else
                 cvtt::Kernels::EncodeETC2Alpha(out + b * 8, in + b, o);
         }
