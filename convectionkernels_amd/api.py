@@ -188,6 +188,7 @@ _EXPORTS = (
     "cvttmi_encode_bc2", "cvttmi_encode_bc3", "cvttmi_encode_bc4", "cvttmi_encode_bc5",
     "cvttmi_decode_bc7_device", "cvttmi_decode_bc7", "cvttmi_decode_bc6h_device", "cvttmi_decode_bc6h",
     "cvttmi_encode_etc1_device", "cvttmi_encode_etc1",
+    "cvttmi_encode_etc2_punchthrough_alpha_device", "cvttmi_encode_etc2_punchthrough_alpha",
     "cvttmi_default_bc7_fine_tuning", "cvttmi_bc7_plan_from_quality", "cvttmi_bc7_plan_from_fine_tuning",
 )
 
@@ -224,7 +225,8 @@ def load_library():
                                               ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     lib.cvttmi_encode_bc6h.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                        ctypes.c_void_p, ctypes.c_int]
-    for n in ("cvttmi_encode_etc2", "cvttmi_encode_etc2_rgba", "cvttmi_encode_etc2_alpha", "cvttmi_encode_etc1"):
+    for n in ("cvttmi_encode_etc2", "cvttmi_encode_etc2_rgba", "cvttmi_encode_etc2_alpha", "cvttmi_encode_etc1",
+              "cvttmi_encode_etc2_punchthrough_alpha"):
         getattr(lib, n).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         getattr(lib, n + "_device").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                                  ctypes.c_void_p, ctypes.c_void_p]
@@ -428,6 +430,12 @@ class Context:
         return self._encode_simple(self._lib.cvttmi_encode_etc2, self._lib.cvttmi_encode_etc2_device, "encode_etc2",
                                    blocks, options, out, stream, 64, 8)
 
+    def encode_etc2_punchthrough_alpha(self, blocks, options=None, out=None, stream=None):
+        """Batched cvtt::Kernels::EncodeETC2PunchthroughAlpha: (N,16,4) uint8 -> (N,8) uint8 (RGB8A1 blocks; a pixel is
+        transparent when its alpha is below floor(clamp(options.threshold, 0, 1) * 255 + 1))."""
+        return self._encode_simple(self._lib.cvttmi_encode_etc2_punchthrough_alpha, self._lib.cvttmi_encode_etc2_punchthrough_alpha_device,
+                                   "encode_etc2_punchthrough_alpha", blocks, options, out, stream, 64, 8)
+
     def encode_etc2_rgba(self, blocks, options=None, out=None, stream=None):
         """Batched cvtt::Kernels::EncodeETC2RGBA: (N,16,4) uint8 -> (N,16) uint8 = [EAC alpha | colour]."""
         return self._encode_simple(self._lib.cvttmi_encode_etc2_rgba, self._lib.cvttmi_encode_etc2_rgba_device,
@@ -532,12 +540,13 @@ class Context:
     def encode_image(self, fmt, image, options=None, plan=None, stream=None):
         """linear image in HBM -> packed blocks of format `fmt`, row-major, ceil(W/4) blocks per row: tiling, encode and
         row compaction all on the device.  fmt: "bc7", "bc1", "bc2", "bc3", "bc4u", "bc4s", "bc5u", "bc5s", "etc1",
-        "etc2" (= "etc2rgb"), "etc2rgba", "eac" (8-bit EAC alpha block alone) from an (H,W,4) uint8 image;
+        "etc2" (= "etc2rgb"), "etc2rgba", "etc2punchthrough", "eac" (8-bit EAC alpha block alone) from an (H,W,4) uint8 image;
         "bc6hu", "bc6hs" from an (H,W,4) half-float image."""
         h, w = int(image.shape[0]), int(image.shape[1])
         blocks = self.tile_image(image, stream)
         simple = {"bc1": self.encode_bc1, "bc2": self.encode_bc2, "bc3": self.encode_bc3, "etc1": self.encode_etc1,
-                  "etc2": self.encode_etc2, "etc2rgb": self.encode_etc2, "etc2rgba": self.encode_etc2_rgba, "eac": self.encode_etc2_alpha}
+                  "etc2": self.encode_etc2, "etc2rgb": self.encode_etc2, "etc2rgba": self.encode_etc2_rgba, "eac": self.encode_etc2_alpha,
+                  "etc2punchthrough": self.encode_etc2_punchthrough_alpha}
         if fmt == "bc7":
             packed = self.encode_bc7(blocks, options, plan, stream=stream)
         elif fmt in simple:
@@ -652,6 +661,11 @@ def EncodeETC2(pBlocks, options=None, compressionData=None, device=0):
     """cvtt::Kernels::EncodeETC2 (reference ConvectionKernels_API.cpp:216-229); the reference's
     ETC2CompressionData scratch argument is accepted and ignored (scratch lives in LDS)."""
     return default_context(device).encode_etc2(pBlocks, options)
+
+
+def EncodeETC2PunchthroughAlpha(pBlocks, options=None, compressionData=None, device=0):
+    """cvtt::Kernels::EncodeETC2PunchthroughAlpha (reference ConvectionKernels_API.cpp:231-244)."""
+    return default_context(device).encode_etc2_punchthrough_alpha(pBlocks, options)
 
 
 def EncodeETC2RGBA(pBlocks, options=None, compressionData=None, device=0):

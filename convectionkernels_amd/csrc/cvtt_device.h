@@ -106,6 +106,7 @@ struct CvttEtcArgs
     uint32_t outStride; // bytes between consecutive output blocks (8, or 16 for RGBA)
     uint32_t outOffset; // byte offset of this kernel's 8 bytes inside the output block
     uint64_t debug;     // developer builds (-DCVTT_ETC_DEBUG): device pointer for per-stage errors, else 0
+    uint32_t alphaThreshold; // punch-through: pixels with alpha below this are transparent (reference ETC.cpp:1672-1675)
 };
 
 #endif

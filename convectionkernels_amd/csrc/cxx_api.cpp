@@ -123,6 +123,11 @@ namespace cvtt
             std::lock_guard<std::mutex> g(g_lock);
             check(cvttmi_encode_bc6h(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), 1), "EncodeBC6HS");
         }
+        void EncodeETC2PunchthroughAlphaBatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
+        {
+            std::lock_guard<std::mutex> g(g_lock);
+            check(cvttmi_encode_etc2_punchthrough_alpha(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeETC2PunchthroughAlpha");
+        }
         void EncodeETC1Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
         {
             std::lock_guard<std::mutex> g(g_lock);
@@ -177,6 +182,7 @@ namespace cvtt
         void EncodeBC1(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options) { EncodeBC1Batch(pBC, pBlocks, NumParallelBlocks, options); }
         void EncodeBC6HU(uint8_t *pBC, const PixelBlockF16 *pBlocks, const Options &options) { EncodeBC6HUBatch(pBC, pBlocks, NumParallelBlocks, options); }
         void EncodeBC6HS(uint8_t *pBC, const PixelBlockF16 *pBlocks, const Options &options) { EncodeBC6HSBatch(pBC, pBlocks, NumParallelBlocks, options); }
+        void EncodeETC2PunchthroughAlpha(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC2CompressionData *) { EncodeETC2PunchthroughAlphaBatch(pBC, pBlocks, NumParallelBlocks, options); }
         void EncodeETC1(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC1CompressionData *) { EncodeETC1Batch(pBC, pBlocks, NumParallelBlocks, options); }
         void EncodeETC2(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC2CompressionData *) { EncodeETC2Batch(pBC, pBlocks, NumParallelBlocks, options); }
         void EncodeETC2RGBA(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC2CompressionData *) { EncodeETC2RGBABatch(pBC, pBlocks, NumParallelBlocks, options); }

@@ -113,7 +113,7 @@ __device__ __forceinline__ int planarDecode(int coeff, int ch)
 }
 
 // EmitTModeBlock, ETC.cpp:2414-2460
-__device__ __forceinline__ void emitT(u32 &hi, u32 &lo, const int (&lineColor)[3], const int (&iso)[3], u32 packedSelectors, int table)
+__device__ __forceinline__ void emitT(u32 &hi, u32 &lo, const int (&lineColor)[3], const int (&iso)[3], u32 packedSelectors, int table, bool opaque = true)
 {
     hi = 0;
     lo = 0;
@@ -127,7 +127,8 @@ __device__ __forceinline__ void emitT(u32 &hi, u32 &lo, const int (&lineColor)[3
     hi |= (u32)lineColor[1] << (40 - 32);
     hi |= (u32)lineColor[2] << (36 - 32);
     hi |= (u32)((table >> 1) & 3) << (34 - 32);
-    hi |= 1u << (33 - 32);
+    if (opaque)
+        hi |= 1u << (33 - 32);
     hi |= (u32)(table & 1);
 #pragma unroll
     for (int px = 0; px < 16; px++)
@@ -138,11 +139,72 @@ __device__ __forceinline__ void emitT(u32 &hi, u32 &lo, const int (&lineColor)[3
         lo |= ((sel >> 1) & 1u) << (16 + px);
     }
 }
+
+// EmitHModeBlock, ETC.cpp:2462-2563.  bc0 / bc1: 4:4:4 colours packed r << 10 | g << 5 | b.
+__device__ __forceinline__ void emitH(u32 &outHi, u32 &outLo, int bc0, int bc1, u32 sectorBits, u32 signBits, int table, bool opaque)
+{
+    if (bc0 == bc1)
+    {
+        const int lineColor[3] = {(bc0 >> 10) & 0x1f, (bc0 >> 5) & 0x1f, bc0 & 0x1f};
+        u32 packedSelectors = 0x55555555u;
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+            packedSelectors |= ((signBits >> px) & 1u) << ((px * 2) + 1);
+        emitT(outHi, outLo, lineColor, lineColor, packedSelectors, table, opaque);
+        return;
+    }
+    int colors[2][3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+    {
+        colors[0][ch] = (bc0 >> ((2 - ch) * 5)) & 15;
+        colors[1][ch] = (bc1 >> ((2 - ch) * 5)) & 15;
+    }
+    if (((table & 1) == 1) != (bc0 > bc1))
+    {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+        {
+            const int t = colors[0][ch];
+            colors[0][ch] = colors[1][ch];
+            colors[1][ch] = t;
+        }
+        sectorBits ^= 0xffffu;
+    }
+    const int r1 = colors[0][0], g1a = colors[0][1] >> 1, g1b = colors[0][1] & 1, b1a = colors[0][2] >> 3, b1b = colors[0][2] & 7;
+    const int r2 = colors[1][0], g2 = colors[1][1], b2 = colors[1][2];
+    u32 hi = 0, lo = 0;
+    if ((g1a & 4) != 0 && r1 + g1a < 8) hi |= 1u << (63 - 32);
+    const int fakeDG = b1b >> 1, fakeG = b1a | (g1b << 1);
+    if (fakeG + fakeDG < 4) hi |= 1u << (50 - 32); else hi |= 7u << (53 - 32);
+    hi |= (u32)r1 << (59 - 32);
+    hi |= (u32)g1a << (56 - 32);
+    hi |= (u32)g1b << (52 - 32);
+    hi |= (u32)b1a << (51 - 32);
+    hi |= (u32)b1b << (47 - 32);
+    hi |= (u32)r2 << (43 - 32);
+    hi |= (u32)g2 << (39 - 32);
+    hi |= (u32)b2 << (35 - 32);
+    hi |= (u32)((table >> 2) & 1) << (34 - 32);
+    if (opaque)
+        hi |= 1u << (33 - 32);
+    hi |= (u32)((table >> 1) & 1);
+#pragma unroll
+    for (int px = 0; px < 16; px++)
+    {
+        const int src2 = ((px & 3) << 2) | (px >> 2);
+        lo |= ((signBits >> src2) & 1u) << px;
+        lo |= ((sectorBits >> src2) & 1u) << (16 + px);
+    }
+    outHi = hi;
+    outLo = lo;
+}
 } // namespace
 
 // ------------------------------------------------------------------------------------------
-template <bool ETC1>
-__global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+// MODE 0: EncodeETC2 (RGB), 1: EncodeETC1, 2: EncodeETC2PunchthroughAlpha
+template <int MODE>
+__global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
                                                                const CvttEtcArgs A, const CvttDeviceTables *__restrict__ T)
 {
     __shared__ EtcWaveShared shared[8];
@@ -153,18 +215,43 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
     const u32 blockIndex = blockIdx.x * 8u + (u32)wave;
     EtcWaveShared &S = shared[wave];
     const EtcErr E = {(A.flags & CVTTMI_FLAG_UNIFORM) != 0, A.rw, A.gw, A.bw};
+    constexpr bool ETC1 = MODE == 1, PUNCH = MODE == 2;
 
-    // ---- load: pixel px by lane px ----
+    // ---- load: pixel px by lane px.  Punch-through: pixels whose alpha is below the threshold are transparent and
+    // count as black from here on (ETC.cpp:1670-1720) ----
+    bool pxTransparent = false;
     if (lane < 16)
     {
         const u32 pk = reinterpret_cast<const u32 *>(blocks + (size_t)blockIndex * 64u)[lane];
-        const int r = (int)(pk & 0xffu), g = (int)((pk >> 8) & 0xffu), b = (int)((pk >> 16) & 0xffu);
+        int r = (int)(pk & 0xffu), g = (int)((pk >> 8) & 0xffu), b = (int)((pk >> 16) & 0xffu);
+        pxTransparent = PUNCH && (pk >> 24) < A.alphaThreshold;
+        if (pxTransparent)
+            r = g = b = 0;
         S.pix[lane][0] = r;
         S.pix[lane][1] = g;
         S.pix[lane][2] = b;
-        S.pw[lane][0] = E.uniform ? (float)r : (float)r * A.rw;
-        S.pw[lane][1] = E.uniform ? (float)g : (float)g * A.gw;
-        S.pw[lane][2] = E.uniform ? (float)b : (float)b * A.bw;
+        S.pw[lane][0] = pxTransparent ? 0.0f : (E.uniform ? (float)r : (float)r * A.rw);
+        S.pw[lane][1] = pxTransparent ? 0.0f : (E.uniform ? (float)g : (float)g * A.gw);
+        S.pw[lane][2] = pxTransparent ? 0.0f : (E.uniform ? (float)b : (float)b * A.bw);
+    }
+    const u32 transMask = PUNCH ? ((u32)__ballot(pxTransparent) & 0xffffu) : 0u;
+    const int numOpaque = 16 - __popc(transMask);
+    // the two group-wide predicates of CompressETC2Block: does ANY block have a transparent pixel (then every block
+    // also goes through the punch-through modes), are ALL blocks fully transparent (then the opaque modes are skipped)
+    bool groupAny = false, groupAll = false;
+    if (PUNCH)
+    {
+        if (lane == 0)
+            groupTCount[wave][0] = (transMask != 0 ? 1 : 0) | (transMask == 0xffffu ? 2 : 0);
+        __syncthreads();
+        groupAll = true;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; w8++)
+        {
+            groupAny = groupAny || (groupTCount[w8][0] & 1) != 0;
+            groupAll = groupAll && (groupTCount[w8][0] & 2) != 0;
+        }
+        __syncthreads();
     }
     WAVE_SYNC();
 
@@ -177,9 +264,11 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
 #define DBG_TAP(i) do {} while (0)
 #endif
 
+    u32 isolatedMask = 0; // bit px: pixel is "isolated" / sector 1
     if (!ETC1) // EncodeETC1 is the cluster fit alone (CompressETC1Block, ETC.cpp:2116-2126)
     {
     // =================================== planar ===================================
+    if (!groupAll)
     {
         // closed-form least squares per channel (lanes 0..2), ETC.cpp:1291-1413
         const int ch = lane < 3 ? lane : 0;
@@ -315,7 +404,6 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
 
     DBG_TAP(0);
     // ============ sector split along the chroma principal axis (ETC.cpp:1723-1848) ============
-    u32 isolatedMask = 0; // bit px: pixel is "isolated" / sector 1
     {
         float cdx[16], cdy[16];
         if (E.uniform)
@@ -333,8 +421,9 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
 #pragma unroll
             for (int px = 0; px < 16; px++)
             {
-                cdx[px] = (float)(int)(short)((int)(short)(ccx[px] << 4) - cenX);
-                cdy[px] = (float)(int)(short)((int)(short)(ccy[px] << 4) - cenY) * 0.57735026918962576450914878050196f;
+                // x 16, or x the number of opaque pixels in the punch-through encoder (ETC.cpp:1746-1765)
+                cdx[px] = (float)(int)(short)((int)(short)(ccx[px] * numOpaque) - cenX);
+                cdy[px] = (float)(int)(short)((int)(short)(ccy[px] * numOpaque) - cenY) * 0.57735026918962576450914878050196f;
             }
         }
         else
@@ -356,8 +445,8 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
 #pragma unroll
             for (int px = 0; px < 16; px++)
             {
-                cdx[px] = ccx[px] * 16.0f - cenX;
-                cdy[px] = ccy[px] * 16.0f - cenY;
+                cdx[px] = ccx[px] * (float)numOpaque - cenX;
+                cdy[px] = ccy[px] * (float)numOpaque - cenY;
             }
         }
         float covXX = 0.0f, covYY = 0.0f, covXY = 0.0f;
@@ -383,7 +472,7 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
     }
 
     // =================================== T mode x2 ===================================
-    for (int call = 0; call < 2; call++)
+    for (int call = 0; call < 2 && !groupAll; call++)
     {
         const u32 iso = call == 0 ? isolatedMask : (~isolatedMask & 0xffffu);
         int isolatedTotal[3] = {0, 0, 0}, lineTotal[3] = {0, 0, 0};
@@ -534,6 +623,7 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
 
     // =================================== H mode ===================================
     // groupings = the flipped sector assignment (ETC.cpp:1855-1860)
+    if (!groupAll)
     {
         const u32 grp = ~isolatedMask & 0xffffu;
         int counts[2], totals[2][3] = {{0, 0, 0}, {0, 0, 0}};
@@ -673,63 +763,7 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
             const int table = wId >> 10;
             u32 sectorBits = bits & 0xffffu;
             const u32 signBits = bits >> 16;
-            // EmitHModeBlock, ETC.cpp:2462-2563
-            if (bc0 == bc1)
-            {
-                const int lineColor[3] = {(bc0 >> 10) & 0x1f, (bc0 >> 5) & 0x1f, bc0 & 0x1f};
-                u32 packedSelectors = 0x55555555u;
-#pragma unroll
-                for (int px = 0; px < 16; px++)
-                    packedSelectors |= ((signBits >> px) & 1u) << ((px * 2) + 1);
-                emitT(outHi, outLo, lineColor, lineColor, packedSelectors, table);
-            }
-            else
-            {
-                int colors[2][3];
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++)
-                {
-                    colors[0][ch] = (bc0 >> ((2 - ch) * 5)) & 15;
-                    colors[1][ch] = (bc1 >> ((2 - ch) * 5)) & 15;
-                }
-                if (((table & 1) == 1) != (bc0 > bc1))
-                {
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++)
-                    {
-                        const int t = colors[0][ch];
-                        colors[0][ch] = colors[1][ch];
-                        colors[1][ch] = t;
-                    }
-                    sectorBits ^= 0xffffu;
-                }
-                const int r1 = colors[0][0], g1a = colors[0][1] >> 1, g1b = colors[0][1] & 1, b1a = colors[0][2] >> 3, b1b = colors[0][2] & 7;
-                const int r2 = colors[1][0], g2 = colors[1][1], b2 = colors[1][2];
-                u32 hi = 0, lo = 0;
-                if ((g1a & 4) != 0 && r1 + g1a < 8) hi |= 1u << (63 - 32);
-                const int fakeDG = b1b >> 1, fakeG = b1a | (g1b << 1);
-                if (fakeG + fakeDG < 4) hi |= 1u << (50 - 32); else hi |= 7u << (53 - 32);
-                hi |= (u32)r1 << (59 - 32);
-                hi |= (u32)g1a << (56 - 32);
-                hi |= (u32)g1b << (52 - 32);
-                hi |= (u32)b1a << (51 - 32);
-                hi |= (u32)b1b << (47 - 32);
-                hi |= (u32)r2 << (43 - 32);
-                hi |= (u32)g2 << (39 - 32);
-                hi |= (u32)b2 << (35 - 32);
-                hi |= (u32)((table >> 2) & 1) << (34 - 32);
-                hi |= 1u << (33 - 32);
-                hi |= (u32)((table >> 1) & 1);
-#pragma unroll
-                for (int px = 0; px < 16; px++)
-                {
-                    const int src2 = ((px & 3) << 2) | (px >> 2);
-                    lo |= ((signBits >> src2) & 1u) << px;
-                    lo |= ((sectorBits >> src2) & 1u) << (16 + px);
-                }
-                outHi = hi;
-                outLo = lo;
-            }
+            emitH(outHi, outLo, bc0, bc1, sectorBits, signBits, table, true);
         }
         WAVE_SYNC();
     }
@@ -738,7 +772,9 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
     } // !ETC1
     // ====================== ETC1 cluster fit ======================
     // ETC2 reaches it through CompressETC2Block, which asks for the differential mode only (d = 1, ETC.cpp:1862);
-    // EncodeETC1 also tries the individual 4:4:4 + 4:4:4 mode (d = 0) of each flip first
+    // EncodeETC1 also tries the individual 4:4:4 + 4:4:4 mode (d = 0) of each flip first.  punch = true is
+    // CompressETC1PunchthroughBlockInternal (ETC.cpp:2885-3082): three paint colours + "transparent" per half block
+    auto clusterFit = [&](const bool punch)
     {
         bool etcBest = false;
         int bFlip = 0, bD = 1;
@@ -769,6 +805,34 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
                 const int numOffsets = T->clusterCount[table];
                 const int start = T->clusterStart[table];
                 int n = 0, last = -1;
+                if (punch)
+                {
+                    // base colours: cumulative + om * modifier, divided by the number of TRANSPARENT pixels of the half
+                    // (sic, ETC.cpp:2949-2951), om = -count..count
+                    const u32 sectorMask = flip == 0 ? (sector ? 0xccccu : 0x3333u) : (sector ? 0xff00u : 0x00ffu);
+                    const int count = __popc(transMask & sectorMask);
+                    const int denominator = (count > 1 ? count : 1) << 8, addend = count << 7, cumulativeMax = 255 * count;
+                    const int modifier = T->etc1Modifiers[table][3];
+                    for (int om = -count; om <= count; om++)
+                    {
+                        const int off = (int)(short)(om * modifier);
+                        int packed = 0;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                        {
+                            int cu = (int)(short)(cumulative[ch] + off);
+                            cu = cu < 0 ? 0 : (cu > cumulativeMax ? cumulativeMax : cu);
+                            const u32 numerator = ((((u32)cu << 5) - (u32)cu) + (((u32)cu >> 3) + (u32)addend)) & 0xffffu;
+                            packed |= udivSmall((int)numerator, denominator) << (ch * 5);
+                        }
+                        if (n == 0 || packed != last)
+                        {
+                            S.dColors[lane][n++] = (unsigned short)packed;
+                            last = packed;
+                        }
+                    }
+                }
+                else
                 for (int oi = 0; oi < numOffsets; oi++)
                 {
                     const int off = T->clusterOffsets[start + oi];
@@ -824,6 +888,21 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
                             modified[s][ch] = v < 0 ? 0 : (v > 255 ? 255 : v);
                         }
                     }
+                    if (punch)
+                    {
+                        // TestHalfBlockPunchthrough, ETC.cpp:151-217: colour - m, colour, colour + m
+                        const int m = T->etc1Modifiers[table][3];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                        {
+                            const int q = (packed >> (ch * 5)) & 31;
+                            const int u = (q << 3) | (q >> 2);
+                            modified[0][ch] = (u > m ? u : m) - m;
+                            modified[1][ch] = u;
+                            modified[2][ch] = u + m < 255 ? u + m : 255;
+                            modified[3][ch] = 0;
+                        }
+                    }
                     u32 selectors = 0;
                     float totalError = 0.0f;
                     for (int spx = 0; spx < 8; spx++)
@@ -835,11 +914,15 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
 #pragma unroll
                         for (int s = 0; s < 4; s++)
                         {
+                            if (punch && s == 3)
+                                continue;
                             const float e = E(modified[s][0], modified[s][1], modified[s][2], S.pix[px], S.pw[px]);
                             if (e < be)
                                 bs = (u32)s;
                             be = sseMin(e, be);
                         }
+                        if (punch && ((transMask >> px) & 1u))
+                            be = 0.0f; // a transparent pixel costs nothing
                         totalError = totalError + be;
                         selectors |= bs << (spx * 2);
                     }
@@ -899,10 +982,13 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
                 const int d0 = (int)(b & 31u) - (int)(a & 31u);
                 return d2 >= -4 && d2 <= 3 && d1 >= -4 && d1 <= 3 && d0 >= -4 && d0 <= 3;
             };
+            // punch-through: a fully transparent half 0 takes the colour of half 1 and is always legal; half 1 never gets
+            // that treatment because the reference starts its flag as false (ETC.cpp:2938)
+            const bool canIgnore0 = punch && (transMask & (flip == 0 ? 0x3333u : 0x00ffu)) == (flip == 0 ? 0x3333u : 0x00ffu);
             if (m0 + m1 < blockBest0)
             {
-                const u32 p0 = colorOf(0, i0) << 16, p1 = colorOf(1, i1) << 16;
-                if (d == 0 || legal(p0 >> 16, p1 >> 16)) // individual mode: the halves are unconstrained (ETC.cpp:2831-2851)
+                const u32 p1 = colorOf(1, i1) << 16, p0 = canIgnore0 ? p1 : (colorOf(0, i0) << 16);
+                if (d == 0 || canIgnore0 || legal(p0 >> 16, p1 >> 16)) // individual mode: the halves are unconstrained (ETC.cpp:2831-2851)
                 {
                     etcBest = true;
                     bestError = m0 + m1;
@@ -992,18 +1078,33 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
 #pragma unroll
                 for (int sel = 0; sel < 4; sel++)
                 {
+                    if (punch && sel == 3)
+                        continue;
                     int m[3];
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++)
                     {
                         const int q = (int)((colr >> (ch * 5)) & 31u);
-                        const int v = (bD == 1 ? ((q << 3) | (q >> 2)) : ((q << 4) | q)) + T->etc1Modifiers[table][sel];
+                        const int u = bD == 1 ? ((q << 3) | (q >> 2)) : ((q << 4) | q);
+                        int v = u + T->etc1Modifiers[table][sel];
+                        if (punch)
+                        {
+                            const int md = T->etc1Modifiers[table][3];
+                            v = sel == 0 ? (u > md ? u : md) - md : (sel == 1 ? u : u + md);
+                        }
                         m[ch] = v < 0 ? 0 : (v > 255 ? 255 : v);
                     }
                     const float e = E(m[0], m[1], m[2], S.pix[px], S.pw[px]);
                     if (e < be)
                         bs = (u32)sel;
                     be = sseMin(e, be);
+                }
+                if (punch)
+                {
+                    // selector codes in table order: 0, 2, 3 are the colours, 1 is "transparent" (ETC.cpp:199-207)
+                    bs = (bs << 1) < 3u ? (bs << 1) : 3u;
+                    if ((transMask >> px) & 1u)
+                        bs = 1u;
                 }
                 const u64 bit0 = __ballot(lane < 16 && (bs & 1u)), bit1 = __ballot(lane < 16 && (bs & 2u));
                 u32 sel0 = 0, sel1 = 0;
@@ -1046,7 +1147,8 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
             }
             hi |= (u32)bTable0 << 5;
             hi |= (u32)bTable1 << 2;
-            hi |= (u32)bD << 1;
+            if (!punch)
+                hi |= (u32)bD << 1; // the opaque bit of the punch-through format stays clear
             hi |= (u32)bFlip;
             // selector -> modifier code {3, 2, 0, 1}, scattered through the flip table then column-major
             u32 codes = 0; // 2 bits per pixel position
@@ -1074,6 +1176,233 @@ __global__ __launch_bounds__(512) void cvttmi_etc2_color_kernel(const uint8_t *_
             outHi = hi;
             outLo = lo;
         }
+    };
+
+    if (!(PUNCH && groupAll))
+        clusterFit(false);
+
+    // ============ punch-through: "virtual T mode" x2 and the punch-through cluster fit (ETC.cpp:1865-1886) ============
+    if (PUNCH && groupAny)
+    {
+        if (transMask != 0)
+            bestError = FLT_MAX; // blocks with a transparent pixel start over; opaque blocks keep their opaque result
+        for (int call = 0; call < 2; call++)
+        {
+            // EncodeVirtualTModePunchthrough, ETC.cpp:887-1264: T mode (isolated colour, line colour +/- m) and H mode
+            // (line colour +/- m, second colour - m) with the remaining paint colour replaced by "transparent"
+            const u32 base = call == 0 ? isolatedMask : (~isolatedMask & 0xffffu);
+            const u32 iso = base & ~transMask, line = ~base & ~transMask & 0xffffu;
+            int isolatedTotal[3] = {0, 0, 0}, lineTotal[3] = {0, 0, 0};
+#pragma unroll
+            for (int px = 0; px < 16; px++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    const int v = S.pix[px][ch];
+                    if ((iso >> px) & 1u)
+                        isolatedTotal[ch] += v;
+                    if ((line >> px) & 1u)
+                        lineTotal[ch] += v;
+                }
+            const int numIsolated = __popc(iso), numLine = __popc(line);
+            const int isoAddend = (numIsolated << 4) | numIsolated;
+            int isoQ[3], isoColor[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+            {
+                isoQ[ch] = numIsolated == 0 ? 0 : udivSmall(isolatedTotal[ch] + isolatedTotal[ch] + isoAddend, numIsolated * 34);
+                isoColor[ch] = isoQ[ch] | (isoQ[ch] << 4);
+            }
+            {
+                const int px = lane & 15;
+                const float e = E(isoColor[0], isoColor[1], isoColor[2], S.pix[px], S.pw[px]);
+                S.isoErr[px] = ((transMask >> px) & 1u) ? 0.0f : e;
+            }
+            // H-mode second colour per table and its error per pixel: lane = (table & 3) * 16 + pixel, two rounds
+#pragma unroll
+            for (int half = 0; half < 2; half++)
+            {
+                const int table = half * 4 + (lane >> 4), px = lane & 15;
+                const int modifier = T->thDistance[table];
+                int hq[3], hc[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    const int offsetTotal = isolatedTotal[ch] + modifier * numIsolated;
+                    int q = numIsolated == 0 ? 0 : udivSmall(offsetTotal + offsetTotal + isoAddend, numIsolated * 34);
+                    q = q < 15 ? q : 15;
+                    hq[ch] = q;
+                    const int u = (q << 4) | q;
+                    hc[ch] = u - modifier > 0 ? u - modifier : 0;
+                }
+                const float e = E(hc[0], hc[1], hc[2], S.pix[px], S.pw[px]);
+                S.u.h.err[table][px] = ((transMask >> px) & 1u) ? 0.0f : e;
+                if (px == 0)
+                    S.u.h.color[0][table] = (unsigned short)((hq[0] << 10) | (hq[1] << 5) | hq[2]);
+            }
+            // the premultiplier of the line colours walks the GROUP's range in steps of two, clamped to the block's own
+            // range (ETC.cpp:1025-1040): the candidates depend on the group maximum of the line-pixel counts
+            if (lane == 0)
+                groupTCount[wave][0] = numLine;
+            __syncthreads();
+            int clusterMaxLine = 0;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; w8++)
+                clusterMaxLine = groupTCount[w8][0] > clusterMaxLine ? groupTCount[w8][0] : clusterMaxLine;
+            __syncthreads();
+            if (lane < 8)
+            {
+                const int modifierOffset = T->thDistance[lane] * 2;
+                const int lineDivisor = numLine * 34;
+                const int lineAddend = (numLine << 4) | numLine;
+                int n = 0, last = -1;
+                for (int k = -clusterMaxLine; k <= clusterMaxLine; k += 2)
+                {
+                    int kc = k < numLine ? k : numLine;
+                    kc = kc > -numLine ? kc : -numLine;
+                    const int modifierAddend = (int)(short)(kc * modifierOffset);
+                    int q[3];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                    {
+                        int numerator = (int)(short)((int)(short)(lineTotal[ch] + lineTotal[ch] + lineAddend) + modifierAddend);
+                        numerator = numerator < 0 ? 0 : numerator;
+                        const int divided = lineDivisor == 0 ? 0 : udivSmall(numerator, lineDivisor);
+                        q[ch] = divided < 15 ? divided : 15;
+                    }
+                    const int packed = (q[0] << 10) | (q[1] << 5) | q[2];
+                    if (n == 0 || packed != last)
+                    {
+                        S.tColors[lane][n++] = (unsigned short)packed;
+                        last = packed;
+                    }
+                }
+                S.tCount[lane] = n;
+                groupTCount[wave][lane] = n;
+            }
+            __syncthreads();
+            int prefix[9];
+            prefix[0] = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+            {
+                int mx = 0;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; w8++)
+                    mx = groupTCount[w8][t] > mx ? groupTCount[w8][t] : mx;
+                prefix[t + 1] = prefix[t] + mx;
+            }
+            __syncthreads();
+
+            // candidate `id` = (table, ci) in the reference's order; own colours, then (hazard H2) one zero slot, then
+            // copies of colour 0
+            auto candidateOf = [&](int id, int &table) -> int {
+                table = 0;
+#pragma unroll
+                for (int t = 1; t < 8; t++)
+                    if (id >= prefix[t])
+                        table = t;
+                const int ci = id - prefix[table];
+                const int n = S.tCount[table];
+                return ci < n ? S.tColors[table][ci] : (ci == n ? 0 : S.tColors[table][0]);
+            };
+            float candErr = FLT_MAX;
+            int candId = 0x7fffffff;
+            bool candH = false;
+            for (int idBase = 0; idBase < prefix[8]; idBase += 64)
+            {
+                const int id = idBase + lane;
+                if (id < prefix[8])
+                {
+                    int table;
+                    const int packed = candidateOf(id, table);
+                    const int modifier = T->thDistance[table];
+                    int lc[2][3];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                    {
+                        const int q = (packed >> (10 - ch * 5)) & 15;
+                        const int u = (q << 4) | q;
+                        lc[0][ch] = u + modifier < 255 ? u + modifier : 255;
+                        lc[1][ch] = u - modifier > 0 ? u - modifier : 0;
+                    }
+                    float tErr = 0.0f, hErr = 0.0f;
+                    for (int px = 0; px < 16; px++)
+                    {
+                        const float e0 = E(lc[0][0], lc[0][1], lc[0][2], S.pix[px], S.pw[px]);
+                        const float e1 = E(lc[1][0], lc[1][1], lc[1][2], S.pix[px], S.pw[px]);
+                        const float le = ((transMask >> px) & 1u) ? 0.0f : sseMin(e0, e1);
+                        tErr = tErr + sseMin(le, S.isoErr[px]);
+                        hErr = hErr + sseMin(le, S.u.h.err[table][px]);
+                    }
+                    // H mode stores the order of its two colours in the low table bit and cannot swap them here
+                    const bool hLegal = (packed < (int)S.u.h.color[0][table]) == ((table & 1) == 0);
+                    const bool useH = (hErr < tErr) && hLegal;
+                    const float roundBest = useH ? hErr : tErr;
+                    if (roundBest < candErr)
+                    {
+                        candErr = roundBest;
+                        candId = id;
+                        candH = useH;
+                    }
+                }
+            }
+            float wErr = candErr;
+            int wId = candId;
+            waveArgmin(wErr, wId);
+            if (wErr < bestError)
+            {
+                bestError = wErr;
+                const bool useH = __shfl((int)candH, wId & 63) != 0;
+                int table;
+                const int packed = candidateOf(wId, table);
+                const int modifier = T->thDistance[table];
+                const int packedH2 = (int)S.u.h.color[0][table];
+                int lc[2][3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    const int q = (packed >> (10 - ch * 5)) & 15;
+                    const int u = (q << 4) | q;
+                    lc[0][ch] = u + modifier < 255 ? u + modifier : 255;
+                    lc[1][ch] = u - modifier > 0 ? u - modifier : 0;
+                }
+                u32 selectors = 0;
+                for (int px = 0; px < 16; px++)
+                {
+                    const float e0 = E(lc[0][0], lc[0][1], lc[0][2], S.pix[px], S.pw[px]);
+                    const float e1 = E(lc[1][0], lc[1][1], lc[1][2], S.pix[px], S.pw[px]);
+                    const bool tr = ((transMask >> px) & 1u) != 0;
+                    const float le = tr ? 0.0f : sseMin(e0, e1);
+                    u32 sel = (e0 <= e1) ? 1u : 3u;
+                    if ((useH ? S.u.h.err[table][px] : S.isoErr[px]) < le)
+                        sel = 0u;
+                    if (tr)
+                        sel = 2u;
+                    selectors |= sel << (px * 2);
+                }
+                if (useH)
+                {
+                    // T: C1, C2+M, transparent, C2-M  ->  H: C1+M, C1-M, transparent, C2-M (ETC.cpp:1232-1251)
+                    u32 sectorBits = 0, signBits = 0;
+#pragma unroll
+                    for (int px = 0; px < 16; px++)
+                    {
+                        const u32 sel = (selectors >> (px * 2)) & 3u;
+                        sectorBits |= ((sel & 1u) ^ 1u) << px;             // {1, 0, 1, 0}
+                        signBits |= ((0x9u >> sel) & 1u) << px;            // {1, 0, 0, 1}
+                    }
+                    emitH(outHi, outLo, packed, packedH2, sectorBits, signBits, table, false);
+                }
+                else
+                {
+                    const int lineColor[3] = {(packed >> 10) & 15, (packed >> 5) & 15, packed & 15};
+                    emitT(outHi, outLo, lineColor, isoQ, selectors, table, false);
+                }
+            }
+            WAVE_SYNC();
+        }
+        clusterFit(true);
     }
 
     DBG_TAP(4);
@@ -1270,7 +1599,7 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
 extern "C" hipError_t cvttmi_launch_etc2(const void *d_blocks, void *d_out, const CvttEtcArgs *args,
                                          const CvttDeviceTables *d_tables, int mode, hipStream_t stream)
 {
-    // mode 0: RGB (8 B), 1: RGBA = [alpha | colour] (16 B), 2: alpha only (8 B), 3: ETC1 (8 B)
+    // mode 0: RGB (8 B), 1: RGBA = [alpha | colour] (16 B), 2: alpha only (8 B), 3: ETC1 (8 B), 4: punch-through alpha (8 B)
     if (args->numBlocks == 0)
         return hipSuccess;
     CvttEtcArgs a = *args;
@@ -1278,14 +1607,21 @@ extern "C" hipError_t cvttmi_launch_etc2(const void *d_blocks, void *d_out, cons
     if (mode == 3)
     {
         a.outOffset = 0u;
-        hipLaunchKernelGGL(cvttmi_etc2_color_kernel<true>, dim3(a.numBlocks / 8u), dim3(512), 0, stream, (const uint8_t *)d_blocks,
+        hipLaunchKernelGGL(cvttmi_etc2_color_kernel<1>, dim3(a.numBlocks / 8u), dim3(512), 0, stream, (const uint8_t *)d_blocks,
+                           (uint8_t *)d_out, a, d_tables);
+        return hipGetLastError();
+    }
+    if (mode == 4)
+    {
+        a.outOffset = 0u;
+        hipLaunchKernelGGL(cvttmi_etc2_color_kernel<2>, dim3(a.numBlocks / 8u), dim3(512), 0, stream, (const uint8_t *)d_blocks,
                            (uint8_t *)d_out, a, d_tables);
         return hipGetLastError();
     }
     if (mode != 2)
     {
         a.outOffset = (mode == 1) ? 8u : 0u;
-        hipLaunchKernelGGL(cvttmi_etc2_color_kernel<false>, dim3(a.numBlocks / 8u), dim3(512), 0, stream, (const uint8_t *)d_blocks,
+        hipLaunchKernelGGL(cvttmi_etc2_color_kernel<0>, dim3(a.numBlocks / 8u), dim3(512), 0, stream, (const uint8_t *)d_blocks,
                            (uint8_t *)d_out, a, d_tables);
     }
     if (mode != 0)

@@ -790,6 +790,13 @@ extern "C"
         }
         args.flags = options->flags;
         args.numBlocks = static_cast<uint32_t>(numBlocks);
+        {
+            // punch-through: alpha below floor(clamp(threshold, 0, 1) * 255 + 1) is transparent (reference ETC.cpp:1672-1675)
+            float t = options->threshold;
+            t = 1.0f < t ? 1.0f : t;
+            t = t > 0.0f ? t : 0.0f;
+            args.alphaThreshold = static_cast<uint16_t>(floorf(t * 255.0f + 1.0f));
+        }
         args.debug = getenv("CVTTMI_ETC_DEBUG_PTR") ? strtoull(getenv("CVTTMI_ETC_DEBUG_PTR"), NULL, 0) : 0;
         if (ctx->timing)
             hipEventRecord(ctx->evStart, stream);
@@ -844,6 +851,10 @@ extern "C"
     { return etc2Device(ctx, d_out, d_blocks, numBlocks, options, 1, hipStream); }
     int cvttmi_encode_etc2_alpha_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, void *hipStream)
     { return etc2Device(ctx, d_out, d_blocks, numBlocks, options, 2, hipStream); }
+    int cvttmi_encode_etc2_punchthrough_alpha_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, void *hipStream)
+    { return etc2Device(ctx, d_out, d_blocks, numBlocks, options, 4, hipStream); }
+    int cvttmi_encode_etc2_punchthrough_alpha(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options)
+    { return etc2Host(ctx, out, blocks, numBlocks, options, 4); }
     int cvttmi_encode_etc1_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, void *hipStream)
     { return etc2Device(ctx, d_out, d_blocks, numBlocks, options, 3, hipStream); }
     int cvttmi_encode_etc1(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options)

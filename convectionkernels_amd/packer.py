@@ -2,12 +2,12 @@
 
     python -m convectionkernels_amd.packer [-format F] [-uniform] [-quality Q] [-dds] input output
 
-The command line follows the reference's example packer (etc2packer.cpp:44-105: `-format etc1|etc2rgb|etc2rgba|r11u|r11s`,
+The command line follows the reference's example packer (etc2packer.cpp:44-105: `-format etc1|etc2rgb|etc2rgba|etc2punchthrough|r11u|r11s`,
 `-uniform`, input, output; default etc2rgb, KTX output) and adds the BC formats (bc1..bc5, bc7; `-dds` for a DX10 DDS
 file, `-quality 1..100` for a BC7 plan).  The image is uploaded once; tiling into groups of eight 4x4 blocks with
 edge clamping (etc2packer.cpp:215-248), encoding and the removal of padding blocks all run on the device, and the
 packed blocks are already in container order.  The input is anything PIL opens, or a .npy of shape (H, W, 4) uint8.
-`-fakebt709` and `etc2punchthrough` are not implemented by the kernels and are refused."""
+`-fakebt709` is not implemented by the kernels and is refused."""
 import sys
 
 import numpy as np
@@ -52,8 +52,6 @@ def encode_file(image, fmt, options=None, plan=None, ctx=None):
         blocks, bw, bh, gw = r11_blocks(image, fmt == "r11s")
         packed = ctx.encode_etc2_alpha11(blocks, signed=(fmt == "r11s"), options=options)
         return np.asarray(packed).reshape(bh, gw, 8)[:, :bw].reshape(-1, 8)
-    if fmt == "etc2punchthrough":
-        raise api.CvttError("EncodeETC2PunchthroughAlpha is not implemented on the GPU path")
     dev = torch.from_numpy(image).cuda(ctx.device)
     packed = ctx.encode_image(fmt, dev, options, plan)
     torch.cuda.synchronize(ctx.device)

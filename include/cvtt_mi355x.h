@@ -176,6 +176,17 @@ int cvttmi_encode_etc1_device(cvttmi_context *ctx, void *d_out, const void *d_bl
 int cvttmi_encode_etc1(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
                        const cvttmi_options *options);
 
+/* replaces cvtt::Kernels::EncodeETC2PunchthroughAlpha (ConvectionKernels_API.cpp:231-244 -> CompressETC2Block with
+ * punchthroughAlpha = true, ConvectionKernels_ETC.cpp:1664-1887; EncodeVirtualTModePunchthrough 887-1264;
+ * CompressETC1PunchthroughBlockInternal 2885-3082): GL_COMPRESSED_RGB8_PUNCHTHROUGH_ALPHA1_ETC2 blocks, 8 B each.
+ * A pixel is transparent when alpha < floor(clamp(options->threshold, 0, 1) * 255 + 1).  Group g = blocks [8g, 8g+8)
+ * keeps the reference's coupling: one transparent pixel anywhere in the group sends all eight blocks through the
+ * punch-through modes as well, and the virtual-T candidate lists depend on the group's pixel counts. */
+int cvttmi_encode_etc2_punchthrough_alpha_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
+                                                 const cvttmi_options *options, void *hipStream);
+int cvttmi_encode_etc2_punchthrough_alpha(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
+                                          const cvttmi_options *options);
+
 /* ---- host-buffer convenience entry points: stage through pinned memory, launch, copy
  * back, synchronise.  Same semantics as the *_device calls. ---- */
 int cvttmi_encode_bc7(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,

@@ -228,3 +228,32 @@ def alpha_structure_blocks(seed, n):
             v = rng.integers(0, 256, (16, 4))
         out[b] = v
     return out
+
+
+def punchthrough_blocks(seed, groups_per_kind=4):
+    """(N,16,4) uint8 for the punch-through (RGB8A1) encoder: mixed colour content whose alpha channel walks through
+    the cases the reference distinguishes -- sparse / dense random cut-outs, fully transparent groups, one fully
+    transparent block or a single transparent pixel in an otherwise opaque group (which still sends all eight blocks
+    through the punch-through modes), transparent halves (the "ignorable" half-block of either flip), soft alpha
+    around the threshold, and all-opaque groups."""
+    rng = _rng(seed)
+    parts = []
+
+    def colour(i):
+        return mixed_ldr_blocks(seed * 131 + i, groups_per_kind)[: groups_per_kind * 8].copy()
+
+    for i, density in enumerate((0.05, 0.3, 0.7, 0.95)):
+        b = colour(i)
+        b[..., 3] = np.where(rng.random(b.shape[:2]) < density, 0, 255)
+        parts.append(b)
+    b = colour(10); b[..., 3] = 0; parts.append(b)
+    b = colour(11); b[..., 3] = 255; b[::8, :, 3] = 0; parts.append(b)
+    b = colour(12); b[..., 3] = 255; b[3::8, 5, 3] = 0; parts.append(b)
+    b = colour(13); b[..., 3] = 255; b[:, :8, 3] = 0; parts.append(b)
+    b = colour(14); b[..., 3] = 255; b[:, [0, 1, 4, 5, 8, 9, 12, 13], 3] = 0; parts.append(b)
+    b = colour(15); b[..., 3] = 255; b[:, 8:, 3] = 0; parts.append(b)
+    b = colour(16); b[..., 3] = 255; b[:, [2, 3, 6, 7, 10, 11, 14, 15], 3] = 0; parts.append(b)
+    b = colour(17); b[..., 3] = rng.integers(120, 136, b.shape[:2]); parts.append(b)
+    b = colour(18); b[..., 3] = 255; parts.append(b)
+    b = colour(19); parts.append(b)  # whatever alpha the mixed content carries
+    return np.concatenate(parts)

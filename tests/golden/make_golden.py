@@ -156,6 +156,16 @@ def main():
         e2["opt_" + name] = o
         for mode, tag in ((0, "rgb"), (1, "rgba"), (2, "alpha"), (3, "etc1")):
             e2["out_%s_%s" % (tag, name)] = ref.encode_etc2(etc_blocks, o, mode)
+    # punch-through alpha (EncodeETC2PunchthroughAlpha): cut-out structures x thresholds / metrics
+    e2["pt_blocks"] = content.punchthrough_blocks(17, 2)
+    for name, o in {
+        "default": P.make_options(),
+        "uniform_t025": P.make_options(flags=P.FLAGS_DEFAULT | P.FLAG_UNIFORM, threshold=0.25),
+        "weights_t0": P.make_options(weights=(1.0, 0.3, 2.0, 1.0), threshold=0.0),
+        "t1": P.make_options(threshold=1.0),
+    }.items():
+        e2["pt_opt_" + name] = o
+        e2["pt_out_" + name] = ref.encode_etc2(e2["pt_blocks"], o, 4)
     # EAC R11 (EncodeETC2Alpha11), unsigned and signed, incl. out-of-range inputs (the reference clamps)
     e2["r11_blocks"] = content.mixed_r11_blocks(11, 64)
     e2["r11_unsigned"] = ref.encode_eac11(e2["r11_blocks"], P.make_options(), False)

@@ -21,6 +21,35 @@ def test_oracle_golden(oracle_lib, name):
         assert bad.size == 0, (tag, bad[:8])
 
 
+PT_NAMES = ["default", "uniform_t025", "weights_t0", "t1"]
+
+
+@pytest.mark.parametrize("name", PT_NAMES)
+def test_oracle_golden_punchthrough(oracle_lib, name):
+    g = np.load(os.path.join(GOLD, "etc2_mixed.npz"))
+    out = oracle_lib.encode_etc2(g["pt_blocks"], g["pt_opt_" + name], 4, threads=8)
+    bad = np.nonzero((out != g["pt_out_" + name]).any(axis=1))[0]
+    assert bad.size == 0, bad[:8]
+
+
+def test_punchthrough_goldens_cover_the_modes():
+    """opaque and non-opaque blocks, and among the latter differential, T and H layouts"""
+    g = np.load(os.path.join(GOLD, "etc2_mixed.npz"))
+    out = g["pt_out_default"]
+    opaque = (out[:, 3] >> 1) & 1
+    assert (opaque == 1).any() and (opaque == 0).any()
+    # non-opaque blocks: R / G overflow patterns select T and H mode (ETC.cpp:2414-2563)
+    r = out[:, 0].astype(int)
+    r_sum = (r >> 3) + ((((r & 7) ^ 4) - 4))
+    assert ((opaque == 0) & ((r_sum < 0) | (r_sum > 31))).any()
+
+
+def test_oracle_punchthrough_vs_reference(oracle_lib, ref_lib):
+    blocks = content.punchthrough_blocks(23, 1)
+    for opt in (pyref.make_options(), pyref.make_options(flags=pyref.FLAG_UNIFORM, threshold=0.75)):
+        assert (oracle_lib.encode_etc2(blocks, opt, 4, 8) == ref_lib.encode_etc2(blocks, opt, 4)).all()
+
+
 def test_oracle_known_answers(oracle_lib):
     g = np.load(os.path.join(GOLD, "known_answers.npz"))
     out = oracle_lib.encode_etc2(g["blocks"], pyref.make_options(), 1)
@@ -50,6 +79,29 @@ def test_t_mode_group_coupling(oracle_lib):
 
 
 # ------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", PT_NAMES)
+def test_gpu_golden_punchthrough(gpu_ctx, name):
+    from convectionkernels_amd import api
+    g = np.load(os.path.join(GOLD, "etc2_mixed.npz"))
+    out = gpu_ctx.encode_etc2_punchthrough_alpha(g["pt_blocks"], api.Options.frombytes(g["pt_opt_" + name]))
+    bad = np.nonzero((out != g["pt_out_" + name]).any(axis=1))[0]
+    assert bad.size == 0, bad[:8]
+
+
+@pytest.mark.gpu
+def test_gpu_punchthrough_vs_oracle(gpu_ctx, oracle_lib):
+    """larger run on the device path: cut-out structures + config-4 noise (alpha random -> half the pixels transparent)"""
+    import torch
+    from convectionkernels_amd import api
+    blocks = np.concatenate([content.punchthrough_blocks(29, 8), content.config_blocks(4, 256, 256)])
+    for thr in (0.5, 0.02):
+        exp = oracle_lib.encode_etc2(blocks, pyref.make_options(threshold=thr), 4, threads=8)
+        out = gpu_ctx.encode_etc2_punchthrough_alpha(torch.from_numpy(blocks).cuda(), api.Options(threshold=thr)).cpu().numpy()
+        bad = np.nonzero((out != exp).any(axis=1))[0]
+        assert bad.size == 0, bad[:8]
+
+
 def _enc(ctx, mode):
     return {0: ctx.encode_etc2, 1: ctx.encode_etc2_rgba, 2: ctx.encode_etc2_alpha, 3: ctx.encode_etc1}[mode]
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel timing of one format on synthetic BASELINE-style input (developer tool, GPU box).
-   python tools/fmt_bench.py bc7|bc7o|bc1|bc1x|bc2|bc3|bc4|bc5|bc6hu|bc6hs|etc1|etc2|etc2rgba|eac [size] [reps]   (bc1x = BC1 with Flags::Better)"""
+   python tools/fmt_bench.py bc7|bc7o|bc1|bc1x|bc2|bc3|bc4|bc5|bc6hu|bc6hs|etc1|etc2|etc2pt|etc2rgba|eac [size] [reps]   (bc1x = BC1 with Flags::Better)"""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,7 +10,7 @@ fmt = sys.argv[1]
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 ctx = api.Context(0)
-if fmt in ("bc7", "bc7o", "bc1", "bc1x", "bc2", "bc3", "bc4", "bc5", "etc1", "etc2", "etc2rgba", "eac"):
+if fmt in ("bc7", "bc7o", "bc1", "bc1x", "bc2", "bc3", "bc4", "bc5", "etc1", "etc2", "etc2pt", "etc2rgba", "eac"):
     b = synth.tile_blocks(synth.image_rgba8(2, size, size, opaque=(fmt == "bc7o")))
 else:
     b = synth.tile_blocks(synth.image_f16bits(3, size, size))
@@ -20,7 +20,7 @@ enc = {"bc7": ctx.encode_bc7, "bc7o": ctx.encode_bc7, "bc1": ctx.encode_bc1,
        "bc6hu": lambda x, out=None: ctx.encode_bc6h(x, signed=False, out=out),
        "bc6hs": lambda x, out=None: ctx.encode_bc6h(x, signed=True, out=out),
        "bc2": ctx.encode_bc2, "bc3": ctx.encode_bc3, "bc4": ctx.encode_bc4, "bc5": ctx.encode_bc5,
-       "etc1": ctx.encode_etc1, "etc2": ctx.encode_etc2, "etc2rgba": ctx.encode_etc2_rgba, "eac": ctx.encode_etc2_alpha}[fmt]
+       "etc1": ctx.encode_etc1, "etc2pt": ctx.encode_etc2_punchthrough_alpha, "etc2": ctx.encode_etc2, "etc2rgba": ctx.encode_etc2_rgba, "eac": ctx.encode_etc2_alpha}[fmt]
 o = enc(t); torch.cuda.synchronize()
 ms = []
 for _ in range(reps):
