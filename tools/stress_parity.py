@@ -2,7 +2,8 @@
 """One-off differential stress test (GPU box): large vectorised content families through the HIP kernels and
 through the real reference (oracle/_ref, all host threads), every block compared.  Catches events too rare for
 the unit tests (the sqrt rounding case was 1 block in 2 million).
-    python tools/stress_parity.py [blocks_per_family]"""
+    python tools/stress_parity.py [blocks_per_family] [all|bc7|ldr|hdr|rows]
+"rows" = the formats / flags added after the first four: BC1-BC3 with S3TC_Exhaustive, BC2-BC5, ETC1, ETC2 punch-through, R11."""
 import os, sys, time, threading
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,6 +13,7 @@ from convectionkernels_amd import api
 from oracle import pyref
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 17
+STAGE = sys.argv[2] if len(sys.argv) > 2 else "all"
 rng = np.random.Generator(np.random.PCG64(2026))
 yy, xx = np.divmod(np.arange(16), 4)
 
@@ -69,7 +71,7 @@ def main():
     fam = families(N)
     bc7_opts = {"default": api.Options(), "better": api.Options(flags=api.Flags.Better), "uniform": api.Options(flags=api.Flags.Default | api.Flags.Uniform),
                 "ultra+pt": api.Options(flags=api.Flags.Ultra | api.Flags.BC7_RespectPunchThrough)}
-    for oname, opt in bc7_opts.items():
+    for oname, opt in (bc7_opts.items() if STAGE in ("all", "bc7") else ()):
         ob = np.frombuffer(opt.tobytes(), np.uint8).copy()
         for name, b in fam.items():
             if oname != "default" and name in ("noise", "opaque noise"):
@@ -81,7 +83,7 @@ def main():
             total_bad += bad
             print("BC7 %-9s %-20s %8d blocks  mismatches %d  (%.1f s)" % (oname, name, b.shape[0], bad, time.time() - t0), flush=True)
     o = pyref.make_options()
-    for name, b in fam.items():
+    for name, b in (fam.items() if STAGE in ("all", "ldr") else ()):
         b = b[: N // 2]
         g = ctx.encode_bc1(torch.from_numpy(b).cuda()).cpu().numpy()
         r = ref_parallel(lambda x: ref.encode_bc1(x, o), b, 8, threads)
@@ -96,7 +98,7 @@ def main():
     h = rng.integers(0, 0x7C00, (n6, 16, 4)).astype(np.uint16); h[:, :, 3] = 0x3C00
     base = rng.integers(0x3000, 0x7000, (n6, 1, 3)); nar = (base + rng.integers(-60, 61, (n6, 16, 3))).astype(np.uint16)
     h2 = np.zeros((n6, 16, 4), np.uint16); h2[:, :, :3] = nar; h2[:, :, 3] = 0x3C00
-    for name, hb in (("wide noise", h), ("narrow", h2)):
+    for name, hb in ((("wide noise", h), ("narrow", h2)) if STAGE in ("all", "hdr") else ()):
         for sg in (False, True):
             hb2 = hb.copy()
             if sg:
@@ -106,6 +108,35 @@ def main():
             r = ref_parallel(lambda x: canon.encode_bc6h(x, o, sg), b, 16, threads)
             bad = int((g != r).any(axis=1).sum()); total_bad += bad
             print("BC6H%s %-24s %8d blocks  mismatches %d" % ("S" if sg else "U", name, b.shape[0], bad), flush=True)
+    if STAGE in ("all", "rows"):
+        better = pyref.make_options(flags=pyref.FLAGS_BETTER)
+        gpu_better = api.Options(flags=api.Flags.Better)
+        for name, b in fam.items():
+            b = b[: N // 4]
+            t = torch.from_numpy(b).cuda()
+            checks = [
+                ("BC1 exhaustive", lambda: ctx.encode_bc1(t, gpu_better), lambda x: ref.encode_bc1(x, better), 8, N // 16),
+                ("BC3 exhaustive", lambda: ctx.encode_bc3(t, gpu_better), lambda x: ref.encode_s3tc(x, better, 3), 16, N // 16),
+                ("BC2", lambda: ctx.encode_bc2(t), lambda x: ref.encode_s3tc(x, o, 2), 16, None),
+                ("BC3", lambda: ctx.encode_bc3(t), lambda x: ref.encode_s3tc(x, o, 3), 16, None),
+                ("BC4U", lambda: ctx.encode_bc4(t), lambda x: ref.encode_s3tc(x, o, 4), 8, None),
+                ("BC5S", lambda: ctx.encode_bc5(t, signed=True), lambda x: ref.encode_s3tc(x, o, 7), 16, None),
+                ("ETC1", lambda: ctx.encode_etc1(t), lambda x: canon.encode_etc2(x, o, 3), 8, None),
+                ("ETC2 punch-through", lambda: ctx.encode_etc2_punchthrough_alpha(t), lambda x: canon.encode_etc2(x, o, 4), 8, None),
+            ]
+            for label, gfn, rfn, per, limit in checks:
+                g = gfn().cpu().numpy()
+                m = b.shape[0] if limit is None else min(limit, b.shape[0])
+                m -= m % 8
+                r = ref_parallel(rfn, b[:m], per, threads)
+                bad = int((g[:m] != r).any(axis=1).sum()); total_bad += bad
+                print("%-20s %-22s %8d blocks  mismatches %d" % (label, name, m, bad), flush=True)
+        r11 = rng.integers(-1500, 2600, (N // 4, 16)).astype(np.int16)
+        for sg in (False, True):
+            g = ctx.encode_etc2_alpha11(r11, signed=sg)
+            r = ref_parallel(lambda x: ref.encode_eac11(x, o, sg), r11, 8, threads)
+            bad = int((np.asarray(g) != r).any(axis=1).sum()); total_bad += bad
+            print("R11 %-37s %8d blocks  mismatches %d" % ("signed" if sg else "unsigned", r11.shape[0], bad), flush=True)
     print("TOTAL MISMATCHES", total_bad)
 
 
