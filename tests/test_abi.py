@@ -85,6 +85,14 @@ int main(int argc, char **argv)
     cvtt::BC7EncodingPlan plan;
     if (sizeof(options) != 44 || sizeof(plan) != 808 || options.refineRoundsIIC != 8 || !plan.mode6Enabled)
         return 2;
+    // plan configuration is host-side: works without a device
+    cvtt::BC7FineTuningParams ft;
+    cvtt::BC7EncodingPlan qplan, fplan;
+    cvtt::Kernels::ConfigureBC7EncodingPlanFromQuality(qplan, 20);
+    if (sizeof(ft) != 285 || ft.mode6SP != 4 || !cvtt::Kernels::ConfigureBC7EncodingPlanFromFineTuningParams(fplan, ft))
+        return 3;
+    if (fplan.rgbNumShapesToEvaluate != 242 || qplan.rgbaNumShapesToEvaluate == 0 || qplan.rgbaNumShapesToEvaluate >= 129)
+        return 4;
     if (argc < 2)
         return 0; // layout check only
     cvtt::PixelBlockU8 in[cvtt::NumParallelBlocks];
@@ -98,7 +106,7 @@ int main(int argc, char **argv)
                 in[b].m_pixels[p][c] = (uint8_t)v;
                 hdr[b].m_pixels[p][c] = (int16_t)(c == 3 ? 0x3C00 : (((8 + (b + p + c) % 12) << 10) | ((131 * b + 61 * p + 17 * c + 7 * p * p) & 0x3FF)));
             }
-    uint8_t out[7][128];
+    uint8_t out[10][128];
     memset(out, 0, sizeof(out));
     cvtt::Kernels::EncodeBC7(out[0], in, options, plan);
     cvtt::Kernels::EncodeBC1(out[1], in, options);
@@ -109,7 +117,14 @@ int main(int argc, char **argv)
     cvtt::Kernels::EncodeETC2RGBA(out[5], in, options, data);
     cvtt::Kernels::ReleaseETC2Data(data, release);
     cvtt::Kernels::EncodeETC2Alpha(out[6], in, options);
-    for (int k = 0; k < 7; k++)
+    data = cvtt::Kernels::AllocETC2Data(allocate, NULL, options);
+    cvtt::Kernels::EncodeETC2PunchthroughAlpha(out[7], in, options, data);
+    cvtt::Kernels::ReleaseETC2Data(data, release);
+    cvtt::ETC1CompressionData *data1 = cvtt::Kernels::AllocETC1Data(allocate, NULL);
+    cvtt::Kernels::EncodeETC1(out[8], in, options, data1);
+    cvtt::Kernels::ReleaseETC1Data(data1, release);
+    cvtt::Kernels::EncodeBC7(out[9], in, options, qplan);
+    for (int k = 0; k < 10; k++)
     {
         for (int i = 0; i < 128; i++)
             printf("%02x", out[k][i]);
@@ -154,7 +169,11 @@ def test_cxx_api_matches_oracle(tmp_path, oracle_lib, gpu_ctx):
     rcp = api.Context(0).get_rcp_table()  # a fresh context's built-in table, as the C++ client's
     want = [oracle_lib.encode_bc7(ldr, o, plan, rcp), oracle_lib.encode_bc1(ldr, o, rcp),
             oracle_lib.encode_bc6h(hdr, o, signed=False, rcp=rcp), oracle_lib.encode_bc6h(hdr, o, signed=True, rcp=rcp),
-            oracle_lib.encode_etc2(ldr, o, mode=0), oracle_lib.encode_etc2(ldr, o, mode=1), oracle_lib.encode_etc2(ldr, o, mode=2)]
+            oracle_lib.encode_etc2(ldr, o, mode=0), oracle_lib.encode_etc2(ldr, o, mode=1), oracle_lib.encode_etc2(ldr, o, mode=2),
+            oracle_lib.encode_etc2(ldr, o, mode=4), oracle_lib.encode_etc2(ldr, o, mode=3)]
+    qplan = api.BC7EncodingPlan()
+    api.ConfigureBC7EncodingPlanFromQuality(qplan, 20)
+    want.append(oracle_lib.encode_bc7(ldr, o, np.frombuffer(bytes(qplan), np.uint8).copy(), rcp))
     for k, w in enumerate(want):
         got = bytes.fromhex(lines[k])[:w.size]
         assert got == w.tobytes(), k
