@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG/fmt
 mkdir -p $OUT
 : > $OUT/fmt_bench.jsonl
-for spec in "bc7 4096" "bc7o 2048" "bc1 4096" "bc6hu 2048" "bc6hs 2048" "etc2 4096" "etc2rgba 4096" "eac 4096"; do
+for spec in "bc7 4096" "bc7o 2048" "bc1 4096" "bc1x 2048" "bc2 4096" "bc3 4096" "bc4 4096" "bc5 4096" "bc6hu 2048" "bc6hs 2048" "etc1 2048" "etc2 4096" "etc2rgba 4096" "etc2pt 2048" "eac 4096"; do
   set -- $spec
   python tools/fmt_bench.py $1 $2 3 >> $OUT/fmt_bench.jsonl 2>> $OUT/fmt_bench.err
 done
