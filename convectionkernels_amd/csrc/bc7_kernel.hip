@@ -54,7 +54,8 @@ __device__ unsigned long long g_bc7Prof[48];
 #define PROF_FLUSH if (threadIdx.x == 0) { unsigned long long tot = 0; for (int i = 0; i < 8; i++) { atomicAdd(&g_bc7Prof[i], profAcc[i]); tot += profAcc[i]; } \
     int bucket = 63 - __builtin_clzll(tot | 1ull) - 12; bucket = bucket < 0 ? 0 : (bucket > 15 ? 15 : bucket); atomicAdd(&g_bc7Prof[16 + bucket], 1ull); \
     } { unsigned long long wsum[8]; for (int i = 0; i < 8; i++) { unsigned long long v = profCnt[i]; if (i >= 4) { for (int st = 1; st < 64; st <<= 1) v += __shfl_xor(v, st); } wsum[i] = v; } \
-    if (threadIdx.x == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_bc7Prof[32 + i], wsum[i]); }
+    if (threadIdx.x == 0) { for (int i = 0; i < 8; i++) atomicAdd(&g_bc7Prof[32 + i], wsum[i]); \
+    const unsigned long long passes = profCnt[2] / 64ull; int pb = 63 - __builtin_clzll(passes | 1ull); pb = pb > 7 ? 7 : pb; atomicAdd(&g_bc7Prof[40 + pb], 1ull); } }
 #define PROF_COUNT(slot, n) { profCnt[slot] += (unsigned long long)(n); }
 extern "C" int cvttmi_bc7_prof_read(unsigned long long *out)
 {
