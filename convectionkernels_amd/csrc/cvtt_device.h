@@ -39,6 +39,8 @@ struct CvttDeviceTables
     uint16_t subsetMask3[64][2];
     // BC1-family single-colour end points (tools/gen_s3tc_single_color.py): [paranoid*4 + (range==3)*2 + green][value] = {min, max, colour, span}
     uint8_t s3tcSingleColor[8][256][4];
+    // ETC_UseFakeBT709 rounding table (tools/gen_fake709_rounding.py): [r << 8 | g << 4 | b] = nearest cell corner
+    uint8_t fake709Rounding[4096];
 };
 
 // The caller's plan plus two bitmaps derived on the host: which shapes the plan's

@@ -85,12 +85,127 @@ __device__ __forceinline__ void waveArgmin(float &err, int &id)
     }
 }
 
+// ConvertToFakeBT709, ETC.cpp:2343-2352
+__device__ __forceinline__ void toFake709(float (&yuv)[3], float r, float g, float b)
+{
+    yuv[0] = r * 0.368233989135369f + g * 1.23876274963149f + b * 0.125054068802017f;
+    yuv[1] = r * 0.5f - g * 0.4541529f - b * 0.04584709f;
+    yuv[2] = r * -0.081014709086133f - g * 0.272538676238785f + b * 0.353553390593274f;
+}
+
+// the octant search shared by ResolveTHFakeBT709Rounding and ResolveHalfBlockFakeBT709RoundingAccurate
+// (ETC.cpp:2199-2231, 2304-2326): which of the 8 cell corners is nearest to `target`; the reference's error adds the
+// chroma-U difference twice instead of squaring it
+__device__ __forceinline__ int fakeOctant(const float (&lowF)[3], const float (&highF)[3], const float (&target)[3])
+{
+    float cum[3];
+    toFake709(cum, target[0], target[1], target[2]);
+    float bestError = FLT_MAX;
+    int bestOctant = 0;
+#pragma unroll
+    for (int octant = 0; octant < 8; octant++)
+    {
+        float oy[3];
+        toFake709(oy, (octant & 1) ? highF[0] : lowF[0], (octant & 2) ? highF[1] : lowF[1], (octant & 4) ? highF[2] : lowF[2]);
+        const float d0 = oy[0] - cum[0], d1 = oy[1] - cum[1], d2 = oy[2] - cum[2];
+        const float error = d0 * d0 + d1 + d1 + d2 * d2;
+        if (error < bestError)
+            bestOctant = octant;
+        bestError = sseMin(error, bestError);
+    }
+    return bestOctant;
+}
+
+// ResolveTHFakeBT709Rounding, ETC.cpp:2286-2327
+__device__ __forceinline__ void resolveTHFake(int (&quantized)[3], const int (&targets)[3], int granularity)
+{
+    float lowF[3], highF[3], tf[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+    {
+        const int unq = (quantized[ch] << 4) | quantized[ch];
+        const int next = unq + 17 < 255 ? unq + 17 : 255;
+        lowF[ch] = (float)(int)(short)((int)(short)(unq * granularity) << 1);
+        highF[ch] = (float)(int)(short)((int)(short)(next * granularity) << 1);
+        tf[ch] = (float)targets[ch];
+    }
+    const int octant = fakeOctant(lowF, highF, tf);
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+        quantized[ch] += (octant >> ch) & 1;
+}
+
+// ResolveHalfBlockFakeBT709RoundingAccurate / Fast, ETC.cpp:2157-2284
+__device__ __forceinline__ void resolveHalfFake(int (&quantized)[3], const int (&cumulative)[3], bool isDifferential, bool accurate,
+                                                const CvttDeviceTables *__restrict__ T)
+{
+    if (accurate)
+    {
+        float lowF[3], highF[3], tf[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+        {
+            const u32 cu = (u32)cumulative[ch];
+            int unq, next;
+            if (isDifferential)
+            {
+                quantized[ch] = (int)(((((cu << 5) - cu) + (cu >> 3)) & 0xffffu) >> 11);
+                unq = (quantized[ch] << 3) | (quantized[ch] >> 2);
+                const int qn = quantized[ch] + 1 < 31 ? quantized[ch] + 1 : 31;
+                next = (qn << 3) | (qn >> 2);
+            }
+            else
+            {
+                quantized[ch] = (int)(((((cu << 5) - ((cu << 1) & 0xffffu)) + (cu >> 3)) & 0xffffu) >> 12);
+                unq = (quantized[ch] << 4) | quantized[ch];
+                next = unq + 17 < 255 ? unq + 17 : 255;
+            }
+            lowF[ch] = (float)(unq << 3);
+            highF[ch] = (float)(next << 3);
+            tf[ch] = (float)cumulative[ch];
+        }
+        const int octant = fakeOctant(lowF, highF, tf);
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+            quantized[ch] += (octant >> ch) & 1;
+        return;
+    }
+    int fill[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+        fill[ch] = cumulative[ch] + (cumulative[ch] >> 8);
+    const int index = isDifferential ? (((fill[0] << 6) & 0xf00) | ((fill[1] << 4) & 0x0f0) | ((fill[2] >> 2) & 0x00f))
+                                     : (((fill[0] << 5) & 0xf00) | ((fill[1] << 1) & 0x0f0) | ((fill[2] >> 3) & 0x00f));
+    const int octant = T->fake709Rounding[index];
+    const int upper = isDifferential ? 31 : 15, shift = isDifferential ? 6 : 7;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+    {
+        const int q = (fill[ch] >> shift) + ((octant >> ch) & 1);
+        quantized[ch] = q < upper ? q : upper;
+    }
+}
+
 struct EtcErr
 {
     bool uniform;
     float rw, gw, bw;
-    // ComputeErrorUniform / ComputeErrorWeighted, ETC.cpp:59-80
+    bool fake;
+    // the metric of most call sites: ComputeErrorFakeBT709 (ETC.cpp:82-92) first, then uniform, then weighted
     __device__ __forceinline__ float operator()(int r, int g, int b, const int *px, const float *pw) const
+    {
+        if (fake)
+        {
+            float yuv[3];
+            toFake709(yuv, (float)r, (float)g, (float)b);
+            const float dy = yuv[0] - pw[0], du = yuv[1] - pw[1], dv = yuv[2] - pw[2];
+            return dy * dy + du * du + dv * dv;
+        }
+        return wu(r, g, b, px, pw);
+    }
+    // ComputeErrorUniform / ComputeErrorWeighted, ETC.cpp:59-80.  The line colours of the T modes are measured with
+    // this even under ETC_UseFakeBT709 (ETC.cpp:600, 1133, 1150), against pre-weighted pixels that then hold luma/chroma
+    __device__ __forceinline__ float wu(int r, int g, int b, const int *px, const float *pw) const
     {
         if (uniform)
         {
@@ -202,8 +317,8 @@ __device__ __forceinline__ void emitH(u32 &outHi, u32 &outLo, int bc0, int bc1, 
 } // namespace
 
 // ------------------------------------------------------------------------------------------
-// MODE 0: EncodeETC2 (RGB), 1: EncodeETC1, 2: EncodeETC2PunchthroughAlpha
-template <int MODE>
+// MODE 0: EncodeETC2 (RGB), 1: EncodeETC1, 2: EncodeETC2PunchthroughAlpha; FAKE: ETC_UseFakeBT709
+template <int MODE, bool FAKE>
 __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
                                                                const CvttEtcArgs A, const CvttDeviceTables *__restrict__ T)
 {
@@ -214,7 +329,8 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
     const int lane = threadIdx.x & 63;
     const u32 blockIndex = blockIdx.x * 8u + (u32)wave;
     EtcWaveShared &S = shared[wave];
-    const EtcErr E = {(A.flags & CVTTMI_FLAG_UNIFORM) != 0, A.rw, A.gw, A.bw};
+    const EtcErr E = {(A.flags & CVTTMI_FLAG_UNIFORM) != 0, A.rw, A.gw, A.bw, FAKE};
+    const bool fakeAccurate = (A.flags & CVTTMI_FLAG_ETC_FAKE_BT709_ACCURATE) != 0;
     constexpr bool ETC1 = MODE == 1, PUNCH = MODE == 2;
 
     // ---- load: pixel px by lane px.  Punch-through: pixels whose alpha is below the threshold are transparent and
@@ -230,9 +346,12 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
         S.pix[lane][0] = r;
         S.pix[lane][1] = g;
         S.pix[lane][2] = b;
-        S.pw[lane][0] = pxTransparent ? 0.0f : (E.uniform ? (float)r : (float)r * A.rw);
-        S.pw[lane][1] = pxTransparent ? 0.0f : (E.uniform ? (float)g : (float)g * A.gw);
-        S.pw[lane][2] = pxTransparent ? 0.0f : (E.uniform ? (float)b : (float)b * A.bw);
+        float pw3[3] = {E.uniform ? (float)r : (float)r * A.rw, E.uniform ? (float)g : (float)g * A.gw, E.uniform ? (float)b : (float)b * A.bw};
+        if (FAKE) // ExtractBlocks, ETC.cpp:2141-2142 (takes precedence over Uniform)
+            toFake709(pw3, (float)r, (float)g, (float)b);
+        S.pw[lane][0] = pxTransparent ? 0.0f : pw3[0];
+        S.pw[lane][1] = pxTransparent ? 0.0f : pw3[1];
+        S.pw[lane][2] = pxTransparent ? 0.0f : pw3[2];
     }
     const u32 transMask = PUNCH ? ((u32)__ballot(pxTransparent) & 0xffffu) : 0u;
     const int numOpaque = 16 - __popc(transMask);
@@ -277,7 +396,7 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
         for (int px = 0; px < 16; px++)
         {
             const float x = (float)(px & 3), y = (float)(px >> 2);
-            const float c = (float)S.pix[px][ch];
+            const float c = FAKE ? S.pw[px][ch] : (float)S.pix[px][ch];
             fhh += x * x; fhv += x * y; fho += x; fh = fh - c * x;
             fhv += y * x; fvv += y * y; fov += y; fv = fv - c * y;
             fho += x; fov += y; foo += 1.0f; fo = fo - c;
@@ -299,6 +418,59 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
         float hc = -g2D / d, vc = -l2D / k1;
         hc = hc * 4.0f + oc;
         vc = vc * 4.0f + oc;
+        float totalError = 0.0f;
+        int coeffs[3][3];
+        if (FAKE)
+        {
+            // ETC.cpp:1415-1474: the plane was fitted in luma/chroma; back to RGB, round to nearest, one candidate
+            float o3[3], h3[3], v3[3];
+#pragma unroll
+            for (int c3 = 0; c3 < 3; c3++)
+            {
+                o3[c3] = __shfl(oc, c3);
+                h3[c3] = __shfl(hc, c3);
+                v3[c3] = __shfl(vc, c3);
+            }
+            auto fromFake = [](float (&rgb)[3], const float (&yuv)[3]) { // ConvertFromFakeBT709, ETC.cpp:2354-2364
+                const float yy = yuv[0] * 0.57735026466774571071f;
+                rgb[0] = yy + yuv[1] * 1.5748000207960953486f;
+                rgb[1] = yy - yuv[1] * 0.46812425854364753669f - yuv[2] * 0.26491652528157560861f;
+                rgb[2] = yy + yuv[2] * 2.6242146882856944069f;
+            };
+            float oRGB[3], hRGB[3], vRGB[3];
+            fromFake(oRGB, o3);
+            fromFake(hRGB, h3);
+            fromFake(vRGB, v3);
+            int dO[3], hMinusO[3], vMinusO[3];
+#pragma unroll
+            for (int c3 = 0; c3 < 3; c3++)
+            {
+                const float fcoeffs[3] = {oRGB[c3], hRGB[c3], vRGB[c3]};
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                {
+                    float coeff = sseMax(0.0f, fcoeffs[c]);
+                    coeff = (c3 == 1) ? sseMin(127.0f, coeff * (127.0f / 255.0f)) : sseMin(63.0f, coeff * (63.0f / 255.0f));
+                    coeffs[c3][c] = (int)rintf(coeff);
+                }
+                dO[c3] = planarDecode(coeffs[c3][0], c3);
+                hMinusO[c3] = (int)(short)(planarDecode(coeffs[c3][1], c3) - dO[c3]);
+                vMinusO[c3] = (int)(short)(planarDecode(coeffs[c3][2], c3) - dO[c3]);
+            }
+            for (int px = 0; px < 16; px++)
+            {
+                int rec[3];
+#pragma unroll
+                for (int c3 = 0; c3 < 3; c3++)
+                {
+                    const int dec = (int)(short)((px & 3) * hMinusO[c3] + (px >> 2) * vMinusO[c3] + (int)(short)((dO[c3] << 2) + 2)) >> 2;
+                    rec[c3] = dec < 0 ? 0 : (dec > 255 ? 255 : dec);
+                }
+                totalError = totalError + E(rec[0], rec[1], rec[2], S.pix[px], S.pw[px]);
+            }
+        }
+        else
+        {
         if (lane < 3)
         {
             const float fcoeffs[3] = {oc, hc, vc};
@@ -346,7 +518,6 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
             cId = take ? oi : cId;
         }
         float chErr[3];
-        int coeffs[3][3];
 #pragma unroll
         for (int c3 = 0; c3 < 3; c3++)
         {
@@ -363,10 +534,10 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
                 chErr[c3] = chErr[c3] * (w * w);
             }
         }
-        float totalError = 0.0f;
         totalError = totalError + chErr[0];
         totalError = totalError + chErr[1];
         totalError = totalError + chErr[2];
+        }
         if (totalError < bestError)
         {
             bestError = totalError;
@@ -488,15 +659,20 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
                     isolatedTotal[ch] += v;
             }
         const int numLine = 16 - numIsolated;
-        int isoQ[3], isoColor[3];
+        int isoQ[3], isoColor[3], isoTargets[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ch++)
         {
             lineTotal[ch] -= isolatedTotal[ch];
-            const int numerator = isolatedTotal[ch] + isolatedTotal[ch] + ((numIsolated << 4) | numIsolated);
+            const int numerator = isolatedTotal[ch] + isolatedTotal[ch] + (FAKE ? 0 : ((numIsolated << 4) | numIsolated));
             isoQ[ch] = numIsolated == 0 ? 0 : udivSmall(numerator, numIsolated * 34);
-            isoColor[ch] = isoQ[ch] | (isoQ[ch] << 4);
+            isoTargets[ch] = numerator;
         }
+        if (FAKE)
+            resolveTHFake(isoQ, isoTargets, numIsolated); // may push a channel to 16 (ETC.cpp:453-454)
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+            isoColor[ch] = isoQ[ch] | (isoQ[ch] << 4);
         {
             const int px = lane & 15;
             S.isoErr[px] = E(isoColor[0], isoColor[1], isoColor[2], S.pix[px], S.pw[px]);
@@ -512,15 +688,21 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
             for (int k = -numLine; k <= numLine; k++)
             {
                 const int modifierAddend = (int)(short)(k * modifierOffset);
-                int packed = 0;
+                int packed = 0, q3[3], targets[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++)
                 {
-                    int numerator = (int)(short)((int)(short)(lineTotal[ch] + lineTotal[ch] + lineAddend) + modifierAddend);
+                    int numerator = (int)(short)((int)(short)(lineTotal[ch] + lineTotal[ch] + (FAKE ? 0 : lineAddend)) + modifierAddend);
                     numerator = numerator < 0 ? 0 : numerator;
                     const int divided = lineDivisor == 0 ? 0 : udivSmall(numerator, lineDivisor);
-                    packed |= (divided < 15 ? divided : 15) << (ch * 5);
+                    q3[ch] = divided < 15 ? divided : 15;
+                    targets[ch] = numerator;
                 }
+                if (FAKE)
+                    resolveTHFake(q3, targets, numLine);
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                    packed |= q3[ch] << (ch * 5);
                 if (n == 0 || packed != last)
                 {
                     S.tColors[lane][n++] = (unsigned short)packed;
@@ -582,7 +764,7 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
 #pragma unroll
                     for (int i = 0; i < 3; i++)
                     {
-                        const float e = E(lc[i][0], lc[i][1], lc[i][2], S.pix[px], S.pw[px]);
+                        const float e = E.wu(lc[i][0], lc[i][1], lc[i][2], S.pix[px], S.pw[px]); // sic: never the fake metric
                         if (e < pixelError)
                             sel = (u32)(i + 1);
                         pixelError = sseMin(e, pixelError);
@@ -837,6 +1019,19 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
                 {
                     const int off = T->clusterOffsets[start + oi];
                     int packed = 0;
+                    if (FAKE)
+                    {
+                        int offsetCumulative[3], q3[3];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                        {
+                            const int cu = (int)(short)(cumulative[ch] + off);
+                            offsetCumulative[ch] = cu < 0 ? 0 : (cu > 2040 ? 2040 : cu);
+                        }
+                        resolveHalfFake(q3, offsetCumulative, d == 1, fakeAccurate, T);
+                        packed = q3[0] | (q3[1] << 5) | (q3[2] << 10);
+                    }
+                    else
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++)
                     {
@@ -1206,13 +1401,18 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
                 }
             const int numIsolated = __popc(iso), numLine = __popc(line);
             const int isoAddend = (numIsolated << 4) | numIsolated;
-            int isoQ[3], isoColor[3];
+            int isoQ[3], isoColor[3], isoTargets[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ch++)
             {
-                isoQ[ch] = numIsolated == 0 ? 0 : udivSmall(isolatedTotal[ch] + isolatedTotal[ch] + isoAddend, numIsolated * 34);
-                isoColor[ch] = isoQ[ch] | (isoQ[ch] << 4);
+                isoTargets[ch] = isolatedTotal[ch] + isolatedTotal[ch] + (FAKE ? 0 : isoAddend);
+                isoQ[ch] = numIsolated == 0 ? 0 : udivSmall(isoTargets[ch], numIsolated * 34);
             }
+            if (FAKE)
+                resolveTHFake(isoQ, isoTargets, numIsolated);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+                isoColor[ch] = isoQ[ch] | (isoQ[ch] << 4);
             {
                 const int px = lane & 15;
                 const float e = E(isoColor[0], isoColor[1], isoColor[2], S.pix[px], S.pw[px]);
@@ -1235,7 +1435,7 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
                     const int u = (q << 4) | q;
                     hc[ch] = u - modifier > 0 ? u - modifier : 0;
                 }
-                const float e = E(hc[0], hc[1], hc[2], S.pix[px], S.pw[px]);
+                const float e = E.wu(hc[0], hc[1], hc[2], S.pix[px], S.pw[px]);
                 S.u.h.err[table][px] = ((transMask >> px) & 1u) ? 0.0f : e;
                 if (px == 0)
                     S.u.h.color[0][table] = (unsigned short)((hq[0] << 10) | (hq[1] << 5) | hq[2]);
@@ -1261,15 +1461,18 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
                     int kc = k < numLine ? k : numLine;
                     kc = kc > -numLine ? kc : -numLine;
                     const int modifierAddend = (int)(short)(kc * modifierOffset);
-                    int q[3];
+                    int q[3], targets[3];
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++)
                     {
-                        int numerator = (int)(short)((int)(short)(lineTotal[ch] + lineTotal[ch] + lineAddend) + modifierAddend);
+                        int numerator = (int)(short)((int)(short)(lineTotal[ch] + lineTotal[ch] + (FAKE ? 0 : lineAddend)) + modifierAddend);
                         numerator = numerator < 0 ? 0 : numerator;
                         const int divided = lineDivisor == 0 ? 0 : udivSmall(numerator, lineDivisor);
                         q[ch] = divided < 15 ? divided : 15;
+                        targets[ch] = numerator;
                     }
+                    if (FAKE)
+                        resolveTHFake(q, targets, numLine);
                     const int packed = (q[0] << 10) | (q[1] << 5) | q[2];
                     if (n == 0 || packed != last)
                     {
@@ -1329,8 +1532,8 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
                     float tErr = 0.0f, hErr = 0.0f;
                     for (int px = 0; px < 16; px++)
                     {
-                        const float e0 = E(lc[0][0], lc[0][1], lc[0][2], S.pix[px], S.pw[px]);
-                        const float e1 = E(lc[1][0], lc[1][1], lc[1][2], S.pix[px], S.pw[px]);
+                        const float e0 = E.wu(lc[0][0], lc[0][1], lc[0][2], S.pix[px], S.pw[px]);
+                        const float e1 = E.wu(lc[1][0], lc[1][1], lc[1][2], S.pix[px], S.pw[px]);
                         const float le = ((transMask >> px) & 1u) ? 0.0f : sseMin(e0, e1);
                         tErr = tErr + sseMin(le, S.isoErr[px]);
                         hErr = hErr + sseMin(le, S.u.h.err[table][px]);
@@ -1370,8 +1573,8 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
                 u32 selectors = 0;
                 for (int px = 0; px < 16; px++)
                 {
-                    const float e0 = E(lc[0][0], lc[0][1], lc[0][2], S.pix[px], S.pw[px]);
-                    const float e1 = E(lc[1][0], lc[1][1], lc[1][2], S.pix[px], S.pw[px]);
+                    const float e0 = E.wu(lc[0][0], lc[0][1], lc[0][2], S.pix[px], S.pw[px]);
+                    const float e1 = E.wu(lc[1][0], lc[1][1], lc[1][2], S.pix[px], S.pw[px]);
                     const bool tr = ((transMask >> px) & 1u) != 0;
                     const float le = tr ? 0.0f : sseMin(e0, e1);
                     u32 sel = (e0 <= e1) ? 1u : 3u;
@@ -1604,26 +1807,32 @@ extern "C" hipError_t cvttmi_launch_etc2(const void *d_blocks, void *d_out, cons
         return hipSuccess;
     CvttEtcArgs a = *args;
     a.outStride = (mode == 1) ? 16u : 8u;
-    if (mode == 3)
+    const bool fake = (a.flags & CVTTMI_FLAG_ETC_USE_FAKE_BT709) != 0;
+#define CVTT_LAUNCH_COLOR(M)                                                                                                      \
+    do                                                                                                                            \
+    {                                                                                                                             \
+        if (fake)                                                                                                                 \
+            hipLaunchKernelGGL((cvttmi_etc2_color_kernel<M, true>), dim3(a.numBlocks / 8u), dim3(512), 0, stream,                 \
+                               (const uint8_t *)d_blocks, (uint8_t *)d_out, a, d_tables);                                         \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((cvttmi_etc2_color_kernel<M, false>), dim3(a.numBlocks / 8u), dim3(512), 0, stream,                \
+                               (const uint8_t *)d_blocks, (uint8_t *)d_out, a, d_tables);                                         \
+    } while (0)
+    if (mode == 3 || mode == 4)
     {
         a.outOffset = 0u;
-        hipLaunchKernelGGL(cvttmi_etc2_color_kernel<1>, dim3(a.numBlocks / 8u), dim3(512), 0, stream, (const uint8_t *)d_blocks,
-                           (uint8_t *)d_out, a, d_tables);
-        return hipGetLastError();
-    }
-    if (mode == 4)
-    {
-        a.outOffset = 0u;
-        hipLaunchKernelGGL(cvttmi_etc2_color_kernel<2>, dim3(a.numBlocks / 8u), dim3(512), 0, stream, (const uint8_t *)d_blocks,
-                           (uint8_t *)d_out, a, d_tables);
+        if (mode == 3)
+            CVTT_LAUNCH_COLOR(1);
+        else
+            CVTT_LAUNCH_COLOR(2);
         return hipGetLastError();
     }
     if (mode != 2)
     {
         a.outOffset = (mode == 1) ? 8u : 0u;
-        hipLaunchKernelGGL(cvttmi_etc2_color_kernel<0>, dim3(a.numBlocks / 8u), dim3(512), 0, stream, (const uint8_t *)d_blocks,
-                           (uint8_t *)d_out, a, d_tables);
+        CVTT_LAUNCH_COLOR(0);
     }
+#undef CVTT_LAUNCH_COLOR
     if (mode != 0)
     {
         a.outOffset = 0u;

@@ -20,6 +20,7 @@
 #include "bc7_tables.h"
 #include "s3tc_sc_tables.h"
 #include "bc7_quality_events.h"
+#include "fake709_rounding.h"
 #include "bc6h_layout.h"
 #include "etc_tables.h"
 
@@ -133,6 +134,7 @@ namespace
             t.anchor3[i][1] = k_anchor3[i * 2 + 1];
         }
         memcpy(t.s3tcSingleColor, k_s3tcsc, sizeof(t.s3tcSingleColor));
+        memcpy(t.fake709Rounding, k_fake709Rounding16, sizeof(t.fake709Rounding));
         for (int r = 0; r < 3; r++)
             for (int tw = 0; tw < 4; tw++)
                 tweakFactors(tw, 4 << r, t.tweakFactors[r][tw]);
@@ -759,8 +761,6 @@ extern "C"
             return CVTTMI_E_INVALID;
         if (!d_out || !d_blocks || !options || (numBlocks % 8) != 0 || numBlocks > 0xfffffff0u)
             return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
-        if (options->flags & CVTTMI_FLAG_ETC_USE_FAKE_BT709)
-            return fail(ctx, CVTTMI_E_UNSUPPORTED, "ETC_UseFakeBT709 is not implemented on the GPU path");
         if (numBlocks == 0)
             return CVTTMI_OK;
         hipError_t e = hipSetDevice(ctx->device);

@@ -1,13 +1,12 @@
 """Image -> compressed texture file on the MI355X: the caller side of the hot path.
 
-    python -m convectionkernels_amd.packer [-format F] [-uniform] [-quality Q] [-dds] input output
+    python -m convectionkernels_amd.packer [-format F] [-uniform] [-fakebt709] [-quality Q] [-dds] input output
 
 The command line follows the reference's example packer (etc2packer.cpp:44-105: `-format etc1|etc2rgb|etc2rgba|etc2punchthrough|r11u|r11s`,
-`-uniform`, input, output; default etc2rgb, KTX output) and adds the BC formats (bc1..bc5, bc7; `-dds` for a DX10 DDS
+`-fakebt709`, `-uniform` (which overrides it), input, output; default etc2rgb, KTX output) and adds the BC formats (bc1..bc5, bc7; `-dds` for a DX10 DDS
 file, `-quality 1..100` for a BC7 plan).  The image is uploaded once; tiling into groups of eight 4x4 blocks with
 edge clamping (etc2packer.cpp:215-248), encoding and the removal of padding blocks all run on the device, and the
-packed blocks are already in container order.  The input is anything PIL opens, or a .npy of shape (H, W, 4) uint8.
-`-fakebt709` is not implemented by the kernels and is refused."""
+packed blocks are already in container order.  The input is anything PIL opens, or a .npy of shape (H, W, 4) uint8."""
 import sys
 
 import numpy as np
@@ -60,7 +59,7 @@ def encode_file(image, fmt, options=None, plan=None, ctx=None):
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    fmt, uniform, quality, dds, paths = "etc2rgb", False, None, False, []
+    fmt, uniform, fake, quality, dds, paths = "etc2rgb", False, False, None, False, []
     i = 0
     while i < len(argv):
         a = argv[i]
@@ -75,8 +74,7 @@ def main(argv=None):
         elif a == "-dds":
             dds = True
         elif a == "-fakebt709":
-            sys.stderr.write("ETC_UseFakeBT709 is not implemented on the GPU path\n")
-            return 2
+            fake = True
         elif a.startswith("-"):
             sys.stderr.write(USAGE + "\n")
             return 2
@@ -93,8 +91,10 @@ def main(argv=None):
         sys.stderr.write("%s\n" % e)
         return 1
     options = api.Options()
-    if uniform:
+    if uniform:  # etc2packer.cpp:202-205
         options.flags |= api.Flags.Uniform
+    elif fake:
+        options.flags |= api.Flags.ETC_UseFakeBT709
     plan = None
     if quality is not None:
         plan = api.BC7EncodingPlan()

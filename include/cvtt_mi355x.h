@@ -159,7 +159,7 @@ int cvttmi_encode_bc6h_device(cvttmi_context *ctx, void *d_out, const void *d_bl
  * block then colour block) per block out.  The reference's ETC2CompressionData scratch
  * (AllocETC2Data / ReleaseETC2Data) has no counterpart: the kernels keep their scratch in
  * LDS and derive the two chroma axes from options->{red,green,blue}Weight on every call.
- * Uses the Uniform flag and the colour weights; ETC_UseFakeBT709 is CVTTMI_E_UNSUPPORTED. */
+ * Uses the colour weights and the Uniform / ETC_UseFakeBT709 / ETC_FakeBT709Accurate flags. */
 int cvttmi_encode_etc2_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
                               const cvttmi_options *options, void *hipStream);
 int cvttmi_encode_etc2_rgba_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,

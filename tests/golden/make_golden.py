@@ -156,8 +156,20 @@ def main():
         e2["opt_" + name] = o
         for mode, tag in ((0, "rgb"), (1, "rgba"), (2, "alpha"), (3, "etc1")):
             e2["out_%s_%s" % (tag, name)] = ref.encode_etc2(etc_blocks, o, mode)
+    # ETC_UseFakeBT709 (0x400), + ETC_FakeBT709Accurate (0x800), + Uniform (sector split only): colour formats
+    fake_opts = {
+        "fake709": P.make_options(flags=P.FLAGS_DEFAULT | 0x400),
+        "fake709_accurate": P.make_options(flags=P.FLAGS_DEFAULT | 0x400 | 0x800),
+        "fake709_uniform": P.make_options(flags=P.FLAGS_DEFAULT | 0x400 | P.FLAG_UNIFORM),
+    }
+    for name, o in fake_opts.items():
+        e2["opt_" + name] = o
+        for mode, tag in ((0, "rgb"), (1, "rgba"), (3, "etc1")):
+            e2["out_%s_%s" % (tag, name)] = ref.encode_etc2(etc_blocks, o, mode)
     # punch-through alpha (EncodeETC2PunchthroughAlpha): cut-out structures x thresholds / metrics
     e2["pt_blocks"] = content.punchthrough_blocks(17, 2)
+    for name, o in fake_opts.items():
+        e2["pt_out_" + name] = ref.encode_etc2(e2["pt_blocks"], o, 4)
     for name, o in {
         "default": P.make_options(),
         "uniform_t025": P.make_options(flags=P.FLAGS_DEFAULT | P.FLAG_UNIFORM, threshold=0.25),

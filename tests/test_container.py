@@ -102,4 +102,13 @@ def test_packer_cli(gpu_ctx, oracle_lib, tmp_path):
     exp = oracle_lib.encode_s3tc(tiles, pyref.make_options(), 3, rcp, threads=4)
     assert (container.read_dds(dds)[3] == content.compact_rows(exp, w, h)).all()
 
-    assert packer.main(["-fakebt709", src, out]) == 2 and packer.main([src]) == 2
+    assert packer.main(["-fakebt709", src, out]) == 0
+    exp = oracle_lib.encode_etc2(tiles, pyref.make_options(flags=pyref.FLAGS_DEFAULT | 0x400), 0, threads=4)
+    assert (container.read_ktx(out)[3] == content.compact_rows(exp, w, h)).all()
+
+    assert packer.main(["-format", "etc2punchthrough", src, out]) == 0
+    exp = oracle_lib.encode_etc2(tiles, pyref.make_options(), 4, threads=4)
+    name, rw, rh, blocks = container.read_ktx(out)
+    assert name == "etc2punchthrough" and (blocks == content.compact_rows(exp, w, h)).all()
+
+    assert packer.main([src]) == 2 and packer.main(["-bogus", src, out]) == 2

@@ -65,9 +65,28 @@ def test_oracle_vs_reference(oracle_lib, ref_lib):
             assert (oracle_lib.encode_etc2(blocks, opt, mode, 8) == ref_lib.encode_etc2(blocks, opt, mode)).all()
 
 
-def test_oracle_rejects_fake_bt709(oracle_lib):
-    with pytest.raises(RuntimeError):
-        oracle_lib.encode_etc2(np.zeros((8, 16, 4), np.uint8), pyref.make_options(flags=0x400), 0)
+FAKE_NAMES = ["fake709", "fake709_accurate", "fake709_uniform"]
+
+
+@pytest.mark.parametrize("name", FAKE_NAMES)
+def test_oracle_golden_fake_bt709(oracle_lib, name):
+    """ETC_UseFakeBT709 (+ ETC_FakeBT709Accurate): every colour format, incl. punch-through"""
+    g = np.load(os.path.join(GOLD, "etc2_mixed.npz"))
+    for mode, tag in ((0, "rgb"), (1, "rgba"), (3, "etc1")):
+        out = oracle_lib.encode_etc2(g["blocks"], g["opt_" + name], mode, threads=8)
+        assert (out == g["out_%s_%s" % (tag, name)]).all(), tag
+    out = oracle_lib.encode_etc2(g["pt_blocks"], g["opt_" + name], 4, threads=8)
+    assert (out == g["pt_out_" + name]).all()
+
+
+def test_fake_bt709_rounding_table_follows_the_rule():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_f709", os.path.join(root, "tools", "gen_fake709_rounding.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for target, text in m.render().items():
+        assert open(os.path.join(root, target)).read() == text, target
 
 
 def test_t_mode_group_coupling(oracle_lib):
@@ -87,6 +106,33 @@ def test_gpu_golden_punchthrough(gpu_ctx, name):
     out = gpu_ctx.encode_etc2_punchthrough_alpha(g["pt_blocks"], api.Options.frombytes(g["pt_opt_" + name]))
     bad = np.nonzero((out != g["pt_out_" + name]).any(axis=1))[0]
     assert bad.size == 0, bad[:8]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FAKE_NAMES)
+def test_gpu_golden_fake_bt709(gpu_ctx, name):
+    from convectionkernels_amd import api
+    g = np.load(os.path.join(GOLD, "etc2_mixed.npz"))
+    opt = api.Options.frombytes(g["opt_" + name])
+    for mode, tag in ((0, "rgb"), (1, "rgba"), (3, "etc1")):
+        out = _enc(gpu_ctx, mode)(g["blocks"], opt)
+        bad = np.nonzero((out != g["out_%s_%s" % (tag, name)]).any(axis=1))[0]
+        assert bad.size == 0, (tag, bad[:8])
+    out = gpu_ctx.encode_etc2_punchthrough_alpha(g["pt_blocks"], opt)
+    bad = np.nonzero((out != g["pt_out_" + name]).any(axis=1))[0]
+    assert bad.size == 0, bad[:8]
+
+
+@pytest.mark.gpu
+def test_gpu_fake_bt709_vs_oracle(gpu_ctx, oracle_lib):
+    import torch
+    from convectionkernels_amd import api
+    blocks = np.concatenate([content.config_blocks(4, 128, 128), content.mixed_ldr_blocks(44, 32)])
+    for flags in (api.Flags.Default | api.Flags.ETC_UseFakeBT709, api.Flags.Ultra | api.Flags.ETC_UseFakeBT709):
+        exp = oracle_lib.encode_etc2(blocks, pyref.make_options(flags=flags), 0, threads=8)
+        out = gpu_ctx.encode_etc2(torch.from_numpy(blocks).cuda(), api.Options(flags=flags)).cpu().numpy()
+        bad = np.nonzero((out != exp).any(axis=1))[0]
+        assert bad.size == 0, bad[:8]
 
 
 @pytest.mark.gpu
@@ -144,7 +190,7 @@ def test_gpu_known_answers_and_config4(gpu_ctx, oracle_lib):
         exp = oracle_lib.encode_etc2(smooth, pyref.make_options(), mode, threads=8)
         assert (_enc(gpu_ctx, mode)(smooth, api.Options()) == exp).all()
     with pytest.raises(api.CvttError):
-        gpu_ctx.encode_etc2(blocks[:8].copy(), api.Options(flags=api.Flags.Default | api.Flags.ETC_UseFakeBT709))
+        gpu_ctx.encode_etc2(blocks[:12].copy(), api.Options())  # not a whole number of 8-block groups
 
 
 @pytest.mark.gpu

@@ -45,6 +45,7 @@ def main():
         bad += not ok
     bad += check_single_colour()
     bad += check_s3tc_single_colour()
+    bad += check_fake709()
     return bad
 
 
@@ -94,6 +95,17 @@ def check_s3tc_single_colour():
             print("S3TC single-colour table %s MISMATCH" % n)
     print("%-20s %5d tables   %s" % ("S3TC single colour", len(names), "OK" if not bad else "MISMATCH"))
     return bad
+
+
+def check_fake709():
+    """ETC fake-BT.709 rounding table (ConvectionKernels_FakeBT709_Rounding.h) vs tools/gen_fake709_rounding.py"""
+    import gen_fake709_rounding as F
+    txt = open("/root/reference/ConvectionKernels_FakeBT709_Rounding.h").read()
+    m = re.search(r"g_rounding16\[\]\s*=\s*\{(.*?)\};", txt, re.S)
+    ref = [int(x) for x in re.findall(r"\d+", m.group(1))]
+    ok = ref == F.build()
+    print("%-20s %5d entries  %s" % ("fake BT.709 rounding", len(ref), "OK" if ok else "MISMATCH"))
+    return 0 if ok else 1
 
 
 if __name__ == "__main__":
