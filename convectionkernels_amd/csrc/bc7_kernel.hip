@@ -827,6 +827,284 @@ __device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int ind
 }
 
 
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+
+// The 4 or 8 reconstructed values of one channel, ((64 - w) * e0 + w * e1 + 32) >> 6 for the BC7 weights w of a 2- or
+// 3-bit index (reference IndexSelector.h:90-100), as bytes: tabLo = levels 0..3, tabHi = levels 4..7 (3-bit only).
+// Two levels per instruction in packed 16-bit lanes (every intermediate fits 16 bits).
+__device__ __forceinline__ void levelTable(int e0, int e1, bool threeBit, u32 &tabLo, u32 &tabHi)
+{
+    const u32 base = (u32)((e0 << 6) + 32), delta = (u32)(e1 - e0) & 0xffffu;
+    const v2us BB = __builtin_bit_cast(v2us, base | (base << 16)), DD = __builtin_bit_cast(v2us, delta | (delta << 16));
+    const v2us six = {6, 6};
+    // weight pairs: 2-bit {0, 21}, {43, 64}; 3-bit {0, 9}, {18, 27}, {37, 46}, {55, 64}
+    const u32 w01 = threeBit ? (0u | (9u << 16)) : (0u | (21u << 16));
+    const u32 w23 = threeBit ? (18u | (27u << 16)) : (43u | (64u << 16));
+    const v2us r01 = (__builtin_bit_cast(v2us, w01) * DD + BB) >> six;
+    const v2us r23 = (__builtin_bit_cast(v2us, w23) * DD + BB) >> six;
+    tabLo = __builtin_amdgcn_perm(__builtin_bit_cast(u32, r23), __builtin_bit_cast(u32, r01), 0x06040200u);
+    tabHi = 0;
+    if (threeBit)
+    {
+        const v2us r45 = (__builtin_bit_cast(v2us, 37u | (46u << 16)) * DD + BB) >> six;
+        const v2us r67 = (__builtin_bit_cast(v2us, 55u | (64u << 16)) * DD + BB) >> six;
+        tabHi = __builtin_amdgcn_perm(__builtin_bit_cast(u32, r67), __builtin_bit_cast(u32, r45), 0x06040200u);
+    }
+}
+
+// four byte-wide indexes -> four nibbles in the low 16 bits
+__device__ __forceinline__ u32 nibblesOf(u32 b4)
+{
+    const u32 t = b4 | (b4 >> 4);
+    return __builtin_amdgcn_perm(0u, t, 0x0c0c0200u);
+}
+
+// evalDual for fast indexing, on channel-major pixels: P[ch][g] holds channel ch of pixels 4g..4g+3 (one byte each),
+// channels already in rotated order (P[3] = the separately coded channel).  The float index selection and the refiner
+// are the reference's operation for operation; the integer error sum(rec - px)^2 is evaluated per channel as
+// sum(rec^2) - 2 sum(rec * px) + sum(px^2) with the reconstructed bytes looked up by v_perm_b32 from the level table
+// and the sums taken by v_dot4_u32_u8 over four pixels at a time -- integers, so the result is the same number.
+__device__ __forceinline__ void evalDualFast(const u32 (&P)[4][4], int mode, int indexSelector, const Unfinished &uRGB,
+                                             int numTweak, const float (&rw)[4], const float (&rwSq)[4],
+                                             const float (&rrcpW)[4], u32 flags, const CvttDeviceTables *__restrict__ T,
+                                             int numRefine, int lane, ShapeBest &bestRGB, ShapeBest &bestA)
+{
+    const int c = lane & 3;
+    int rgbPrec, alphaPrec;
+    if (mode == 4)
+    {
+        rgbPrec = indexSelector ? 3 : 2;
+        alphaPrec = indexSelector ? 2 : 3;
+    }
+    else
+        rgbPrec = alphaPrec = 2;
+    const float rgbMax = (float)((1 << rgbPrec) - 1), alphaMaxV = (float)((1 << alphaPrec) - 1);
+    const float rgbRcpMax = T->rcpMaxIndex[rgbPrec], alphaRcpMax = T->rcpMaxIndex[alphaPrec];
+    const float wRcp16 = T->rcpTable[16];
+    const bool uniformErr = (flags & CVTTMI_FLAG_UNIFORM) != 0;
+
+    bestRGB.err = bestA.err = FLT_MAX;
+    bestRGB.ep0 = bestRGB.ep1 = bestRGB.idxLo = bestRGB.idxHi = 0;
+    bestA.ep0 = bestA.ep1 = bestA.idxLo = bestA.idxHi = 0;
+
+    // min / max of the separately coded channel and sum(px^2) per channel
+    int alphaMin = 255, alphaMax = 0;
+    u32 sumSq[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+    {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const int a = byteI(P[3][g], k);
+            alphaMin = a < alphaMin ? a : alphaMin;
+            alphaMax = a > alphaMax ? a : alphaMax;
+        }
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++)
+            sumSq[ch] = __builtin_amdgcn_udot4(P[ch][g], P[ch][g], sumSq[ch], false);
+    }
+
+    const int tweak = c;
+    if (tweak < numTweak)
+    {
+        int ep[2][4];
+        {
+            const float tf0 = T->tweakFactors[rgbPrec - 2][tweak][0];
+            const float tf1 = T->tweakFactors[rgbPrec - 2][tweak][1];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+            {
+                ep[0][ch] = (int)clampRound(uRGB.base[ch] + uRGB.offset[ch] * tf0, 255.0f);
+                ep[1][ch] = (int)clampRound(uRGB.base[ch] + uRGB.offset[ch] * tf1, 255.0f);
+            }
+            // TweakAlpha (reference BC67.cpp:815-827)
+            const float af0 = T->tweakFactors[alphaPrec - 2][tweak][0];
+            const float af1 = T->tweakFactors[alphaPrec - 2][tweak][1];
+            const float base = (float)alphaMin;
+            const float offs = (float)alphaMax - base;
+            ep[0][3] = (int)clampRound(base + offs * af0, 255.0f);
+            ep[1][3] = (int)clampRound(base + offs * af1, 255.0f);
+        }
+
+        for (int refine = 0; refine < numRefine; refine++)
+        {
+            const bool last = (refine == numRefine - 1);
+            // CompressEndpoints4 / 5 (reference BC67.cpp:901-923)
+            const int cb = (mode == 4) ? 5 : 7;
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+            {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                    ep[j][ch] = unquantize(quantizeNoP(ep[j][ch], cb), cb);
+                if (mode == 4)
+                    ep[j][3] = unquantize(quantizeNoP(ep[j][3], 6), 6);
+            }
+
+            // IndexSelector<3> (rotated weights) and IndexSelector<1> (weight 1.0)
+            float origin[4], axis[4];
+            u32 tabLo[4], tabHi[4];
+            {
+                float epDW[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    origin[ch] = (float)ep[0][ch];
+                    epDW[ch] = ((float)ep[1][ch] - origin[ch]) * rw[ch];
+                }
+                float lenSq = epDW[0] * epDW[0];
+                lenSq = lenSq + epDW[1] * epDW[1];
+                lenSq = lenSq + epDW[2] * epDW[2];
+                lenSq = safeDenom(lenSq);
+                const float mvdls = rgbMax / lenSq;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                    axis[ch] = epDW[ch] * rw[ch] * mvdls;
+                origin[3] = (float)ep[0][3];
+                const float aDW = (float)ep[1][3] - origin[3];
+                const float aLen = safeDenom(aDW * aDW);
+                axis[3] = aDW * (alphaMaxV / aLen);
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                    levelTable(ep[0][ch], ep[1][ch], rgbPrec == 3, tabLo[ch], tabHi[ch]);
+                levelTable(ep[0][3], ep[1][3], alphaPrec == 3, tabLo[3], tabHi[3]);
+            }
+            const v2f org01 = {origin[0], origin[1]}, org23 = {origin[2], origin[3]};
+            const v2f ax01 = {axis[0], axis[1]}, ax23 = {axis[2], axis[3]};
+            const v2f w01 = {rw[0], rw[1]}, w23 = {rw[2], 1.0f};
+            const v2f rcpMax2 = {rgbRcpMax, alphaRcpMax};
+
+            u32 s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+            v2f tv01 = {0.0f, 0.0f}, tv23 = {0.0f, 0.0f}, vs01 = {0.0f, 0.0f}, vs23 = {0.0f, 0.0f};
+            v2f tt2 = {0.0f, 0.0f}, ts2 = {0.0f, 0.0f}; // {RGB plane, alpha plane}
+            u32 idxRGB4[4], idxA4[4]; // one byte per pixel
+
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+            {
+                u32 iR4 = 0, iA4 = 0;
+                // fresh values for the optimiser (see fetchPixel): no hoisting of the 64 conversions out of the rounds
+                const u32 Pg[4] = {fetchPixel(P[0][g]), fetchPixel(P[1][g]), fetchPixel(P[2][g]), fetchPixel(P[3][g])};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const v2f x01 = {byteF(Pg[0], k), byteF(Pg[1], k)}, x23 = {byteF(Pg[2], k), byteF(Pg[3], k)};
+                    const v2f p01 = (x01 - org01) * ax01, p23 = (x23 - org23) * ax23;
+                    float dist = p01.x + p01.y;
+                    dist = dist + p23.x;
+                    const float fRGB = clampRound(dist, rgbMax);
+                    const float fA = clampRound(p23.y, alphaMaxV);
+                    iR4 |= (u32)(int)fRGB << (8 * k);
+                    iA4 |= (u32)(int)fA << (8 * k);
+                    if (!last)
+                    {
+                        // EndpointRefiner<3> with the rotated weights and EndpointRefiner<1> with weight 1
+                        const v2f f2 = {fRGB, fA};
+                        const v2f t2 = f2 * rcpMax2;
+                        const v2f tt = {t2.x, t2.x};
+                        const v2f v01 = x01 * w01, v23 = x23 * w23;
+                        tv01 = tv01 + tt * v01;
+                        tv23 = tv23 + t2 * v23;
+                        vs01 = vs01 + v01;
+                        vs23 = vs23 + v23;
+                        tt2 = tt2 + t2 * t2;
+                        ts2 = ts2 + t2;
+                    }
+                }
+                idxRGB4[g] = iR4;
+                idxA4[g] = iA4;
+#pragma unroll
+                for (int ch = 0; ch < 4; ch++)
+                {
+                    const u32 R = __builtin_amdgcn_perm(tabHi[ch], tabLo[ch], ch == 3 ? iA4 : iR4);
+                    s1[ch] = __builtin_amdgcn_udot4(R, Pg[ch], s1[ch], false);
+                    s2[ch] = __builtin_amdgcn_udot4(R, R, s2[ch], false);
+                }
+            }
+
+            u32 err[4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++)
+                err[ch] = s2[ch] + sumSq[ch] - 2u * s1[ch];
+            float errorRGB, errorA;
+            if (uniformErr)
+            {
+                errorRGB = (float)(int)(err[0] + err[1] + err[2]);
+                errorA = (float)(int)err[3];
+            }
+            else
+            {
+                errorRGB = (float)(int)err[0] * rwSq[0];
+                errorRGB = errorRGB + (float)(int)err[1] * rwSq[1];
+                errorRGB = errorRGB + (float)(int)err[2] * rwSq[2];
+                errorA = (float)(int)err[3] * rwSq[3];
+            }
+
+            if (errorRGB < bestRGB.err)
+            {
+                bestRGB.err = errorRGB;
+                bestRGB.ep0 = (u32)ep[0][0] | ((u32)ep[0][1] << 8) | ((u32)ep[0][2] << 16);
+                bestRGB.ep1 = (u32)ep[1][0] | ((u32)ep[1][1] << 8) | ((u32)ep[1][2] << 16);
+                bestRGB.idxLo = nibblesOf(idxRGB4[0]) | (nibblesOf(idxRGB4[1]) << 16);
+                bestRGB.idxHi = nibblesOf(idxRGB4[2]) | (nibblesOf(idxRGB4[3]) << 16);
+            }
+            if (errorA < bestA.err)
+            {
+                bestA.err = errorA;
+                bestA.ep0 = (u32)ep[0][3] << 24;
+                bestA.ep1 = (u32)ep[1][3] << 24;
+                bestA.idxLo = nibblesOf(idxA4[0]) | (nibblesOf(idxA4[1]) << 16);
+                bestA.idxHi = nibblesOf(idxA4[2]) | (nibblesOf(idxA4[3]) << 16);
+            }
+
+            if (!last)
+            {
+                // EndpointRefiner<3> / <1>::GetRefinedEndpointsLDR, 16 contributions each
+                const float tv[4] = {tv01.x, tv01.y, tv23.x, tv23.y}, vs[4] = {vs01.x, vs01.y, vs23.x, vs23.y};
+                {
+                    const float ttRGB = tt2.x, tsRGB = ts2.x;
+                    float adenom = (ttRGB * 16.0f - tsRGB * tsRGB) * wRcp16;
+                    const bool z = (adenom == 0.0f);
+                    if (z) adenom = 1.0f;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                    {
+                        const float a = (tv[ch] - tsRGB * vs[ch] * wRcp16) / adenom;
+                        const float b = (vs[ch] - a * tsRGB) * wRcp16;
+                        float p1 = b, p2 = a + b;
+                        if (z)
+                        {
+                            p1 = vs[ch] * wRcp16;
+                            p2 = p1;
+                        }
+                        ep[0][ch] = (int)clampRound(p1 * rrcpW[ch], 255.0f);
+                        ep[1][ch] = (int)clampRound(p2 * rrcpW[ch], 255.0f);
+                    }
+                }
+                {
+                    const float ttA = tt2.y, tsA = ts2.y;
+                    float adenom = (ttA * 16.0f - tsA * tsA) * wRcp16;
+                    const bool z = (adenom == 0.0f);
+                    if (z) adenom = 1.0f;
+                    const float a = (tv[3] - tsA * vs[3] * wRcp16) / adenom;
+                    const float b = (vs[3] - a * tsA) * wRcp16;
+                    float p1 = b, p2 = a + b;
+                    if (z)
+                    {
+                        p1 = vs[3] * wRcp16;
+                        p2 = p1;
+                    }
+                    ep[0][3] = (int)clampRound(p1, 255.0f);
+                    ep[1][3] = (int)clampRound(p2, 255.0f);
+                }
+            }
+        }
+    }
+    quadArgminBroadcast(bestRGB, lane);
+    quadArgminBroadcast(bestA, lane);
+}
+
 // =====================================================================================
 // Exact branch-and-bound, part 2: cheap bounds for every partition before anything is
 // searched (part 1, the bound itself, is shapeErrorLowerBound in cvtt_kernel_common.h).
@@ -1320,6 +1598,25 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
         }
         PROF_MARK(0)
 
+        // fast indexing: channel-major copy of the block, P[ch][g] = channel ch of pixels 4g..4g+3; a rotation then is an
+        // exchange of four registers with four others instead of a byte shuffle of all sixteen pixels
+        u32 P[4][4];
+        if (FAST)
+        {
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+            {
+                const u32 a = pix[4 * g], b = pix[4 * g + 1], cc = pix[4 * g + 2], d = pix[4 * g + 3];
+                const u32 ab02 = __builtin_amdgcn_perm(b, a, 0x06020400u); // a0 b0 a2 b2
+                const u32 ab13 = __builtin_amdgcn_perm(b, a, 0x07030501u); // a1 b1 a3 b3
+                const u32 cd02 = __builtin_amdgcn_perm(d, cc, 0x06020400u);
+                const u32 cd13 = __builtin_amdgcn_perm(d, cc, 0x07030501u);
+                P[0][g] = __builtin_amdgcn_perm(cd02, ab02, 0x05040100u); // a0 b0 c0 d0
+                P[2][g] = __builtin_amdgcn_perm(cd02, ab02, 0x07060302u); // a2 b2 c2 d2
+                P[1][g] = __builtin_amdgcn_perm(cd13, ab13, 0x05040100u);
+                P[3][g] = __builtin_amdgcn_perm(cd13, ab13, 0x07060302u);
+            }
+        }
         int curRotation = 0;
         for (int step = 0; step < 12; step++)
         {
@@ -1344,9 +1641,33 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
 
             if (rotation != curRotation)
             {
+                if (FAST)
+                {
+                    // undo the previous exchange, then exchange channel rotation-1 with channel 3
 #pragma unroll
-                for (int px = 0; px < 16; px++)
-                    pix[px] = rotatePixel(rotatePixel(pix[px], curRotation), rotation);
+                    for (int pass = 0; pass < 2; pass++)
+                    {
+                        const int r = pass == 0 ? curRotation : rotation;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                            if (r == ch + 1)
+                            {
+#pragma unroll
+                                for (int g = 0; g < 4; g++)
+                                {
+                                    const u32 t = P[ch][g];
+                                    P[ch][g] = P[3][g];
+                                    P[3][g] = t;
+                                }
+                            }
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int px = 0; px < 16; px++)
+                        pix[px] = rotatePixel(rotatePixel(pix[px], curRotation), rotation);
+                }
                 curRotation = rotation;
             }
             float rw[4], rwSq[4], rrcpW[4];
@@ -1374,7 +1695,10 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             Unfinished u;
             quadBroadcast(u, uRot, lane, rotation);
             ShapeBest b, bA;
-            evalDual<FAST>(pix, mode, indexSelector, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
+            if (FAST)
+                evalDualFast(P, mode, indexSelector, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
+            else
+                evalDual<FAST>(pix, mode, indexSelector, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
 
 #ifdef CVTT_BC7_DEBUG
             if (blockIdx.x * 16u + (u32)(lane >> 2) == g_bc7DbgBlock && c == 0)
@@ -1420,11 +1744,25 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 }
             }
         }
-        if (curRotation != 0)
+        if (!FAST && curRotation != 0)
         {
 #pragma unroll
             for (int px = 0; px < 16; px++)
                 pix[px] = rotatePixel(pix[px], curRotation);
+        }
+        if (FAST)
+        {
+            // the pixel-major copy was dead during the search (registers); take it back from LDS
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                const uint4 v = *reinterpret_cast<const uint4 *>(&s_pix[lane >> 2][4 * i]);
+                pix[4 * i + 0] = v.x;
+                pix[4 * i + 1] = v.y;
+                pix[4 * i + 2] = v.z;
+                pix[4 * i + 3] = v.w;
+            }
         }
         PROF_MARK(1)
     }
