@@ -29,6 +29,9 @@
 #include "cvtt_device.h"
 
 // minimum waves per SIMD the register allocator must leave room for (512 VGPR+AGPR / waves)
+#ifndef CVTT_BOUND_GRID
+#define CVTT_BOUND_GRID 2000.0f // half-range of the integer grid the projected points are rounded to
+#endif
 #ifndef CVTT_BC7_WAVES
 #define CVTT_BC7_WAVES 3
 #endif
@@ -1825,7 +1828,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 {
                     const bool use4 = (boundSet == 0);
                     const float wsum = A.wSq[0] + A.wSq[1] + A.wSq[2] + (use4 ? A.wSq[3] : 0.0f);
-                    const float scale = 2000.0f / (255.0f * __builtin_amdgcn_sqrtf(wsum)); // wave-uniform
+                    const float scale = CVTT_BOUND_GRID / (255.0f * __builtin_amdgcn_sqrtf(wsum)); // wave-uniform
                     const float invScaleSq = 1.0f / (scale * scale);
                     // rounding the projected points moves each by at most sqrt(2)/2 grid units
                     const float delta = (use4 ? A.delta4 : A.delta3) + 0.7072f / scale;
