@@ -981,7 +981,7 @@ __device__ __forceinline__ void evalDualFast(const u32 (&P)[4][4], int mode, int
             u32 s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
             v2f tv01 = {0.0f, 0.0f}, tv23 = {0.0f, 0.0f}, vs01 = {0.0f, 0.0f}, vs23 = {0.0f, 0.0f};
             v2f tt2 = {0.0f, 0.0f}, ts2 = {0.0f, 0.0f}; // {RGB plane, alpha plane}
-            u32 idxRGB4[4], idxA4[4]; // one byte per pixel
+            u32 rgbLo = 0, rgbHi = 0, aLo = 0, aHi = 0; // 4 bits per pixel
 
 #pragma unroll
             for (int g = 0; g < 4; g++)
@@ -1015,8 +1015,16 @@ __device__ __forceinline__ void evalDualFast(const u32 (&P)[4][4], int mode, int
                         ts2 = ts2 + t2;
                     }
                 }
-                idxRGB4[g] = iR4;
-                idxA4[g] = iA4;
+                if (g < 2)
+                {
+                    rgbLo |= nibblesOf(iR4) << (16 * g);
+                    aLo |= nibblesOf(iA4) << (16 * g);
+                }
+                else
+                {
+                    rgbHi |= nibblesOf(iR4) << (16 * (g - 2));
+                    aHi |= nibblesOf(iA4) << (16 * (g - 2));
+                }
 #pragma unroll
                 for (int ch = 0; ch < 4; ch++)
                 {
@@ -1049,16 +1057,16 @@ __device__ __forceinline__ void evalDualFast(const u32 (&P)[4][4], int mode, int
                 bestRGB.err = errorRGB;
                 bestRGB.ep0 = (u32)ep[0][0] | ((u32)ep[0][1] << 8) | ((u32)ep[0][2] << 16);
                 bestRGB.ep1 = (u32)ep[1][0] | ((u32)ep[1][1] << 8) | ((u32)ep[1][2] << 16);
-                bestRGB.idxLo = nibblesOf(idxRGB4[0]) | (nibblesOf(idxRGB4[1]) << 16);
-                bestRGB.idxHi = nibblesOf(idxRGB4[2]) | (nibblesOf(idxRGB4[3]) << 16);
+                bestRGB.idxLo = rgbLo;
+                bestRGB.idxHi = rgbHi;
             }
             if (errorA < bestA.err)
             {
                 bestA.err = errorA;
                 bestA.ep0 = (u32)ep[0][3] << 24;
                 bestA.ep1 = (u32)ep[1][3] << 24;
-                bestA.idxLo = nibblesOf(idxA4[0]) | (nibblesOf(idxA4[1]) << 16);
-                bestA.idxHi = nibblesOf(idxA4[2]) | (nibblesOf(idxA4[3]) << 16);
+                bestA.idxLo = aLo;
+                bestA.idxHi = aHi;
             }
 
             if (!last)
