@@ -102,8 +102,8 @@ def cpu_baseline(blocks, gpu_out, opt_bytes, plan_bytes, rcp, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=4096, help="image edge in pixels (default: BASELINE config 2)")
     ap.add_argument("--opaque", action="store_true", help="variant 2b: alpha forced to 255 (modes 0-3 run)")
     ap.add_argument("--no-cpu", action="store_true")
