@@ -9,14 +9,14 @@
 // 2366-2411).  Bit-identical to the reference's SSE2 lanes in its canonical build (SURVEY App. C,
 // hazard H2: the T-mode candidate slot just past a lane's unique colours reads as zero).
 //
-// Colour kernel mapping: one WORKGROUP (8 waves) = one reference group of 8 blocks, one WAVE =
-// one block, one LANE = one candidate (a T-mode line colour, an H-mode colour pair, an ETC1
+// Colour kernel mapping: one WAVE (= workgroup) = one block, one LANE = one candidate (a T-mode line colour, an H-mode colour pair, an ETC1
 // half-block base colour, a planar coefficient combination).  Every candidate is evaluated over
 // its pixels sequentially in registers (the reference's float sums are order dependent); the
 // wave then reduces (error, candidate id) with ties going to the lowest id, which is the first
 // candidate the reference's strict '<' would have kept.  Pixels, candidate lists and the
-// differential attempt lists live in LDS; the only cross-block exchange is the group maximum of
-// the T-mode unique-colour counts (one __syncthreads per T-mode call).
+// differential attempt lists live in LDS.  The quantities that couple the eight blocks of a reference group (maxima of
+// the T-mode unique-colour counts and line-pixel counts, the punch-through predicates) are recomputed by every wave
+// from the group's 512 bytes of pixels, lane l standing in for group member l & 7: no workgroup barrier.
 // Alpha kernel: integer-only and lane independent, one lane per block.
 #include "cvtt_kernel_common.h"
 
@@ -319,16 +319,20 @@ __device__ __forceinline__ void emitH(u32 &outHi, u32 &outLo, int bc0, int bc1, 
 // ------------------------------------------------------------------------------------------
 // MODE 0: EncodeETC2 (RGB), 1: EncodeETC1, 2: EncodeETC2PunchthroughAlpha; FAKE: ETC_UseFakeBT709
 template <int MODE, bool FAKE>
-__global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
-                                                               const CvttEtcArgs A, const CvttDeviceTables *__restrict__ T)
+__global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+                                                              const CvttEtcArgs A, const CvttDeviceTables *__restrict__ T)
 {
-    __shared__ EtcWaveShared shared[8];
-    __shared__ int groupTCount[8][8];
+    // One wave = one workgroup = one block.  What a block needs from the other seven of its reference group (the maxima of
+    // the unique-colour counts and of the line-pixel counts, the two punch-through predicates) it computes itself: lane l
+    // works for group member l & 7 from the 512 bytes of the group's pixels.  No workgroup barrier, no waiting for the
+    // slowest block of the group, and 9 KB of LDS per wave instead of 72 KB per eight.
+    __shared__ EtcWaveShared shared1;
+    __shared__ u32 gpix[8][16];
 
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    const u32 blockIndex = blockIdx.x * 8u + (u32)wave;
-    EtcWaveShared &S = shared[wave];
+    const int lane = threadIdx.x;
+    const u32 blockIndex = blockIdx.x;
+    const int own = (int)(blockIndex & 7u), jb = lane & 7;
+    EtcWaveShared &S = shared1;
     const EtcErr E = {(A.flags & CVTTMI_FLAG_UNIFORM) != 0, A.rw, A.gw, A.bw, FAKE};
     const bool fakeAccurate = (A.flags & CVTTMI_FLAG_ETC_FAKE_BT709_ACCURATE) != 0;
     constexpr bool ETC1 = MODE == 1, PUNCH = MODE == 2;
@@ -354,25 +358,55 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
         S.pw[lane][2] = pxTransparent ? 0.0f : pw3[2];
     }
     const u32 transMask = PUNCH ? ((u32)__ballot(pxTransparent) & 0xffffu) : 0u;
-    const int numOpaque = 16 - __popc(transMask);
-    // the two group-wide predicates of CompressETC2Block: does ANY block have a transparent pixel (then every block
-    // also goes through the punch-through modes), are ALL blocks fully transparent (then the opaque modes are skipped)
-    bool groupAny = false, groupAll = false;
-    if (PUNCH)
+    // the group's pixels: 128 words, two per lane
     {
-        if (lane == 0)
-            groupTCount[wave][0] = (transMask != 0 ? 1 : 0) | (transMask == 0xffffu ? 2 : 0);
-        __syncthreads();
-        groupAll = true;
-#pragma unroll
-        for (int w8 = 0; w8 < 8; w8++)
-        {
-            groupAny = groupAny || (groupTCount[w8][0] & 1) != 0;
-            groupAll = groupAll && (groupTCount[w8][0] & 2) != 0;
-        }
-        __syncthreads();
+        const u32 *gsrc = reinterpret_cast<const u32 *>(blocks + (size_t)(blockIndex & ~7u) * 64u);
+        (&gpix[0][0])[lane] = gsrc[lane];
+        (&gpix[0][0])[lane + 64] = gsrc[lane + 64];
     }
     WAVE_SYNC();
+    // member jb of the group as this lane sees it: transparency mask, and pixel accessors that apply ExtractBlocks and
+    // the punch-through blackening exactly as the block's own wave does
+    u32 transJ = 0;
+    if (PUNCH)
+    {
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+            transJ |= ((gpix[jb][px] >> 24) < A.alphaThreshold ? 1u : 0u) << px;
+    }
+    const int numOpaqueJ = 16 - __popc(transJ);
+    auto pixJ = [&](int px, int (&c)[3]) {
+        const u32 pk = gpix[jb][px];
+        const bool tr = ((transJ >> px) & 1u) != 0;
+        c[0] = tr ? 0 : (int)(pk & 0xffu);
+        c[1] = tr ? 0 : (int)((pk >> 8) & 0xffu);
+        c[2] = tr ? 0 : (int)((pk >> 16) & 0xffu);
+    };
+    auto pwJ = [&](int px, float (&w3)[3]) {
+        int c[3];
+        pixJ(px, c);
+        w3[0] = E.uniform ? (float)c[0] : (float)c[0] * A.rw;
+        w3[1] = E.uniform ? (float)c[1] : (float)c[1] * A.gw;
+        w3[2] = E.uniform ? (float)c[2] : (float)c[2] * A.bw;
+        if (FAKE)
+            toFake709(w3, (float)c[0], (float)c[1], (float)c[2]);
+        if ((transJ >> px) & 1u)
+            w3[0] = w3[1] = w3[2] = 0.0f;
+    };
+    // the two group-wide predicates of CompressETC2Block: does ANY block have a transparent pixel (then every block
+    // also goes through the punch-through modes), are ALL blocks fully transparent (then the opaque modes are skipped)
+    const bool groupAny = PUNCH && (__ballot(transJ != 0) & 0xffull) != 0;
+    const bool groupAll = PUNCH && (__ballot(transJ == 0xffffu) & 0xffull) == 0xffull;
+    // maximum over the eight members (lanes that differ in their low three bits)
+    auto groupMax = [](int v) {
+#pragma unroll
+        for (int step = 1; step <= 4; step <<= 1)
+        {
+            const int o = __shfl_xor(v, step);
+            v = o > v ? o : v;
+        }
+        return v;
+    };
 
     float bestError = FLT_MAX;
     u32 outHi = 0, outLo = 0;
@@ -384,6 +418,22 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
 #endif
 
     u32 isolatedMask = 0; // bit px: pixel is "isolated" / sector 1
+    u32 isoJ = 0;         // the same for group member jb
+    // line-pixel totals of member jb under a sector assignment (the T modes' candidate lists come from them)
+    auto lineTotalsJ = [&](u32 lineMask, int (&tot)[3]) {
+        tot[0] = tot[1] = tot[2] = 0;
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+            if ((lineMask >> px) & 1u)
+            {
+                int c[3];
+                pixJ(px, c);
+                tot[0] += c[0];
+                tot[1] += c[1];
+                tot[2] += c[2];
+            }
+    };
+
     if (!ETC1) // EncodeETC1 is the cluster fit alone (CompressETC1Block, ETC.cpp:2116-2126)
     {
     // =================================== planar ===================================
@@ -575,6 +625,7 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
 
     DBG_TAP(0);
     // ============ sector split along the chroma principal axis (ETC.cpp:1723-1848) ============
+    // every lane does it for group member jb; the block's own split is lane `own`'s
     {
         float cdx[16], cdy[16];
         if (E.uniform)
@@ -584,8 +635,10 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
 #pragma unroll
             for (int px = 0; px < 16; px++)
             {
-                ccx[px] = (int)(short)(S.pix[px][0] - S.pix[px][2]);
-                ccy[px] = (int)(short)(S.pix[px][0] - (S.pix[px][1] << 1) + S.pix[px][2]);
+                int c[3];
+                pixJ(px, c);
+                ccx[px] = (int)(short)(c[0] - c[2]);
+                ccy[px] = (int)(short)(c[0] - (c[1] << 1) + c[2]);
                 cenX = (int)(short)(cenX + ccx[px]);
                 cenY = (int)(short)(cenY + ccy[px]);
             }
@@ -593,8 +646,8 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
             for (int px = 0; px < 16; px++)
             {
                 // x 16, or x the number of opaque pixels in the punch-through encoder (ETC.cpp:1746-1765)
-                cdx[px] = (float)(int)(short)((int)(short)(ccx[px] * numOpaque) - cenX);
-                cdy[px] = (float)(int)(short)((int)(short)(ccy[px] * numOpaque) - cenY) * 0.57735026918962576450914878050196f;
+                cdx[px] = (float)(int)(short)((int)(short)(ccx[px] * numOpaqueJ) - cenX);
+                cdy[px] = (float)(int)(short)((int)(short)(ccy[px] * numOpaqueJ) - cenY) * 0.57735026918962576450914878050196f;
             }
         }
         else
@@ -603,9 +656,10 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
 #pragma unroll
             for (int px = 0; px < 16; px++)
             {
-                const float p0 = S.pw[px][0], p1 = S.pw[px][1], p2 = S.pw[px][2];
-                ccx[px] = p0 * A.axis0[0] + p1 * A.axis0[1] + p2 * A.axis0[2];
-                ccy[px] = p0 * A.axis1[0] + p1 * A.axis1[1] + p2 * A.axis1[2];
+                float w3[3];
+                pwJ(px, w3);
+                ccx[px] = w3[0] * A.axis0[0] + w3[1] * A.axis0[1] + w3[2] * A.axis0[2];
+                ccy[px] = w3[0] * A.axis1[0] + w3[1] * A.axis1[1] + w3[2] * A.axis1[2];
             }
 #pragma unroll
             for (int px = 0; px < 16; px++)
@@ -616,8 +670,8 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
 #pragma unroll
             for (int px = 0; px < 16; px++)
             {
-                cdx[px] = ccx[px] * (float)numOpaque - cenX;
-                cdy[px] = ccy[px] * (float)numOpaque - cenY;
+                cdx[px] = ccx[px] * (float)numOpaqueJ - cenX;
+                cdy[px] = ccy[px] * (float)numOpaqueJ - cenY;
             }
         }
         float covXX = 0.0f, covYY = 0.0f, covXY = 0.0f;
@@ -639,9 +693,9 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
 #pragma unroll
         for (int px = 0; px < 16; px++)
             if ((cdx[px] * dx + cdy[px] * dy) < 0.0f)
-                isolatedMask |= 1u << px;
+                isoJ |= 1u << px;
     }
-
+    isolatedMask = (u32)__shfl((int)isoJ, own);
     // =================================== T mode x2 ===================================
     for (int call = 0; call < 2 && !groupAll; call++)
     {
@@ -677,55 +731,60 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
             const int px = lane & 15;
             S.isoErr[px] = E(isoColor[0], isoColor[1], isoColor[2], S.pix[px], S.pw[px]);
         }
-        // unique line colours: lane = table (ETC.cpp:494-560)
-        if (lane < 8)
+        // unique line colours (ETC.cpp:494-560): lane = (group member jb, table); only the block's own lists are kept, the
+        // other members' are counted for the group maxima
+        int nUnique = 0;
         {
-            const int modifier = T->thDistance[lane];
+            const int tbl = lane >> 3;
+            const u32 isoM = call == 0 ? isoJ : (~isoJ & 0xffffu);
+            int lineTotalM[3];
+            lineTotalsJ(~isoM & 0xffffu, lineTotalM);
+            const int numLineM = 16 - __popc(isoM);
+            const bool mine = jb == own;
+            const int modifier = T->thDistance[tbl];
             const int modifierOffset = modifier + modifier;
-            const int lineDivisor = numLine * 34;
-            const int lineAddend = (numLine << 4) | numLine;
+            const int lineDivisor = numLineM * 34;
+            const int lineAddend = (numLineM << 4) | numLineM;
             int n = 0, last = -1;
-            for (int k = -numLine; k <= numLine; k++)
+            const int kMax = __builtin_amdgcn_readfirstlane(groupMax(numLineM)); // the same in every lane
+            for (int k = -kMax; k <= kMax; k++)
             {
+                if (k < -numLineM || k > numLineM)
+                    continue;
                 const int modifierAddend = (int)(short)(k * modifierOffset);
                 int packed = 0, q3[3], targets[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++)
                 {
-                    int numerator = (int)(short)((int)(short)(lineTotal[ch] + lineTotal[ch] + (FAKE ? 0 : lineAddend)) + modifierAddend);
+                    int numerator = (int)(short)((int)(short)(lineTotalM[ch] + lineTotalM[ch] + (FAKE ? 0 : lineAddend)) + modifierAddend);
                     numerator = numerator < 0 ? 0 : numerator;
                     const int divided = lineDivisor == 0 ? 0 : udivSmall(numerator, lineDivisor);
                     q3[ch] = divided < 15 ? divided : 15;
                     targets[ch] = numerator;
                 }
                 if (FAKE)
-                    resolveTHFake(q3, targets, numLine);
+                    resolveTHFake(q3, targets, numLineM);
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++)
                     packed |= q3[ch] << (ch * 5);
                 if (n == 0 || packed != last)
                 {
-                    S.tColors[lane][n++] = (unsigned short)packed;
+                    if (mine)
+                        S.tColors[tbl][n] = (unsigned short)packed;
+                    n++;
                     last = packed;
                 }
             }
-            S.tCount[lane] = n;
-            groupTCount[wave][lane] = n;
+            if (mine)
+                S.tCount[tbl] = n;
+            nUnique = groupMax(n);
         }
-        __syncthreads();
-        int gmax[8], prefix[9];
+        WAVE_SYNC();
+        int prefix[9];
         prefix[0] = 0;
 #pragma unroll
         for (int t = 0; t < 8; t++)
-        {
-            int mx = 0;
-#pragma unroll
-            for (int w8 = 0; w8 < 8; w8++)
-                mx = groupTCount[w8][t] > mx ? groupTCount[w8][t] : mx;
-            gmax[t] = mx;
-            prefix[t + 1] = prefix[t] + mx;
-        }
-        __syncthreads();
+            prefix[t + 1] = prefix[t] + __shfl(nUnique, t * 8);
 
         float candErr = FLT_MAX;
         int candId = 0x7fffffff;
@@ -1441,61 +1500,58 @@ __global__ __launch_bounds__(512, 4) void cvttmi_etc2_color_kernel(const uint8_t
                     S.u.h.color[0][table] = (unsigned short)((hq[0] << 10) | (hq[1] << 5) | hq[2]);
             }
             // the premultiplier of the line colours walks the GROUP's range in steps of two, clamped to the block's own
-            // range (ETC.cpp:1025-1040): the candidates depend on the group maximum of the line-pixel counts
-            if (lane == 0)
-                groupTCount[wave][0] = numLine;
-            __syncthreads();
-            int clusterMaxLine = 0;
-#pragma unroll
-            for (int w8 = 0; w8 < 8; w8++)
-                clusterMaxLine = groupTCount[w8][0] > clusterMaxLine ? groupTCount[w8][0] : clusterMaxLine;
-            __syncthreads();
-            if (lane < 8)
+            // range (ETC.cpp:1025-1040): the candidates depend on the group maximum of the line-pixel counts.
+            // lane = (group member jb, table), as in the opaque T mode
+            int nUnique = 0;
             {
-                const int modifierOffset = T->thDistance[lane] * 2;
-                const int lineDivisor = numLine * 34;
-                const int lineAddend = (numLine << 4) | numLine;
+                const int tbl = lane >> 3;
+                const u32 baseM = call == 0 ? isoJ : (~isoJ & 0xffffu);
+                const u32 lineM = ~baseM & ~transJ & 0xffffu;
+                int lineTotalM[3];
+                lineTotalsJ(lineM, lineTotalM);
+                const int numLineM = __popc(lineM);
+                const int clusterMaxLine = __builtin_amdgcn_readfirstlane(groupMax(numLineM));
+                const bool mine = jb == own;
+                const int modifierOffset = T->thDistance[tbl] * 2;
+                const int lineDivisor = numLineM * 34;
+                const int lineAddend = (numLineM << 4) | numLineM;
                 int n = 0, last = -1;
                 for (int k = -clusterMaxLine; k <= clusterMaxLine; k += 2)
                 {
-                    int kc = k < numLine ? k : numLine;
-                    kc = kc > -numLine ? kc : -numLine;
+                    int kc = k < numLineM ? k : numLineM;
+                    kc = kc > -numLineM ? kc : -numLineM;
                     const int modifierAddend = (int)(short)(kc * modifierOffset);
                     int q[3], targets[3];
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++)
                     {
-                        int numerator = (int)(short)((int)(short)(lineTotal[ch] + lineTotal[ch] + (FAKE ? 0 : lineAddend)) + modifierAddend);
+                        int numerator = (int)(short)((int)(short)(lineTotalM[ch] + lineTotalM[ch] + (FAKE ? 0 : lineAddend)) + modifierAddend);
                         numerator = numerator < 0 ? 0 : numerator;
                         const int divided = lineDivisor == 0 ? 0 : udivSmall(numerator, lineDivisor);
                         q[ch] = divided < 15 ? divided : 15;
                         targets[ch] = numerator;
                     }
                     if (FAKE)
-                        resolveTHFake(q, targets, numLine);
+                        resolveTHFake(q, targets, numLineM);
                     const int packed = (q[0] << 10) | (q[1] << 5) | q[2];
                     if (n == 0 || packed != last)
                     {
-                        S.tColors[lane][n++] = (unsigned short)packed;
+                        if (mine)
+                            S.tColors[tbl][n] = (unsigned short)packed;
+                        n++;
                         last = packed;
                     }
                 }
-                S.tCount[lane] = n;
-                groupTCount[wave][lane] = n;
+                if (mine)
+                    S.tCount[tbl] = n;
+                nUnique = groupMax(n);
             }
-            __syncthreads();
+            WAVE_SYNC();
             int prefix[9];
             prefix[0] = 0;
 #pragma unroll
             for (int t = 0; t < 8; t++)
-            {
-                int mx = 0;
-#pragma unroll
-                for (int w8 = 0; w8 < 8; w8++)
-                    mx = groupTCount[w8][t] > mx ? groupTCount[w8][t] : mx;
-                prefix[t + 1] = prefix[t] + mx;
-            }
-            __syncthreads();
+                prefix[t + 1] = prefix[t] + __shfl(nUnique, t * 8);
 
             // candidate `id` = (table, ci) in the reference's order; own colours, then (hazard H2) one zero slot, then
             // copies of colour 0
@@ -1812,10 +1868,10 @@ extern "C" hipError_t cvttmi_launch_etc2(const void *d_blocks, void *d_out, cons
     do                                                                                                                            \
     {                                                                                                                             \
         if (fake)                                                                                                                 \
-            hipLaunchKernelGGL((cvttmi_etc2_color_kernel<M, true>), dim3(a.numBlocks / 8u), dim3(512), 0, stream,                 \
+            hipLaunchKernelGGL((cvttmi_etc2_color_kernel<M, true>), dim3(a.numBlocks), dim3(64), 0, stream,                 \
                                (const uint8_t *)d_blocks, (uint8_t *)d_out, a, d_tables);                                         \
         else                                                                                                                      \
-            hipLaunchKernelGGL((cvttmi_etc2_color_kernel<M, false>), dim3(a.numBlocks / 8u), dim3(512), 0, stream,                \
+            hipLaunchKernelGGL((cvttmi_etc2_color_kernel<M, false>), dim3(a.numBlocks), dim3(64), 0, stream,                \
                                (const uint8_t *)d_blocks, (uint8_t *)d_out, a, d_tables);                                         \
     } while (0)
     if (mode == 3 || mode == 4)
