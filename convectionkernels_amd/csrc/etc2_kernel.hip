@@ -316,6 +316,17 @@ __device__ __forceinline__ void emitH(u32 &outHi, u32 &outLo, int bc0, int bc1, 
 }
 } // namespace
 
+#ifdef CVTT_ETC_PROFILE
+// developer-only: wave cycles per stage (0 planar, 1/2 T mode calls, 3 H mode, 4 cluster fit), summed over waves
+__device__ unsigned long long g_etcProf[8];
+extern "C" int cvttmi_etc_prof_read(unsigned long long *out)
+{
+    unsigned long long zero[8] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_etcProf), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_etcProf), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 // ------------------------------------------------------------------------------------------
 // MODE 0: EncodeETC2 (RGB), 1: EncodeETC1, 2: EncodeETC2PunchthroughAlpha; FAKE: ETC_UseFakeBT709
 template <int MODE, bool FAKE>
@@ -410,7 +421,10 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
 
     float bestError = FLT_MAX;
     u32 outHi = 0, outLo = 0;
-#ifdef CVTT_ETC_DEBUG
+#ifdef CVTT_ETC_PROFILE
+    unsigned long long profT = __builtin_readcyclecounter();
+#define DBG_TAP(i) do { const unsigned long long now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_etcProf[i], now - profT); profT = now; } while (0)
+#elif defined(CVTT_ETC_DEBUG)
     float *dbg = reinterpret_cast<float *>(A.debug) + (size_t)blockIndex * 8;
 #define DBG_TAP(i) do { if (lane == 0 && A.debug) dbg[i] = bestError; } while (0)
 #else
@@ -1027,7 +1041,64 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
         {
             // half-block membership: flip 0 = left/right 2x4 columns, flip 1 = top/bottom (g_flipTables, ETC.cpp:47-57)
             // pixel list of (flip, sector): computed on the fly
-            // ---- de-duplicated base colours: lane = sector * 8 + table (ETC.cpp:2690-2791) ----
+            // ---- base colours of the cluster fit (ETC.cpp:2690-2760): all 2 x 624 (sector, table, offset) candidates in
+            // parallel, one per lane and pass, parked in the (still unused) attempt-error area; the order-dependent
+            // removal of consecutive duplicates follows, one lane per (sector, table) ----
+            unsigned short *const rawColors = reinterpret_cast<unsigned short *>(&S.u.a.err[0][0]); // [16][82]
+            if (!punch)
+            {
+                int cum[2][3] = {{0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+                for (int px = 0; px < 16; px++)
+                {
+                    const int inSector = flip == 0 ? ((px >> 1) & 1) : (px >> 3);
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                    {
+                        const int v = S.pix[px][ch];
+                        cum[0][ch] += inSector ? 0 : v;
+                        cum[1][ch] += inSector ? v : 0;
+                    }
+                }
+                for (int id = lane; id < 2 * kMaxAttempts; id += 64)
+                {
+                    const int sector = id >= kMaxAttempts ? 1 : 0;
+                    const int f = id - sector * kMaxAttempts;
+                    int table = 0;
+#pragma unroll
+                    for (int t = 1; t < 8; t++)
+                        if (f >= T->clusterStart[t])
+                            table = t;
+                    const int off = T->clusterOffsets[f];
+                    int packed = 0;
+                    if (FAKE)
+                    {
+                        int offsetCumulative[3], q3[3];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                        {
+                            const int cu = (int)(short)((sector ? cum[1][ch] : cum[0][ch]) + off);
+                            offsetCumulative[ch] = cu < 0 ? 0 : (cu > 2040 ? 2040 : cu);
+                        }
+                        resolveHalfFake(q3, offsetCumulative, d == 1, fakeAccurate, T);
+                        packed = q3[0] | (q3[1] << 5) | (q3[2] << 10);
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                        {
+                            int cu = (int)(short)((sector ? cum[1][ch] : cum[0][ch]) + off);
+                            cu = cu < 0 ? 0 : (cu > 2040 ? 2040 : cu);
+                            const u32 q = d == 1 ? ((((u32)cu << 5) - (u32)cu + ((u32)cu >> 3) + 1024u) & 0xffffu) >> 11
+                                                 : ((((u32)cu << 5) - ((u32)cu << 1) + ((u32)cu >> 3) + 2048u) & 0xffffu) >> 12;
+                            packed |= (int)q << (ch * 5);
+                        }
+                    }
+                    rawColors[(sector * 8 + table) * 82 + (f - T->clusterStart[table])] = (unsigned short)packed;
+                }
+                WAVE_SYNC();
+            }
             if (lane < 16)
             {
                 const int sector = lane >> 3, table = lane & 7;
@@ -1076,30 +1147,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                 else
                 for (int oi = 0; oi < numOffsets; oi++)
                 {
-                    const int off = T->clusterOffsets[start + oi];
-                    int packed = 0;
-                    if (FAKE)
-                    {
-                        int offsetCumulative[3], q3[3];
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++)
-                        {
-                            const int cu = (int)(short)(cumulative[ch] + off);
-                            offsetCumulative[ch] = cu < 0 ? 0 : (cu > 2040 ? 2040 : cu);
-                        }
-                        resolveHalfFake(q3, offsetCumulative, d == 1, fakeAccurate, T);
-                        packed = q3[0] | (q3[1] << 5) | (q3[2] << 10);
-                    }
-                    else
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++)
-                    {
-                        int cu = (int)(short)(cumulative[ch] + off);
-                        cu = cu < 0 ? 0 : (cu > 2040 ? 2040 : cu);
-                        const u32 q = d == 1 ? ((((u32)cu << 5) - (u32)cu + ((u32)cu >> 3) + 1024u) & 0xffffu) >> 11
-                                             : ((((u32)cu << 5) - ((u32)cu << 1) + ((u32)cu >> 3) + 2048u) & 0xffffu) >> 12;
-                        packed |= (int)q << (ch * 5);
-                    }
+                    const int packed = rawColors[lane * 82 + oi];
                     if (n == 0 || packed != last)
                     {
                         S.dColors[lane][n++] = (unsigned short)packed;
