@@ -903,49 +903,63 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
         u32 hBestBits = 0;        // sectorBits | signBits << 16
         int hBestC0 = 0, hBestC1 = 0;
 
-        for (int table = 0; table < 8; table++)
+        // base colours of all eight tables and both sectors (ETC.cpp:691-737), one (table, sector, premultiplier) per lane
+        // and pass: 8 x 34 candidates; then the order-dependent removal of consecutive duplicates, one lane per
+        // (table, sector), in place.  Lists: S.dColors[table * 2 + sector][], counts: S.dCount[table * 2 + sector]
+        // (both free until the cluster fit).
         {
-            const int modifier = T->thDistance[table];
-            // unique colours per sector: lane = sector (ETC.cpp:691-737)
-            if (lane < 2)
+            const int perTable = 2 * counts[0] + 1 + 2 * counts[1] + 1; // 34
+            for (int id = lane; id < 8 * perTable; id += 64)
             {
-                const int cnt = lane == 0 ? counts[0] : counts[1];
-                const int t0 = lane == 0 ? totals[0][0] : totals[1][0];
-                const int t1 = lane == 0 ? totals[0][1] : totals[1][1];
-                const int t2 = lane == 0 ? totals[0][2] : totals[1][2];
-                int n = 0, last = -1;
-                for (int k = -cnt; k <= cnt; k++)
-                {
-                    int q[3];
-                    const int tt[3] = {t0, t1, t2};
+                const int table = id / perTable, j = id - table * perTable;
+                const int sector = j < 2 * counts[0] + 1 ? 0 : 1;
+                const int kk = sector ? j - (2 * counts[0] + 1) : j;
+                const int cnt = sector ? counts[1] : counts[0];
+                const int k = kk - cnt;
+                const int modifier = T->thDistance[table];
+                int q[3];
 #pragma unroll
-                    for (int ch = 0; ch < 3; ch++)
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    const int tt = sector ? totals[1][ch] : totals[0][ch];
+                    if (cnt == 0)
+                        q[ch] = 0;
+                    else
                     {
-                        if (cnt == 0)
-                            q[ch] = 0;
-                        else
-                        {
-                            int v = (int)(short)(tt[ch] * 2 + cnt * 17 + modifier * 2 * k);
-                            v = v < 0 ? 0 : v;
-                            v = udivSmall(v, cnt * 34);
-                            q[ch] = v < 15 ? v : 15;
-                        }
+                        int v = (int)(short)(tt * 2 + cnt * 17 + modifier * 2 * k);
+                        v = v < 0 ? 0 : v;
+                        v = udivSmall(v, cnt * 34);
+                        q[ch] = v < 15 ? v : 15;
                     }
-                    const int packed = (q[0] << 10) | (q[1] << 5) | q[2];
+                }
+                S.dColors[table * 2 + sector][kk] = (unsigned short)((q[0] << 10) | (q[1] << 5) | q[2]);
+            }
+            WAVE_SYNC();
+            if (lane < 16)
+            {
+                const int cnt = (lane & 1) ? counts[1] : counts[0];
+                int n = 0, last = -1;
+                for (int kk = 0; kk <= 2 * cnt; kk++)
+                {
+                    const int packed = S.dColors[lane][kk];
                     if (n == 0 || packed != last)
                     {
-                        S.u.h.color[lane][n++] = (unsigned short)packed;
+                        S.dColors[lane][n++] = (unsigned short)packed; // n <= kk: in place
                         last = packed;
                     }
                 }
                 S.dCount[lane] = n;
             }
             WAVE_SYNC();
-            const int n0 = S.dCount[0], n1 = S.dCount[1];
+        }
+        for (int table = 0; table < 8; table++)
+        {
+            const int modifier = T->thDistance[table];
+            const int n0 = S.dCount[table * 2], n1 = S.dCount[table * 2 + 1];
             // per-colour error rows: lane = colour (ETC.cpp:752-787)
             if (lane < n0 + n1)
             {
-                const int packed = lane < n0 ? S.u.h.color[0][lane] : S.u.h.color[1][lane - n0];
+                const int packed = lane < n0 ? S.dColors[table * 2][lane] : S.dColors[table * 2 + 1][lane - n0];
                 int c0[3], c1[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++)
@@ -996,8 +1010,8 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                         hBestErr = totalError;
                         hBestId = table * 1024 + k;
                         hBestBits = sectorBits | (signBits << 16);
-                        hBestC0 = S.u.h.color[0][i0];
-                        hBestC1 = S.u.h.color[1][i1];
+                        hBestC0 = S.dColors[table * 2][i0];
+                        hBestC1 = S.dColors[table * 2 + 1][i1];
                     }
                 }
             }
