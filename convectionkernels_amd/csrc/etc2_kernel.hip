@@ -1112,8 +1112,29 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                     rawColors[(sector * 8 + table) * 82 + (f - T->clusterStart[table])] = (unsigned short)packed;
                 }
                 WAVE_SYNC();
+                // removal of consecutive duplicates (ETC.cpp:2762-2775): a colour stays iff it differs from its
+                // predecessor; positions by ballot prefix, 64 candidates of one (sector, table) list at a time
+                for (int slot = 0; slot < 16; slot++)
+                {
+                    const int numOffsets = T->clusterCount[slot & 7];
+                    int kept = 0;
+                    for (int c0 = 0; c0 < numOffsets; c0 += 64)
+                    {
+                        const int oi = c0 + lane;
+                        const bool in = oi < numOffsets;
+                        const int cur = in ? (int)rawColors[slot * 82 + oi] : -1;
+                        const int prev = (in && oi > 0) ? (int)rawColors[slot * 82 + oi - 1] : -1;
+                        const bool keep = in && (oi == 0 || cur != prev);
+                        const u64 bal = __ballot(keep);
+                        if (keep)
+                            S.dColors[slot][kept + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)cur;
+                        kept += __popcll(bal);
+                    }
+                    if (lane == 0)
+                        S.dCount[slot] = kept;
+                }
             }
-            if (lane < 16)
+            if (punch && lane < 16)
             {
                 const int sector = lane >> 3, table = lane & 7;
                 int cumulative[3] = {0, 0, 0};
@@ -1156,16 +1177,6 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                             S.dColors[lane][n++] = (unsigned short)packed;
                             last = packed;
                         }
-                    }
-                }
-                else
-                for (int oi = 0; oi < numOffsets; oi++)
-                {
-                    const int packed = rawColors[lane * 82 + oi];
-                    if (n == 0 || packed != last)
-                    {
-                        S.dColors[lane][n++] = (unsigned short)packed;
-                        last = packed;
                     }
                 }
                 S.dCount[lane] = n;
