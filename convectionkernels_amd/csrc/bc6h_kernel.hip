@@ -53,7 +53,7 @@ namespace
 //   scratch (HBM/L2, [wave][entry][lane], one coalesced 256-byte line per access):
 //         EPQ0 36 dwords + IDX 2 subsets x 12 rounds x 2 dwords (4 bits per pixel) = 84 dwords,
 //         written once per round, read only by the legality pass / at a commit
-constexpr int kErrBase = 0, kEpqBase = 24, kMetaDwords = 60;
+constexpr int kEpqBase = 0, kMetaDwords = 36; // the 24 per-round errors live in registers (uniform dynamic index)
 constexpr int kScrEpq0 = 0, kScrIdx = 36, kScratchDwords = 84;
 #ifndef CVTT_BC6H_WAVES
 #define CVTT_BC6H_WAVES 3
@@ -204,6 +204,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                                          u32 *__restrict__ scratch)
 {
     __shared__ u32 meta[kMetaDwords][64];
+    float errR[24]; // error of every (round, subset) of the current partition; indexed by wave-uniform loop counters
     const int lane = threadIdx.x;
     u32 *const scr = scratch + (size_t)blockIdx.x * (kScratchDwords * 64) + lane; // entry e at scr[e * 64]
     const u32 blockIndex = blockIdx.x * 64u + (u32)lane;
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     }
                                 scr[(kScrIdx + (subset * 12 + metaRound) * 2) * 64] = idxLo;
                                 scr[(kScrIdx + (subset * 12 + metaRound) * 2 + 1) * 64] = idxHi;
-                                meta[kErrBase + metaRound * 2 + subset][lane] = __float_as_uint(subsetError);
+                                errR[metaRound * 2 + subset] = subsetError;
                             }
                             PROF_MARK(4)
                         }
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                     minErr1 = FLT_MAX;
                     for (int m = 0; m < 12; m++)
                     {
-                        const float e = __uint_as_float(meta[kErrBase + m * 2 + 1][lane]);
+                        const float e = errR[m * 2 + 1];
                         if (((roundValid1 >> m) & 1u) && e < minErr1)
                             minErr1 = e;
                     }
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                 for (int meta0 = 0; meta0 < 12; meta0++)
                 {
                     const bool valid0 = ((roundValid0 >> meta0) & 1u) != 0;
-                    const float err0 = __uint_as_float(meta[kErrBase + meta0 * 2][lane]);
+                    const float err0 = errR[meta0 * 2];
                     const bool canBeat = valid0 && ((partitioned ? err0 + minErr1 : err0) < bestError);
                     if (__ballot(canBeat) == 0)
                         continue;
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                         const bool roundsOk = valid0 && (!partitioned || ((roundValid1 >> meta1) & 1u));
                         float combined = err0;
                         if (partitioned)
-                            combined = combined + __uint_as_float(meta[kErrBase + meta1 * 2 + 1][lane]);
+                            combined = combined + errR[meta1 * 2 + 1];
                         const bool errorBetter = roundsOk && (combined < bestError);
                         if (__ballot(errorBetter) == 0)
                             continue;
