@@ -432,18 +432,20 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     }
                             }
                             // raw (un-inverted) index of the pixel packed in (a, b); SelectIndexHDRSlow keeps the FIRST minimum
-                            auto rawIndexOf = [&](u32 a, u32 b) -> int {
-                                const int c0 = (int)(short)(a & 0xffffu), c1 = (int)(short)(a >> 16), c2 = (int)(short)(b & 0xffffu);
+                            // lf: the pixel's three half values as floats (slow indexing only; the caller converts them once
+                            // and uses them for the error as well)
+                            auto rawIndexOf = [&](u32 a, u32 b, const float (&lf)[3]) -> int {
                                 if (FAST)
                                 {
+                                    const int c0 = (int)(short)(a & 0xffffu), c1 = (int)(short)(a >> 16), c2 = (int)(short)(b & 0xffffu);
                                     float dist = ((float)c0 - origin[0]) * axis[0];
                                     dist = dist + ((float)c1 - origin[1]) * axis[1];
                                     dist = dist + ((float)c2 - origin[2]) * axis[2];
                                     return (int)clampRound(dist, maxValue);
                                 }
-                                const float l0 = twosCLHalfToFloat<SIGNED>(c0) * A.w[0];
-                                const float l1 = twosCLHalfToFloat<SIGNED>(c1) * A.w[1];
-                                const float l2 = twosCLHalfToFloat<SIGNED>(c2) * A.w[2];
+                                const float l0 = lf[0] * A.w[0];
+                                const float l1 = lf[1] * A.w[1];
+                                const float l2 = lf[2] * A.w[2];
                                 float be = 0.0f;
                                 int bi = 0;
 #pragma unroll
@@ -476,7 +478,14 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     fa = pk01[px];
                                     fb = pk2[px];
                                 }
-                            const int fixRaw = rawIndexOf(fetchPixel(fa), fetchPixel(fb));
+                            float fixLf[3] = {0.0f, 0.0f, 0.0f};
+                            if (!FAST)
+                            {
+                                fixLf[0] = twosCLHalfToFloat<SIGNED>((int)(short)(fa & 0xffffu));
+                                fixLf[1] = twosCLHalfToFloat<SIGNED>((int)(short)(fa >> 16));
+                                fixLf[2] = twosCLHalfToFloat<SIGNED>((int)(short)(fb & 0xffffu));
+                            }
+                            const int fixRaw = rawIndexOf(fetchPixel(fa), fetchPixel(fb), fixLf);
                             PROF_MARK(2)
                             const bool invert = (indexRange / 2 - 1) < fixRaw;
                             if (invert)
@@ -517,7 +526,14 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     if ((sm >> px) & 1u)
                                     {
                                         const u32 a = fetchPixel(pk01[px]), b = fetchPixel(pk2[px]);
-                                        const int raw = rawIndexOf(a, b);
+                                        float lf[3] = {0.0f, 0.0f, 0.0f};
+                                        if (!FAST)
+                                        {
+                                            lf[0] = twosCLHalfToFloat<SIGNED>((int)(short)(a & 0xffffu));
+                                            lf[1] = twosCLHalfToFloat<SIGNED>((int)(short)(a >> 16));
+                                            lf[2] = twosCLHalfToFloat<SIGNED>((int)(short)(b & 0xffffu));
+                                        }
+                                        const int raw = rawIndexOf(a, b, lf);
                                         const int index = invert ? (indexRange - 1) - raw : raw;
                                         if (px < 8)
                                             idxLo |= (u32)index << (4 * px);
@@ -541,7 +557,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                             }
                                             else
                                             {
-                                                const float d = twosCLHalfToFloat<SIGNED>(rec) - twosCLHalfToFloat<SIGNED>(orig[ch]);
+                                                const float d = twosCLHalfToFloat<SIGNED>(rec) - lf[ch];
                                                 sq = d * d;
                                             }
                                             err = uniformErr ? (err + sq) : (err + sq * A.wSq[ch]);
