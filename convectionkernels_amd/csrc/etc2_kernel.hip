@@ -745,130 +745,203 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
             const int px = lane & 15;
             S.isoErr[px] = E(isoColor[0], isoColor[1], isoColor[2], S.pix[px], S.pw[px]);
         }
-        // unique line colours (ETC.cpp:494-560): lane = (group member jb, table); only the block's own lists are kept, the
-        // other members' are counted for the group maxima
-        int nUnique = 0;
+        // unique line colours of this block (ETC.cpp:494-560): all 8 x (2 numLine + 1) (table, premultiplier) candidates in
+        // parallel, then the order-dependent removal of consecutive duplicates per table (in place, by ballot prefix)
         {
-            const int tbl = lane >> 3;
-            const u32 isoM = call == 0 ? isoJ : (~isoJ & 0xffffu);
-            int lineTotalM[3];
-            lineTotalsJ(~isoM & 0xffffu, lineTotalM);
-            const int numLineM = 16 - __popc(isoM);
-            const bool mine = jb == own;
-            const int modifier = T->thDistance[tbl];
-            const int modifierOffset = modifier + modifier;
-            const int lineDivisor = numLineM * 34;
-            const int lineAddend = (numLineM << 4) | numLineM;
-            int n = 0, last = -1;
-            const int kMax = __builtin_amdgcn_readfirstlane(groupMax(numLineM)); // the same in every lane
-            for (int k = -kMax; k <= kMax; k++)
+            const int span = 2 * numLine + 1; // <= 33
+            const int lineDivisor = numLine * 34;
+            const int lineAddend = (numLine << 4) | numLine;
+            for (int id = lane; id < 8 * span; id += 64)
             {
-                if (k < -numLineM || k > numLineM)
-                    continue;
-                const int modifierAddend = (int)(short)(k * modifierOffset);
+                const int tbl = id / span, kk = id - tbl * span;
+                const int modifierAddend = (int)(short)((kk - numLine) * (T->thDistance[tbl] * 2));
                 int packed = 0, q3[3], targets[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++)
                 {
-                    int numerator = (int)(short)((int)(short)(lineTotalM[ch] + lineTotalM[ch] + (FAKE ? 0 : lineAddend)) + modifierAddend);
+                    int numerator = (int)(short)((int)(short)(lineTotal[ch] + lineTotal[ch] + (FAKE ? 0 : lineAddend)) + modifierAddend);
                     numerator = numerator < 0 ? 0 : numerator;
                     const int divided = lineDivisor == 0 ? 0 : udivSmall(numerator, lineDivisor);
                     q3[ch] = divided < 15 ? divided : 15;
                     targets[ch] = numerator;
                 }
                 if (FAKE)
-                    resolveTHFake(q3, targets, numLineM);
+                    resolveTHFake(q3, targets, numLine);
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++)
                     packed |= q3[ch] << (ch * 5);
-                if (n == 0 || packed != last)
-                {
-                    if (mine)
-                        S.tColors[tbl][n] = (unsigned short)packed;
-                    n++;
-                    last = packed;
-                }
+                S.tColors[tbl][kk] = (unsigned short)packed;
             }
-            if (mine)
-                S.tCount[tbl] = n;
-            nUnique = groupMax(n);
+            WAVE_SYNC();
+            for (int tbl = 0; tbl < 8; tbl++)
+            {
+                const bool in = lane < span;
+                const int cur = in ? (int)S.tColors[tbl][lane] : -1;
+                const int prev = (in && lane > 0) ? (int)S.tColors[tbl][lane - 1] : -1;
+                const bool keep = in && (lane == 0 || cur != prev);
+                const u64 bal = __ballot(keep);
+                WAVE_SYNC(); // every lane has read before anyone writes
+                if (keep)
+                    S.tColors[tbl][__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)cur;
+                if (lane == 0)
+                    S.tCount[tbl] = __popcll(bal);
+            }
+            WAVE_SYNC();
         }
-        WAVE_SYNC();
+        // Candidates in the reference's order: per table its unique colours, then -- hazard H2, only when another block of
+        // the group has MORE unique colours for that table -- one slot that reads as colour 0 (the copies of colour 0
+        // behind it repeat candidate 0 and can never pass the strict '<').  Whether the slot exists takes the other seven
+        // blocks' counts, which cost more than this block's whole candidate generation, and the black line colour almost
+        // never wins; so the slot is evaluated as "tentative" and the counts are only computed when a tentative candidate
+        // would be the winner.
+        // Work order: the real candidates table by table, then the eight zero slots (they usually fit in the idle lanes of
+        // the last pass).  Reference order, for ties: key = table << 8 | position in the table's list.
         int prefix[9];
         prefix[0] = 0;
 #pragma unroll
         for (int t = 0; t < 8; t++)
-            prefix[t + 1] = prefix[t] + __shfl(nUnique, t * 8);
-
-        float candErr = FLT_MAX;
-        int candId = 0x7fffffff;
-        u32 candSel = 0;
-        for (int base = 0; base < prefix[8]; base += 64)
+            prefix[t + 1] = prefix[t] + S.tCount[t];
+        // attempt 0: zero slots tracked apart (tentative); attempt 1 (rare): the slots of the tables in presentMask are
+        // candidates like the others, the rest is skipped.  One copy of the evaluation loop serves both.
+        float candErr = FLT_MAX, wErr = FLT_MAX;
+        int candId = 0x7fffffff, wId = 0x7fffffff;
+        u32 candSel = 0, presentMask = 0;
+        for (int attempt = 0; attempt < 2; attempt++)
         {
-            const int id = base + lane;
-            if (id < prefix[8])
+            const bool exact = attempt == 1;
+            float rErr = FLT_MAX, zErr = FLT_MAX;
+            int rId = 0x7fffffff, zId = 0x7fffffff;
+            u32 rSel = 0;
+            for (int base = 0; base < prefix[8] + 8; base += 64)
             {
-                int table = 0;
-#pragma unroll
-                for (int t = 1; t < 8; t++)
-                    if (id >= prefix[t])
-                        table = t;
-                const int ci = id - prefix[table];
-                const int n = S.tCount[table];
-                // own colours, then (hazard H2) one zero slot, then copies of colour 0
-                const int packed = ci < n ? S.tColors[table][ci] : (ci == n ? 0 : S.tColors[table][0]);
-                const int modifier = T->thDistance[table];
-                int lc[3][3];
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++)
+                const int e = base + lane;
+                if (e < prefix[8] + 8)
                 {
-                    const int q = (packed >> (ch * 5)) & 15;
-                    const int u = (q << 4) | q;
-                    lc[0][ch] = u + modifier < 255 ? u + modifier : 255;
-                    lc[1][ch] = u;
-                    lc[2][ch] = u - modifier > 0 ? u - modifier : 0;
-                }
-                u32 selectors = 0;
-                float error = 0.0f;
-                for (int px = 0; px < 16; px++)
-                {
-                    float pixelError = S.isoErr[px];
-                    u32 sel = 0;
+                    const bool zeroSlot = e >= prefix[8];
+                    int table = 0;
 #pragma unroll
-                    for (int i = 0; i < 3; i++)
+                    for (int t = 1; t < 8; t++)
+                        if (e >= prefix[t])
+                            table = t;
+                    if (zeroSlot)
+                        table = e - prefix[8];
+                    const int ci = zeroSlot ? S.tCount[table] : e - prefix[table];
+                    const int id = (table << 8) | ci;
+                    if (zeroSlot && exact && !((presentMask >> table) & 1u))
+                        continue;
+                    const int packed = zeroSlot ? 0 : (int)S.tColors[table][ci];
+                    const int modifier = T->thDistance[table];
+                    int lc[3][3];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
                     {
-                        const float e = E.wu(lc[i][0], lc[i][1], lc[i][2], S.pix[px], S.pw[px]); // sic: never the fake metric
-                        if (e < pixelError)
-                            sel = (u32)(i + 1);
-                        pixelError = sseMin(e, pixelError);
+                        const int q = (packed >> (ch * 5)) & 15;
+                        const int u = (q << 4) | q;
+                        lc[0][ch] = u + modifier < 255 ? u + modifier : 255;
+                        lc[1][ch] = u;
+                        lc[2][ch] = u - modifier > 0 ? u - modifier : 0;
                     }
-                    error = error + pixelError;
-                    selectors |= sel << (px * 2);
-                }
-                if (error < candErr) // ids ascend per lane, strict '<' keeps the first
-                {
-                    candErr = error;
-                    candId = id;
-                    candSel = selectors;
+                    u32 selectors = 0;
+                    float error = 0.0f;
+                    for (int px = 0; px < 16; px++)
+                    {
+                        float pixelError = S.isoErr[px];
+                        u32 sel = 0;
+#pragma unroll
+                        for (int i = 0; i < 3; i++)
+                        {
+                            const float e = E.wu(lc[i][0], lc[i][1], lc[i][2], S.pix[px], S.pw[px]); // sic: never the fake metric
+                            if (e < pixelError)
+                                sel = (u32)(i + 1);
+                            pixelError = sseMin(e, pixelError);
+                        }
+                        error = error + pixelError;
+                        selectors |= sel << (px * 2);
+                    }
+                    if (zeroSlot && !exact)
+                    {
+                        if (error < zErr || (error == zErr && id < zId))
+                        {
+                            zErr = error;
+                            zId = id;
+                        }
+                    }
+                    else if (error < rErr || (error == rErr && id < rId)) // the reference keeps the first in ITS order
+                    {
+                        rErr = error;
+                        rId = id;
+                        rSel = selectors;
+                    }
                 }
             }
+            candErr = rErr;
+            candId = rId;
+            candSel = rSel;
+            wErr = rErr;
+            wId = rId;
+            waveArgmin(wErr, wId);
+            if (exact)
+                break;
+            float wzErr = zErr;
+            int wzId = zId;
+            waveArgmin(wzErr, wzId);
+            if (!(wzErr < bestError && (wzErr < wErr || (wzErr == wErr && wzId < wId))))
+                break;
+            // a zero slot would win: now the group's counts are needed (lane = (group member jb, table), counting only)
+            int nMember;
+            {
+                const int tbl = lane >> 3;
+                const u32 isoM = call == 0 ? isoJ : (~isoJ & 0xffffu);
+                int lineTotalM[3];
+                lineTotalsJ(~isoM & 0xffffu, lineTotalM);
+                const int numLineM = 16 - __popc(isoM);
+                const int modifierOffset = T->thDistance[tbl] * 2;
+                const int lineDivisor = numLineM * 34;
+                const int lineAddend = (numLineM << 4) | numLineM;
+                int n = 0, last = -1;
+                const int kMax = __builtin_amdgcn_readfirstlane(groupMax(numLineM));
+                for (int k = -kMax; k <= kMax; k++)
+                {
+                    if (k < -numLineM || k > numLineM)
+                        continue;
+                    const int modifierAddend = (int)(short)(k * modifierOffset);
+                    int packed = 0, q3[3], targets[3];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                    {
+                        int numerator = (int)(short)((int)(short)(lineTotalM[ch] + lineTotalM[ch] + (FAKE ? 0 : lineAddend)) + modifierAddend);
+                        numerator = numerator < 0 ? 0 : numerator;
+                        const int divided = lineDivisor == 0 ? 0 : udivSmall(numerator, lineDivisor);
+                        q3[ch] = divided < 15 ? divided : 15;
+                        targets[ch] = numerator;
+                    }
+                    if (FAKE)
+                        resolveTHFake(q3, targets, numLineM);
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                        packed |= q3[ch] << (ch * 5);
+                    if (n == 0 || packed != last)
+                    {
+                        n++;
+                        last = packed;
+                    }
+                }
+                nMember = groupMax(n);
+            }
+            presentMask = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+                if (__shfl(nMember, t * 8) > S.tCount[t])
+                    presentMask |= 1u << t;
         }
-        float wErr = candErr;
-        int wId = candId;
-        waveArgmin(wErr, wId);
         if (wErr < bestError)
         {
             bestError = wErr;
-            const int src = wId & 63; // candidate id -> owning lane
-            const u32 selectors = __shfl(candSel, src);
-            int table = 0;
-#pragma unroll
-            for (int t = 1; t < 8; t++)
-                if (wId >= prefix[t])
-                    table = t;
-            const int ci = wId - prefix[table];
-            const int n = S.tCount[table];
-            const int packed = ci < n ? S.tColors[table][ci] : (ci == n ? 0 : S.tColors[table][0]);
+            // the winner's selectors sit in the lane that evaluated it
+            const u64 who = __ballot(candId == wId && candErr == wErr);
+            const u32 selectors = __shfl(candSel, __ffsll((long long)who) - 1);
+            const int table = wId >> 8, ci = wId & 255;
+            const int packed = ci < S.tCount[table] ? (int)S.tColors[table][ci] : 0;
             const int lineColor[3] = {packed & 15, (packed >> 5) & 15, (packed >> 10) & 15};
             emitT(outHi, outLo, lineColor, isoQ, selectors, table);
         }
