@@ -888,6 +888,10 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
             if (!(wzErr < bestError && (wzErr < wErr || (wzErr == wErr && wzId < wId))))
                 break;
             // a zero slot would win: now the group's counts are needed (lane = (group member jb, table), counting only)
+#ifdef CVTT_ETC_PROFILE
+            if (lane == 0)
+                atomicAdd(&g_etcProf[6], 1ull);
+#endif
             int nMember;
             {
                 const int tbl = lane >> 3;

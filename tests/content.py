@@ -257,3 +257,20 @@ def punchthrough_blocks(seed, groups_per_kind=4):
     b = colour(18); b[..., 3] = 255; parts.append(b)
     b = colour(19); parts.append(b)  # whatever alpha the mixed content carries
     return np.concatenate(parts)
+
+
+def dark_blocks(seed, n):
+    """(4n,16,4) uint8: dark content on which the ETC2 T mode's "zero slot" (hazard H2: the candidate just past a block's
+    unique line colours reads as black when another block of the group has more of them) can be the winner: very dark
+    noise, dark with bright outliers, black + random pixels with binary alpha, flat colours with black pixels."""
+    rng = _rng(seed)
+    fam = []
+    b = rng.integers(0, 24, (n, 16, 4)).astype(np.uint8); b[..., 3] = 255; fam.append(b)
+    b = rng.integers(0, 8, (n, 16, 4)).astype(np.uint8)
+    m = rng.random((n, 16)) < 0.15
+    b[m] = rng.integers(100, 256, (int(m.sum()), 4)); b[..., 3] = 255; fam.append(b)
+    b = np.zeros((n, 16, 4), np.uint8)
+    m = rng.random((n, 16)) < 0.3
+    b[m] = rng.integers(0, 256, (int(m.sum()), 4)); b[..., 3] = rng.integers(0, 2, (n, 16)) * 255; fam.append(b)
+    b = rng.integers(0, 256, (n, 1, 4)).astype(np.uint8).repeat(16, 1); b[::3, ::2, :3] = 0; b[..., 3] = 255; fam.append(b)
+    return np.concatenate(fam)

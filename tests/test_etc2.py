@@ -136,6 +136,23 @@ def test_gpu_fake_bt709_vs_oracle(gpu_ctx, oracle_lib):
 
 
 @pytest.mark.gpu
+def test_gpu_dark_content_zero_slot(gpu_ctx, oracle_lib):
+    """dark blocks make the T mode's zero-slot candidate (hazard H2) win, which sends the kernel through its exact path
+    (the group's unique-colour counts are only computed then)"""
+    import torch
+    from convectionkernels_amd import api
+    blocks = content.dark_blocks(7, 2048)
+    t = torch.from_numpy(blocks).cuda()
+    for flags in (api.Flags.Default, api.Flags.Default | api.Flags.Uniform):
+        opt = pyref.make_options(flags=flags)
+        for mode, fn in ((0, gpu_ctx.encode_etc2), (4, gpu_ctx.encode_etc2_punchthrough_alpha)):
+            exp = oracle_lib.encode_etc2(blocks, opt, mode, threads=8)
+            out = fn(t, api.Options(flags=flags)).cpu().numpy()
+            bad = np.nonzero((out != exp).any(axis=1))[0]
+            assert bad.size == 0, (mode, bad[:8])
+
+
+@pytest.mark.gpu
 def test_gpu_punchthrough_vs_oracle(gpu_ctx, oracle_lib):
     """larger run on the device path: cut-out structures + config-4 noise (alpha random -> half the pixels transparent)"""
     import torch

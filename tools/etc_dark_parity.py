@@ -27,3 +27,10 @@ for mode, fn in ((0, ctx.encode_etc2), (4, ctx.encode_etc2_punchthrough_alpha)):
         # share of T-mode blocks with black line colour
         print("mode", mode, "flags", hex(flags), "blocks", blocks.shape[0], "mismatches", k, flush=True)
 print("TOTAL", bad)
+try:  # profile builds count how often the exact path ran
+    import ctypes
+    buf = (ctypes.c_ulonglong * 8)()
+    api.load_library().cvttmi_etc_prof_read(buf)
+    print("T-mode exact-path executions:", buf[6])
+except AttributeError:
+    pass
