@@ -42,9 +42,9 @@ struct EtcWaveShared
     {
         struct
         {
-            float err[36][16];       // H mode: min error of colour ci +/- modifier per pixel
+            float err[72][16];       // H mode: min error of colour ci +/- modifier per pixel, two tables at a time
             unsigned short color[2][36];
-            unsigned short sign[36];
+            unsigned short sign[72];
         } h;
         struct
         {
@@ -1029,47 +1029,64 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
             }
             WAVE_SYNC();
         }
-        for (int table = 0; table < 8; table++)
+        // two tables per step, so that the (at most 34-entry) error-row pass and the last pair pass of a table do not leave
+        // most lanes idle
+        for (int tp = 0; tp < 4; tp++)
         {
-            const int modifier = T->thDistance[table];
-            const int n0 = S.dCount[table * 2], n1 = S.dCount[table * 2 + 1];
+            const int tabA = 2 * tp, tabB = tabA + 1;
+            const int nA0 = S.dCount[tabA * 2], nA1 = S.dCount[tabA * 2 + 1], nB0 = S.dCount[tabB * 2], nB1 = S.dCount[tabB * 2 + 1];
+            const int rowsA = nA0 + nA1, rowsB = nB0 + nB1; // table B's rows follow table A's
             // per-colour error rows: lane = colour (ETC.cpp:752-787)
-            if (lane < n0 + n1)
+            for (int base = 0; base < rowsA + rowsB; base += 64)
             {
-                const int packed = lane < n0 ? S.dColors[table * 2][lane] : S.dColors[table * 2 + 1][lane - n0];
-                int c0[3], c1[3];
+                const int r = base + lane;
+                if (r < rowsA + rowsB)
+                {
+                    const bool isB = r >= rowsA;
+                    const int table = isB ? tabB : tabA;
+                    const int li = isB ? r - rowsA : r;
+                    const int n0 = isB ? nB0 : nA0;
+                    const int modifier = T->thDistance[table];
+                    const int packed = li < n0 ? S.dColors[table * 2][li] : S.dColors[table * 2 + 1][li - n0];
+                    int c0[3], c1[3];
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++)
-                {
-                    const int q = (packed >> ((2 - ch) * 5)) & 15;
-                    const int u = (q << 4) | q;
-                    c0[ch] = u + modifier < 255 ? u + modifier : 255;
-                    c1[ch] = u - modifier > 0 ? u - modifier : 0;
+                    for (int ch = 0; ch < 3; ch++)
+                    {
+                        const int q = (packed >> ((2 - ch) * 5)) & 15;
+                        const int u = (q << 4) | q;
+                        c0[ch] = u + modifier < 255 ? u + modifier : 255;
+                        c1[ch] = u - modifier > 0 ? u - modifier : 0;
+                    }
+                    u32 signBits = 0;
+                    for (int px = 0; px < 16; px++)
+                    {
+                        const float e0 = E(c0[0], c0[1], c0[2], S.pix[px], S.pw[px]);
+                        const float e1 = E(c1[0], c1[1], c1[2], S.pix[px], S.pw[px]);
+                        if (e1 < e0)
+                            signBits |= 1u << px;
+                        S.u.h.err[r][px] = sseMin(e0, e1);
+                    }
+                    S.u.h.sign[r] = (unsigned short)signBits;
                 }
-                u32 signBits = 0;
-                for (int px = 0; px < 16; px++)
-                {
-                    const float e0 = E(c0[0], c0[1], c0[2], S.pix[px], S.pw[px]);
-                    const float e1 = E(c1[0], c1[1], c1[2], S.pix[px], S.pw[px]);
-                    if (e1 < e0)
-                        signBits |= 1u << px;
-                    S.u.h.err[lane][px] = sseMin(e0, e1);
-                }
-                S.u.h.sign[lane] = (unsigned short)signBits;
             }
             WAVE_SYNC();
             // colour pairs in the reference's odometer order (ETC.cpp:797-812): step s = 1..n0*n1 visits
             // (s % n0, min(n1 - 1, s / n0)); the last step wraps to (0, n1 - 1), which is a repeat
-            // unless n1 == 1, where it is the only visit of (0, 0)
-            const int numPairs = n0 * n1;
-            for (int base = 1; base <= numPairs; base += 64)
+            // unless n1 == 1, where it is the only visit of (0, 0).  Table A's steps, then table B's.
+            const int pairsA = nA0 * nA1, pairsB = nB0 * nB1;
+            for (int base = 1; base <= pairsA + pairsB; base += 64)
             {
-                const int k = base + lane;
-                if (k <= numPairs)
+                const int kk = base + lane;
+                if (kk <= pairsA + pairsB)
                 {
+                    const bool isB = kk > pairsA;
+                    const int table = isB ? tabB : tabA;
+                    const int k = isB ? kk - pairsA : kk;
+                    const int n0 = isB ? nB0 : nA0, n1 = isB ? nB1 : nA1;
+                    const int rowBase = isB ? rowsA : 0;
                     const int i0 = k % n0;
                     const int i1 = (k / n0) < n1 - 1 ? (k / n0) : n1 - 1;
-                    const int ci0 = i0, ci1 = n0 + i1;
+                    const int ci0 = rowBase + i0, ci1 = rowBase + n0 + i1;
                     const u32 s0 = S.u.h.sign[ci0], s1 = S.u.h.sign[ci1];
                     float totalError = 0.0f;
                     u32 sectorBits = 0, signBits = 0;
@@ -1082,10 +1099,11 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                             sectorBits |= 1u << px;
                         signBits |= (1u << px) & (oneBetter ? s1 : s0);
                     }
-                    if (totalError < hBestErr)
+                    const int id = table * 1024 + k;
+                    if (totalError < hBestErr || (totalError == hBestErr && id < hBestId))
                     {
                         hBestErr = totalError;
-                        hBestId = table * 1024 + k;
+                        hBestId = id;
                         hBestBits = sectorBits | (signBits << 16);
                         hBestC0 = S.dColors[table * 2][i0];
                         hBestC1 = S.dColors[table * 2 + 1][i1];
