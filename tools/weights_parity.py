@@ -20,3 +20,17 @@ for w in ((1,1,1,0), (0,1,0,1), (1,1,1,1e-3), (100,1,0.01,5), (0,0,0,0), (1,1,1,
     g = ctx.encode_bc1(torch.from_numpy(blocks).cuda(), o).cpu().numpy()
     r = ref.encode_bc1(blocks, ob)
     print("BC1 weights", w, "mismatches", int((g != r).any(axis=1).sum()), flush=True)
+
+# ETC2 RGB / BC6H with the same weights (canonical reference build)
+canon = pyref.RefLib()
+hdr = content.mixed_hdr_blocks(9, 16)
+etcb = blocks[:1024]
+for w in ((1, 1, 1, 0), (0, 1, 0, 1), (100, 1, 0.01, 5), (0, 0, 0, 0)):
+    o = api.Options(); o.redWeight, o.greenWeight, o.blueWeight, o.alphaWeight = w
+    ob = np.frombuffer(o.tobytes(), np.uint8).copy()
+    g = ctx.encode_etc2(torch.from_numpy(etcb).cuda(), o).cpu().numpy()
+    r = canon.encode_etc2(etcb, ob, 0)
+    print("ETC2 weights", w, "mismatches", int((g != r).any(axis=1).sum()), "of", etcb.shape[0], flush=True)
+    g = ctx.encode_bc6h(torch.from_numpy(hdr).cuda(), o, signed=False).cpu().numpy()
+    r = canon.encode_bc6h(hdr, ob, False)
+    print("BC6HU weights", w, "mismatches", int((g != r).any(axis=1).sum()), "of", hdr.shape[0], flush=True)
