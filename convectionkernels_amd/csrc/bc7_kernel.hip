@@ -29,6 +29,7 @@
 #include "cvtt_device.h"
 
 // minimum waves per SIMD the register allocator must leave room for (512 VGPR+AGPR / waves)
+constexpr int kMaxPTRefine = 6; // BC7_RespectPunchThrough: refine rounds whose trial errors fit the LDS table
 #ifndef CVTT_BOUND_GRID
 #define CVTT_BOUND_GRID 2000.0f // half-range of the integer grid the projected points are rounded to
 #endif
@@ -1439,7 +1440,8 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     __shared__ UnitRec s_unit[64];    // PCA seeds per (item, subset)
     __shared__ u32 s_res[96][5];      // best of every (item, subset): error, endpoints, indexes
     // BC7_RespectPunchThrough: the error of every trial (chain x refine round) of every unit of the round
-    __shared__ float s_trialErr[PT ? 32 : 1][48];
+    // [unit][chain][round], 32 x 16 x numRefine floats (punch-through instantiation only; up to kMaxPTRefine rounds)
+    __shared__ float s_trialErr[PT ? 32 * 16 * kMaxPTRefine : 1];
     const cvttmi_bc7_plan *__restrict__ plan = &dplan->plan;
     const int lane = threadIdx.x;
     const u32 blockIndex = blockIdx.x * 16u + (u32)(lane >> 2);
@@ -2118,7 +2120,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                     // record every trial; the lock-step commit rule is applied below
                     if (PT)
                         evalChain<4, FAST, true>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b,
-                                                 &s_trialErr[inRange ? unit : 0][chain * 3], -1);
+                                                 &s_trialErr[((inRange ? unit : 0) * 16 + chain) * numRefine], -1);
                     continue;
                 }
                 if (isRGB)
@@ -2171,9 +2173,9 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                     for (int tw = 0; tw < 4; tw++)
                         for (int rf = 0; rf < numRefine; rf++)
                         {
-                            const int t = (pI * 4 + tw) * 3 + rf;
+                            const int t = (pI * 4 + tw) * numRefine + rf;
                             const bool run = scanActive && !allInvalid && tw < r.numTweak;
-                            const float e = run ? s_trialErr[unit][t] : FLT_MAX;
+                            const float e = run ? s_trialErr[unit * 16 * numRefine + t] : FLT_MAX;
                             const bool better = run && e < held;
                             const bool anyBetter = ((u32)(__ballot(better) >> slice) & 0xffu) != 0;
                             bool commit = better;
@@ -2193,7 +2195,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 }
                 // the payload of the held trial: run that chain again up to its round
                 const bool have = scanActive && last >= 0;
-                const int hChain = have ? last / 3 : 0, hRound = have ? last - hChain * 3 : 0;
+                const int hChain = have ? last / numRefine : 0, hRound = have ? last - hChain * numRefine : 0;
                 int maxCount = have ? __popc(r.mask) : 0;
 #pragma unroll
                 for (int step = 1; step < 64; step <<= 1)

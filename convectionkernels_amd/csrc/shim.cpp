@@ -709,8 +709,8 @@ extern "C"
             return CVTTMI_E_INVALID;
         if (!d_out || !d_blocks || !options || !plan || (numBlocks % 8) != 0 || numBlocks > 0xfffffff0u)
             return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
-        if ((options->flags & CVTTMI_FLAG_BC7_RESPECT_PUNCHTHROUGH) && options->refineRoundsBC7 > 3)
-            return fail(ctx, CVTTMI_E_UNSUPPORTED, "BC7_RespectPunchThrough supports refineRoundsBC7 <= 3 on the GPU path");
+        if ((options->flags & CVTTMI_FLAG_BC7_RESPECT_PUNCHTHROUGH) && options->refineRoundsBC7 > 6)
+            return fail(ctx, CVTTMI_E_UNSUPPORTED, "BC7_RespectPunchThrough supports refineRoundsBC7 <= 6 on the GPU path (2 KB of LDS per round)");
         if (numBlocks == 0)
             return CVTTMI_OK;
         hipError_t e = hipSetDevice(ctx->device);
