@@ -1435,6 +1435,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     __shared__ float s_bound[64][16]; // error lower bound of every partition of the current mode, per block
     __shared__ u32 s_pix[16][16];     // the 16 blocks of this wave
     __shared__ u32 s_blkFlags[16];    // wantPCA4 of the block's group
+    __shared__ float s_scatter[16][14]; // scatter matrix + centroid of every block, parked here during the dual-plane search
     __shared__ u32 s_item[32];        // offers of the round: block | partition << 8
     __shared__ uint8_t s_myItems[16][32]; // the items a block offered this round
     __shared__ UnitRec s_unit[64];    // PCA seeds per (item, subset)
@@ -1538,6 +1539,15 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     if (prune)
     {
         blockScatter(pix, A, bs);
+        if (c == 0)
+        {
+#pragma unroll
+            for (int i = 0; i < 10; i++)
+                s_scatter[lane >> 2][i] = bs.S[i];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                s_scatter[lane >> 2][10 + i] = bs.meanW[i];
+        }
         {
             Moments<4> m;
 #pragma unroll
@@ -1844,7 +1854,17 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                     const float delta = (use4 ? A.delta4 : A.delta3) + 0.7072f / scale;
                     Proj2D P;
                     PROF_MARK(2)
-                    makeProjection(pix, bs, A, use4, scale, P);
+                    {
+                        // take the block statistics back from LDS (they were not kept in registers across the search)
+                        BlockScatter bsL;
+#pragma unroll
+                        for (int i = 0; i < 10; i++)
+                            bsL.S[i] = s_scatter[blk][i];
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            bsL.meanW[i] = s_scatter[blk][10 + i];
+                        makeProjection(pix, bsL, A, use4, scale, P);
+                    }
                     PROF_MARK(7)
                     for (int k = 0; k < 16; k++)
                     {
