@@ -46,3 +46,30 @@ def encode_sharded(encode, blocks, block_rows, blocks_per_row, bytes_per_block, 
     out = torch.empty((world * m, bytes_per_block), dtype=torch.uint8, device=local.device)
     dist.all_gather_into_tensor(out, padded, group=group)
     return torch.cat([out[r * m:r * m + sizes[r]] for r in range(world)])
+
+
+def pipelined_gather_steps(num_steps, encode_step, outs, gathered, group=None):
+    """Run `num_steps` encode steps whose packed output is gathered on every rank, with the gather of step i overlapping
+    the encode of step i + 1: `encode_step(i, out)` fills `out` (= outs[i & 1]) on the current stream, the all-gather
+    into gathered[i & 1] is issued asynchronously on the backend's stream, and a buffer pair is reused only after the
+    gather that read it has completed.  Falls back to blocking gathers on a backend without asynchronous ones.
+    Returns True when the gathers were overlapped.  With one process it just runs the steps."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    pending = []
+    overlapped = world > 1
+    for i in range(num_steps):
+        buf = i & 1
+        if len(pending) >= 2:
+            pending.pop(0).wait()  # the current stream waits for the gather that last read outs[buf]
+        encode_step(i, outs[buf])
+        if world > 1:
+            if overlapped:
+                try:
+                    pending.append(dist.all_gather_into_tensor(gathered[buf], outs[buf], group=group, async_op=True))
+                    continue
+                except Exception:  # noqa -- no asynchronous gathers: serialise
+                    overlapped = False
+            dist.all_gather_into_tensor(gathered[buf], outs[buf], group=group)
+    for work in pending:
+        work.wait()
+    return overlapped

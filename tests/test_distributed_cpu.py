@@ -29,6 +29,19 @@ for rows, per_row in ((6, 8), (5, 16), (3, 24), (7, 8)):
     full = sharding.encode_sharded(encode, torch.from_numpy(blocks), rows, per_row, 16)
     if rank == 0:
         np.save(os.path.join(os.environ["OUT_DIR"], "out_%%d_%%d.npy" %% (rows, per_row)), full.numpy())
+# the bench's step loop: gather of step i overlapped with the encode of step i + 1, two buffer pairs
+outs = [torch.zeros((8, 16), dtype=torch.uint8) for _ in range(2)]
+gathered = [torch.zeros((world * 8, 16), dtype=torch.uint8) for _ in range(2)]
+log = []
+def encode_step(i, out):
+    out.fill_(rank * 16 + i)
+    log.append(i)
+overlapped = sharding.pipelined_gather_steps(5, encode_step, outs, gathered)
+expect4 = [r * 16 + 4 for r in range(world) for _ in range(8)]
+expect3 = [r * 16 + 3 for r in range(world) for _ in range(8)]
+assert log == [0, 1, 2, 3, 4] and gathered[0][:, 0].tolist() == expect4 and gathered[1][:, 0].tolist() == expect3, (gathered[0][:, 0], gathered[1][:, 0])
+if rank == 0:
+    open(os.path.join(os.environ["OUT_DIR"], "pipeline_ok"), "w").write("overlapped=%%s" %% overlapped)
 dist.destroy_process_group()
 ''' % (ROOT, ROOT)
 
@@ -66,3 +79,4 @@ def test_two_rank_gloo_matches_single_process(tmp_path, oracle_lib):
         got = np.load(tmp_path / ("out_%d_%d.npy" % (rows, per_row)))
         assert got.shape[0] == rows * per_row
         assert (got[:n] == exp).all()
+    assert open(tmp_path / "pipeline_ok").read() == "overlapped=True"
