@@ -7,32 +7,36 @@
 // lanes; the arithmetic contract is kept by compiling this file with
 // -ffp-contract=off and IEEE divide/sqrt, f32 denormals on.
 //
-// Mapping (this is not the reference's 8-blocks-per-SSE-register layout):
+// Mapping (this is not the reference's 8-blocks-per-SSE-register layout; DESIGN.md 4.1 has the measurements):
 //   * one wavefront = 16 blocks = two reference "groups" of 8; lanes [0,32) and [32,64) each
 //     form one group, whose two alpha-derived booleans (BC67.cpp:1069, 1072) are wave ballots.
-//   * a block is owned by a lane QUAD.  Sub-lane c of the quad walks a quarter of the
-//     candidate chains of the current shape -- the (p-bit, seed-point) pairs of the
-//     reference's pIter x tweak loops (BC67.cpp:1298-1305) -- and runs each chain's refine
-//     rounds sequentially in registers (the refinement chain is inherently serial).
-//   * the 16 pixels of the block live packed (RGBA8) in 16 VGPRs per lane; the shape being
-//     searched is wave-uniform, so the pixel loop is a fully unrolled sequence of scalar
-//     (SGPR) bit tests: no divergence, no LDS, no scratch.
-//   * per shape the quad reduces (error, chain id) with an order-preserving argmin -- the
-//     reference commits with a strict '<' in p -> tweak -> refine order, so ties go to the
-//     lowest chain id -- and broadcasts the winner's endpoints/indexes with quad shuffles.
-//   * partition totals and the mode/partition commit are per-lane scalars (identical in
-//     the four lanes of a quad); sub-lane 0 packs and stores the 16-byte block.
+//   * exact branch-and-bound: a rigorous lower bound on the error of ANY trial of a shape (its
+//     total-least-squares residual minus the allowance for rounding, cvtt_kernel_common.h) is compared with the
+//     block's best error so far; a candidate that cannot pass the reference's commit test is skipped, which leaves
+//     the output bit-identical.  Whole-block bounds order and prune the four rotations of modes 4/5 and mode 6;
+//     bounds of all 64 partitions (2-D projection, v_dot2 masked sums) go to LDS per mode family.
+//   * dual-plane modes 4/5: a block is owned by a lane QUAD, sub-lane = seed point; the block is held channel-major,
+//     the float index selection and refiner sums are the reference's operations, the integer error comes from level
+//     tables + v_perm_b32 + v_dot4_u32_u8 (evalDualFast; evalDual for slow indexing).
+//   * single-plane modes 0-3, 6, 7: work pooled over the wave.  Per round the blocks offer their cheapest-bound
+//     partitions, one lane per (item, subset) runs the PCA seed search on LDS-staged pixels, then one lane per CHAIN
+//     (p-bit combination x seed point, with its serial refine rounds: evalChain) evaluates it; an order-preserving
+//     argmin reproduces the reference's first-minimum rule and the owning block commits by (error, position in the
+//     reference's candidate order), so the evaluation order is free.
+//   * BC7_RespectPunchThrough (separate instantiation): the commit rule couples the 8 blocks of a group per trial;
+//     every trial's error is recorded in LDS and the rule is replayed over 8-lane ballot slices.
+//   * the quad packs the (up to 66) bit fields of its block in parallel and sub-lane 0 stores the 16 bytes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
 
 #include "cvtt_device.h"
 
-// minimum waves per SIMD the register allocator must leave room for (512 VGPR+AGPR / waves)
 constexpr int kMaxPTRefine = 6; // BC7_RespectPunchThrough: refine rounds whose trial errors fit the LDS table
 #ifndef CVTT_BOUND_GRID
 #define CVTT_BOUND_GRID 2000.0f // half-range of the integer grid the projected points are rounded to
 #endif
+// minimum waves per SIMD the register allocator must leave room for (512 VGPR+AGPR / waves)
 #ifndef CVTT_BC7_WAVES
 #define CVTT_BC7_WAVES 3
 #endif
