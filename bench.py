@@ -210,7 +210,9 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "kernel": "cvttmi_bc7_kernel", "kernel_ms": k_ms,
-                "note": "VALU-bound search: %d algorithmic bytes per block; see DESIGN.md for the lane-op model" % ALGO_BYTES_PER_BLOCK,
+                "note": "VALU-bound search: %d algorithmic bytes per block; see DESIGN.md for the lane-op model. kernel_ms brackets the "
+                        "launches of one encode on the stream: the search, the second launch that finishes the blocks it handed "
+                        "over (~0.06 ms) and the commit (~0.004 ms)" % ALGO_BYTES_PER_BLOCK,
             },
         }
         pmc = profiled_counters()

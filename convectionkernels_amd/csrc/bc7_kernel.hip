@@ -1431,7 +1431,13 @@ __device__ __forceinline__ void quadBroadcast(Unfinished &dst, const Unfinished 
     }
 }
 
-template <bool FAST, bool PT>
+// HARD = false: the encoder.  A block whose mode-7 stage starts with at least A.hardMin partitions alive hands them to
+// the second launch (A.hardCap slots; none left: it searches them itself) and records its best without them.
+// HARD = true: the second launch.  kHardWaves (16) wavefronts per recorded block; each reloads the block's original wave
+// (the group-wide booleans need its neighbours), searches one slice of the 64 mode-7 partitions against the recorded
+// best and leaves its best candidate, packed, in A.hardCand; cvttmi_bc7_hard_commit_kernel picks the winner.
+// Every candidate is compared by (error, position in the reference's order), so the split cannot change the result.
+template <bool FAST, bool PT, bool HARD>
 __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
                                                         const CvttBc7Args A, const CvttDeviceTables *__restrict__ T,
                                                         const CvttBc7DevicePlan *__restrict__ dplan)
@@ -1449,14 +1455,47 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     __shared__ float s_trialErr[PT ? 32 * 16 * kMaxPTRefine : 1];
     const cvttmi_bc7_plan *__restrict__ plan = &dplan->plan;
     const int lane = threadIdx.x;
-    const u32 blockIndex = blockIdx.x * 16u + (u32)(lane >> 2);
-    const bool valid = blockIndex < A.numBlocks;
     const int c = lane & 3;
+    u32 hardIndex = 0, hardBlock = 0;
+    u64 hardMine = 0;
+    float hardErr = FLT_MAX;
+    int hardSeq = -1;
+    if (HARD)
+    {
+        hardIndex = blockIdx.x / kHardWaves;
+        const u32 count = *A.hardCount;
+        if (hardIndex >= (count < A.hardCap ? count : A.hardCap))
+            return;
+        const CvttBc7HardRec rec = A.hardRec[hardIndex];
+        hardBlock = rec.blockIndex;
+        hardErr = rec.err;
+        hardSeq = rec.seq;
+        // this wavefront's share: every kHardWaves-th of the partitions that were alive when the block was handed over
+        u64 m = ((u64)rec.aliveHi << 32) | rec.aliveLo;
+        const int q = (int)(blockIdx.x % kHardWaves);
+        for (int r = 0; m != 0; r++)
+        {
+            const u64 low = m & (0ull - m);
+            if ((r % kHardWaves) == q)
+                hardMine |= low;
+            m ^= low;
+        }
+        if (hardMine == 0)
+        {
+            if (lane == 0)
+                A.hardCand[blockIdx.x].err = FLT_MAX;
+            return;
+        }
+    }
+    const u32 blockIndex = (HARD ? (hardBlock & ~15u) : blockIdx.x * 16u) + (u32)(lane >> 2);
+    const bool inRange = blockIndex < A.numBlocks;
+    // HARD: the neighbours are loaded for the group-wide booleans only
+    const bool valid = inRange && (!HARD || blockIndex == hardBlock);
 
     PROF_DECL
     u32 pix[16];
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(blocks + (size_t)(valid ? blockIndex : 0u) * 64u);
+        const uint4 *src = reinterpret_cast<const uint4 *>(blocks + (size_t)(inRange ? blockIndex : 0u) * 64u);
 #pragma unroll
         for (int i = 0; i < 4; i++)
         {
@@ -1524,8 +1563,8 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     // We evaluate in a different order, so every candidate carries its position `seq` in the
     // reference's order and the commit compares (error, seq) lexicographically.
     WorkState work;
-    work.err = FLT_MAX;
-    int workSeq = -1; // nothing committed yet: a candidate must beat FLT_MAX strictly
+    work.err = HARD ? hardErr : FLT_MAX;
+    int workSeq = HARD ? hardSeq : -1; // nothing committed yet: a candidate must beat FLT_MAX strictly
     work.mode = 0;
     work.partOrIS = 0;
     work.rotation = 0;
@@ -1535,7 +1574,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     work.idxLo = work.idxHi = work.idx2Lo = work.idx2Hi = 0;
 
     // ------------- whole-block scatter matrix: bounds for mode 6 and the four rotations -------------
-    const bool prune = A.prune != 0;
+    const bool prune = !HARD && A.prune != 0; // HARD: the bounds have been applied by the first launch
     BlockScatter bs;
     float lbRot[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float lbMode6 = 0.0f;
@@ -1552,6 +1591,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             for (int i = 0; i < 4; i++)
                 s_scatter[lane >> 2][10 + i] = bs.meanW[i];
         }
+        if (!HARD)
         {
             Moments<4> m;
 #pragma unroll
@@ -1560,6 +1600,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             lbMode6 = shapeErrorLowerBound<4>(m, 16.0f, A.delta4);
         }
         // rotation r codes channel r-1 (alpha for r = 0) on its own; the other three share a line
+        if (!HARD)
         {
             const float s012 = A.wSq[0] + A.wSq[1] + A.wSq[2];
             const float d0 = A.delta3;
@@ -1573,9 +1614,9 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
         }
         // search the rotations in the order of their bounds summed over the wave: the likely
         // winner first, so that the others meet a tight best error
-        float tot[4];
+        float tot[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int r = 0; r < 4 && !HARD; r++)
         {
             float t = valid ? lbRot[r] : 0.0f;
 #pragma unroll
@@ -1603,6 +1644,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     // reference TryDualPlane, BC67.cpp:1678-1963.  The RGB seeds depend only on the rotation,
     // so sub-lane r computes them for rotation r once (the reference recomputes them for each
     // mode / index selector).
+    if constexpr (!HARD)
     {
         Unfinished uRot;
         {
@@ -1830,6 +1872,13 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
         case 4: stage = 0; md = {0, 3, 4, 4, 5}; numSubsets = 3; numPartitions = 16; boundSet = 2; enabled = plan->mode0PartitionEnabled & 0xffffull; break;
         default: stage = 2; md = {2, 2, 1, 5, 5}; numSubsets = 3; numPartitions = 64; boundSet = 2; enabled = plan->mode2PartitionEnabled; break;
         }
+        if (HARD)
+        {
+            // this wavefront's slice of the mode-7 partitions
+            if (stageIter != 1)
+                continue;
+            enabled = hardMine;
+        }
         const int mode = md.mode;
         const bool isRGB = mode < 4;
         // does this mode run for my group?  (wave-uniform skip when it runs for nobody)
@@ -1928,6 +1977,51 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             aliveBits |= alive ? (1u << k) : 0u;
         }
 
+        if (!PT && !HARD && mode == 7 && A.hardCap != 0)
+        {
+            // A wave with many partitions to search runs for tens of chain passes.  That only matters when it starts
+            // near the end of the launch (workgroups are dispatched in order), where it would run on alone: the number
+            // of partitions a wave may keep shrinks with the number of waves still to be dispatched after it.
+            int cnt = __popc(aliveBits);
+            cnt += __shfl_xor(cnt, 1);
+            cnt += __shfl_xor(cnt, 2);
+            int waveCnt = cnt;
+#pragma unroll
+            for (int step = 4; step < 64; step <<= 1)
+                waveCnt += __shfl_xor(waveCnt, step);
+            u32 allowed = (gridDim.x - blockIdx.x) / A.hardDiv;
+            allowed = allowed > A.hardMin ? allowed : A.hardMin;
+            // the blocks that make up most of the excess go; an eighth of the allowance each may stay
+            if ((u32)waveCnt >= allowed && cnt >= 2 && (u32)cnt >= allowed / 8u)
+            {
+                u32 slot = 0;
+                if (c == 0)
+                    slot = atomicAdd(A.hardCount, 1u);
+                slot = __shfl(slot, lane & ~3);
+                if (slot < A.hardCap)
+                {
+                    // bit k of sub-lane c is partition 4k + c
+                    u64 m = aliveBits;
+                    m = (m | (m << 24)) & 0x000000ff000000ffull;
+                    m = (m | (m << 12)) & 0x000f000f000f000full;
+                    m = (m | (m << 6)) & 0x0303030303030303ull;
+                    m = (m | (m << 3)) & 0x1111111111111111ull;
+                    m <<= c;
+                    u32 lo = (u32)m, hi = (u32)(m >> 32);
+                    lo |= __shfl_xor(lo, 1);
+                    hi |= __shfl_xor(hi, 1);
+                    lo |= __shfl_xor(lo, 2);
+                    hi |= __shfl_xor(hi, 2);
+                    aliveBits = 0;
+                    if (c == 0)
+                    {
+                        A.hardRec[slot].aliveLo = lo;
+                        A.hardRec[slot].aliveHi = hi;
+                        s_blkFlags[blk] |= (slot + 1u) << 8; // remembered in LDS until the block's best is final
+                    }
+                }
+            }
+        }
         PROF_COUNT(4, __popc(aliveBits))
         PROF_COUNT(5, (c == 0 && valid) ? 1 : 0)
         const int itemCap = (numSubsets == 3) ? 21 : 32; // items * subsets <= 64 lanes of the seed pass
@@ -2520,7 +2614,24 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             w3 |= __shfl_xor(w3, step);
         }
 
-        if (valid && c == 0)
+        if (HARD)
+        {
+            if (valid && c == 0)
+            {
+                // nothing committed: no candidate from this slice
+                const bool improved = (work.err != hardErr) || (workSeq != hardSeq);
+                CvttBc7HardCand cand;
+                cand.packed[0] = w0;
+                cand.packed[1] = w1;
+                cand.packed[2] = w2;
+                cand.packed[3] = w3;
+                cand.err = improved ? work.err : FLT_MAX;
+                cand.seq = workSeq;
+                cand.pad[0] = cand.pad[1] = 0;
+                A.hardCand[blockIdx.x] = cand;
+            }
+        }
+        else if (valid && c == 0)
         {
             uint4 o;
             o.x = w0;
@@ -2528,10 +2639,52 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             o.z = w2;
             o.w = w3;
             *reinterpret_cast<uint4 *>(out + (size_t)blockIndex * 16u) = o;
+            if (!PT && A.hardCap != 0)
+            {
+                const u32 slot = s_blkFlags[blk] >> 8;
+                if (slot != 0)
+                {
+                    CvttBc7HardRec &rec = A.hardRec[slot - 1u];
+                    rec.blockIndex = blockIndex;
+                    rec.err = work.err;
+                    rec.seq = workSeq;
+                }
+            }
         }
     }
     PROF_MARK(5)
     PROF_FLUSH
+}
+
+// Third launch: the winner among the recorded best of a handed-over block and the candidates of its partition slices.
+__global__ __launch_bounds__(64) void cvttmi_bc7_hard_commit_kernel(uint8_t *__restrict__ out, const CvttBc7Args A)
+{
+    const u32 h = blockIdx.x * 64u + threadIdx.x;
+    const u32 count = *A.hardCount;
+    if (h >= (count < A.hardCap ? count : A.hardCap))
+        return;
+    const CvttBc7HardRec rec = A.hardRec[h];
+    float bestErr = rec.err;
+    int bestSeq = rec.seq, best = -1;
+    for (int q = 0; q < kHardWaves; q++)
+    {
+        const CvttBc7HardCand &cand = A.hardCand[h * kHardWaves + q];
+        const float e = cand.err;
+        const int sq = cand.seq;
+        if (e == FLT_MAX)
+            continue; // nothing from this slice
+        if (e < bestErr || (e == bestErr && sq < bestSeq))
+        {
+            bestErr = e;
+            bestSeq = sq;
+            best = q;
+        }
+    }
+    if (best >= 0)
+    {
+        const CvttBc7HardCand &cand = A.hardCand[h * kHardWaves + best];
+        *reinterpret_cast<uint4 *>(out + (size_t)rec.blockIndex * 16u) = make_uint4(cand.packed[0], cand.packed[1], cand.packed[2], cand.packed[3]);
+    }
 }
 
 extern "C" hipError_t cvttmi_launch_bc7(const void *d_blocks, void *d_out, const CvttBc7Args *args,
@@ -2543,14 +2696,26 @@ extern "C" hipError_t cvttmi_launch_bc7(const void *d_blocks, void *d_out, const
         return hipSuccess;
     const bool fast = (args->flags & CVTTMI_FLAG_BC7_FAST_INDEXING) != 0;
     const bool pt = (args->flags & CVTTMI_FLAG_BC7_RESPECT_PUNCHTHROUGH) != 0;
-#define CVTT_LAUNCH(F, P) hipLaunchKernelGGL((cvttmi_bc7_kernel<F, P>), dim3(waves), dim3(64), 0, stream, (const uint8_t *)d_blocks, (uint8_t *)d_out, *args, d_tables, d_plan)
+#define CVTT_LAUNCH(F, P, H, GRID) hipLaunchKernelGGL((cvttmi_bc7_kernel<F, P, H>), dim3(GRID), dim3(64), 0, stream, (const uint8_t *)d_blocks, (uint8_t *)d_out, *args, d_tables, d_plan)
     if (pt)
     {
-        if (fast) CVTT_LAUNCH(true, true); else CVTT_LAUNCH(false, true);
+        if (fast) CVTT_LAUNCH(true, true, false, waves); else CVTT_LAUNCH(false, true, false, waves);
+        return hipGetLastError();
     }
-    else
+    const bool split = args->hardCap != 0;
+    if (split)
     {
-        if (fast) CVTT_LAUNCH(true, false); else CVTT_LAUNCH(false, false);
+        const hipError_t e = hipMemsetAsync(args->hardCount, 0, sizeof(uint32_t), stream);
+        if (e != hipSuccess)
+            return e;
+    }
+    if (fast) CVTT_LAUNCH(true, false, false, waves); else CVTT_LAUNCH(false, false, false, waves);
+    if (split)
+    {
+        // sized for every slot: the wavefronts past the recorded count leave at once
+        const uint32_t hardGrid = args->hardCap * (uint32_t)kHardWaves;
+        if (fast) CVTT_LAUNCH(true, false, true, hardGrid); else CVTT_LAUNCH(false, false, true, hardGrid);
+        hipLaunchKernelGGL(cvttmi_bc7_hard_commit_kernel, dim3((args->hardCap + 63u) / 64u), dim3(64), 0, stream, (uint8_t *)d_out, *args);
     }
 #undef CVTT_LAUNCH
     return hipGetLastError();

@@ -54,6 +54,25 @@ struct CvttBc7DevicePlan
     uint32_t rgbaListed[5];
 };
 
+// BC7 blocks whose mode-7 partitions are searched by a second launch (bc7_kernel.hip, HARD): what the first launch
+// leaves per block, and what every wavefront of the second one leaves per partition slice.
+constexpr int kHardWaves = 16;
+struct CvttBc7HardRec
+{
+    uint32_t blockIndex;
+    float err;    // best error without the handed-over partitions
+    int32_t seq;  // its position in the reference's candidate order
+    uint32_t aliveLo, aliveHi; // the partitions handed over
+    uint32_t pad[3];
+};
+struct CvttBc7HardCand
+{
+    uint32_t packed[4];
+    float err;    // FLT_MAX: the slice holds nothing better than the record
+    int32_t seq;
+    uint32_t pad[2];
+};
+
 // Per-launch uniform parameters (kernel argument, lives in SGPRs).
 struct CvttBc7Args
 {
@@ -67,6 +86,13 @@ struct CvttBc7Args
     uint32_t prune;
     float delta3;    // 0.5*sqrt(wSq[0]+wSq[1]+wSq[2]), rounded up
     float delta4;    // 0.5*sqrt(wSq[0..3]), rounded up
+    // hand-over of blocks with many live mode-7 partitions to a second launch; hardCap = 0: off
+    uint32_t hardCap;   // record slots of this launch
+    uint32_t hardMin;   // live partitions of a wave from which its blocks are handed over, at the end of the grid
+    uint32_t hardDiv;   // ... and one more for every hardDiv waves that follow it
+    uint32_t *hardCount;
+    CvttBc7HardRec *hardRec;
+    CvttBc7HardCand *hardCand; // [hardCap][kHardWaves]
 };
 
 // BC1 per-launch parameters.

@@ -77,6 +77,16 @@ struct cvttmi_context
     void *dScratch;       // kernel work space (BC6H endpoint history), grown on demand
     size_t dScratchBytes;
     bool exhaustive; // search every candidate even when it provably cannot win
+    // BC7: blocks with many live mode-7 partitions are finished by a second launch (bc7_kernel.hip, HARD).
+    // One set of buffers per context, like dScratch: launches of one context are expected on one stream at a time.
+    static const uint32_t kHardSlots = 8192;
+    uint32_t *dHardCount;
+    CvttBc7HardRec *dHardRec;
+    CvttBc7HardCand *dHardCand;
+    int hardMin;         // live partitions of a wave from which its blocks are handed over; 0 = never
+    int hardDiv;
+    int hardCapOverride; // > 0: slots per launch (experiments)
+    uint32_t lastHardCap;
     // timing
     bool timing;
     hipEvent_t evStart, evStop;
@@ -452,9 +462,21 @@ extern "C"
         ctx->exhaustive = getenv("CVTTMI_EXHAUSTIVE") != NULL && atoi(getenv("CVTTMI_EXHAUSTIVE")) != 0;
         ctx->totalMs = 0.0;
         ctx->launches = 0;
+        ctx->dHardCount = NULL;
+        ctx->dHardRec = NULL;
+        ctx->dHardCand = NULL;
+        ctx->lastHardCap = 0;
+        ctx->hardMin = getenv("CVTTMI_BC7_HARD_MIN") ? atoi(getenv("CVTTMI_BC7_HARD_MIN")) : 8;
+        ctx->hardDiv = getenv("CVTTMI_BC7_HARD_DIV") ? atoi(getenv("CVTTMI_BC7_HARD_DIV")) : 128;
+        if (ctx->hardDiv < 1)
+            ctx->hardDiv = 1;
+        ctx->hardCapOverride = getenv("CVTTMI_BC7_HARD_CAP") ? atoi(getenv("CVTTMI_BC7_HARD_CAP")) : 0;
         fillTables(ctx->hostTables);
         hipError_t e;
-        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->dTables), sizeof(CvttDeviceTables))) != hipSuccess ||
+        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->dHardCount), 256)) != hipSuccess ||
+            (e = hipMalloc(reinterpret_cast<void **>(&ctx->dHardRec), sizeof(CvttBc7HardRec) * cvttmi_context::kHardSlots)) != hipSuccess ||
+            (e = hipMalloc(reinterpret_cast<void **>(&ctx->dHardCand), sizeof(CvttBc7HardCand) * cvttmi_context::kHardSlots * kHardWaves)) != hipSuccess ||
+            (e = hipMalloc(reinterpret_cast<void **>(&ctx->dTables), sizeof(CvttDeviceTables))) != hipSuccess ||
             (e = hipMalloc(reinterpret_cast<void **>(&ctx->dPlans), sizeof(CvttBc7DevicePlan) * cvttmi_context::kPlanSlots)) != hipSuccess ||
             (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
             (e = hipEventCreate(&ctx->evStart)) != hipSuccess || (e = hipEventCreate(&ctx->evStop)) != hipSuccess)
@@ -484,6 +506,9 @@ extern "C"
         if (ctx->dIn) hipFree(ctx->dIn);
         if (ctx->dOut) hipFree(ctx->dOut);
         if (ctx->dScratch) hipFree(ctx->dScratch);
+        if (ctx->dHardCount) hipFree(ctx->dHardCount);
+        if (ctx->dHardRec) hipFree(ctx->dHardRec);
+        if (ctx->dHardCand) hipFree(ctx->dHardCand);
         if (ctx->stream) hipStreamDestroy(ctx->stream);
         hipEventDestroy(ctx->evStart);
         hipEventDestroy(ctx->evStop);
@@ -683,6 +708,22 @@ extern "C"
         return CVTTMI_OK;
     }
 
+    // Diagnostic (tools/, not part of include/): blocks the last BC7 launch of this context handed to its second launch,
+    // and how many of them found a slot.  Synchronises the device.
+    int cvttmi_bc7_hard_stats(cvttmi_context *ctx, uint32_t *handedOver, uint32_t *slots)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        hipSetDevice(ctx->device);
+        hipDeviceSynchronize();
+        uint32_t v = 0;
+        if (hipMemcpy(&v, ctx->dHardCount, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "hipMemcpy(hard count)");
+        if (handedOver) *handedOver = v;
+        if (slots) *slots = ctx->lastHardCap;
+        return CVTTMI_OK;
+    }
+
     int cvttmi_timing_enable(cvttmi_context *ctx, int enable)
     {
         if (!ctx)
@@ -729,6 +770,22 @@ extern "C"
         args.refineRounds = options->refineRoundsBC7;
         args.numBlocks = static_cast<uint32_t>(numBlocks);
         args.prune = ctx->exhaustive ? 0u : 1u;
+        {
+            // slots for about one block in five hundred: enough for the rare block of ordinary content, and a bound on the
+            // extra wavefronts where every block is such a block
+            uint32_t cap = static_cast<uint32_t>(numBlocks / 512);
+            cap = cap < 1024u ? 1024u : cap;
+            if (ctx->hardCapOverride > 0)
+                cap = static_cast<uint32_t>(ctx->hardCapOverride);
+            cap = cap > cvttmi_context::kHardSlots ? cvttmi_context::kHardSlots : cap;
+            args.hardCap = (args.prune && ctx->hardMin > 0) ? cap : 0u;
+            args.hardMin = static_cast<uint32_t>(ctx->hardMin);
+            args.hardDiv = static_cast<uint32_t>(ctx->hardDiv);
+            args.hardCount = ctx->dHardCount;
+            args.hardRec = ctx->dHardRec;
+            args.hardCand = ctx->dHardCand;
+            ctx->lastHardCap = args.hardCap;
+        }
         {
             const double s3 = (double)args.wSq[0] + (double)args.wSq[1] + (double)args.wSq[2];
             const double s4 = s3 + (double)args.wSq[3];

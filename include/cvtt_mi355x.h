@@ -129,7 +129,10 @@ int cvttmi_set_rcp_table(cvttmi_context *ctx, const float lut[17]);
 int cvttmi_get_rcp_table(const cvttmi_context *ctx, float lut[17]);
 
 /* ---- device-resident entry points: d_blocks / d_out are HBM pointers on the context's
- * device; the launch is asynchronous on `hipStream` (a hipStream_t, NULL = default). ---- */
+ * device; the launch is asynchronous on `hipStream` (a hipStream_t, NULL = default).
+ * A context owns device work space that its BC7 and BC6H launches use (hand-over list, endpoint
+ * history): calls on ONE context must be issued on one stream at a time; use a context per
+ * stream to encode concurrently. ---- */
 
 /* replaces cvtt::Kernels::EncodeBC7 (ConvectionKernels_API.cpp:41-54): numBlocks * 64 B
  * of PixelBlockU8 in, numBlocks * 16 B out. */

@@ -162,6 +162,27 @@ def test_single_colour_flag_on_dark_content(gpu_ctx, oracle_lib):
         assert bad.size == 0, "flags %x blocks %s" % (flags, bad[:8])
 
 
+def test_second_launch_hand_over_is_invisible(gpu_ctx, oracle_lib, monkeypatch):
+    """Blocks with many live mode-7 partitions are finished by a second launch (bc7_kernel.hip, HARD).  Off, with three
+    slots only (most such blocks find none and search on themselves) and with the defaults, the output is the oracle's."""
+    api = _api()
+    rcp = oracle_lib.probe_rcp()
+    blocks = np.concatenate([content.mixed_ldr_blocks(777, 40), content.config_blocks(9, 256, 256)])
+    opt, plan = api.Options(), api.BC7EncodingPlan()
+    exp = oracle_lib.encode_bc7(blocks, np.frombuffer(opt.tobytes(), np.uint8).copy(),
+                                np.frombuffer(plan.tobytes(), np.uint8).copy(), rcp, threads=8)
+    for env in ({"CVTTMI_BC7_HARD_MIN": "0"}, {"CVTTMI_BC7_HARD_CAP": "3", "CVTTMI_BC7_HARD_MIN": "2"},
+                {"CVTTMI_BC7_HARD_MIN": "2", "CVTTMI_BC7_HARD_DIV": "1000000"}, {}):
+        for k in ("CVTTMI_BC7_HARD_MIN", "CVTTMI_BC7_HARD_CAP", "CVTTMI_BC7_HARD_DIV"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = api.Context(0)  # the settings are read when the context is created
+        ctx.set_rcp_table(rcp)
+        bad = _diff(ctx.encode_bc7(blocks, opt, plan), exp)
+        assert bad.size == 0, "%s: blocks %s differ" % (env, bad[:8])
+
+
 def test_config2_full_size_hash(gpu_ctx):
     """BASELINE config 2: 4096x4096 random RGBA, seed 2 (1,048,576 blocks) -- SHA-256 of the
     whole output equals the reference's (generated with the recorded RCPPS table)."""
