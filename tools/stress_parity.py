@@ -2,7 +2,7 @@
 """One-off differential stress test (GPU box): large vectorised content families through the HIP kernels and
 through the real reference (oracle/_ref, all host threads), every block compared.  Catches events too rare for
 the unit tests (the sqrt rounding case was 1 block in 2 million).
-    python tools/stress_parity.py [blocks_per_family] [all|bc7|ldr|hdr|rows]
+    python tools/stress_parity.py [blocks_per_family] [all|bc7|ldr|hdr|rows] [seed]
 "rows" = the formats / flags added after the first four: BC1-BC3 with S3TC_Exhaustive, BC2-BC5, ETC1, ETC2 punch-through, R11."""
 import os, sys, time, threading
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,8 @@ from oracle import pyref
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 17
 STAGE = sys.argv[2] if len(sys.argv) > 2 else "all"
-rng = np.random.Generator(np.random.PCG64(2026))
+SEED = int(sys.argv[3]) if len(sys.argv) > 3 else 2026
+rng = np.random.Generator(np.random.PCG64(SEED))
 yy, xx = np.divmod(np.arange(16), 4)
 
 
