@@ -487,7 +487,11 @@ struct UnitRec
     int blk;
     int slot; // item * 3 + subset: where the subset's result goes
     float scErr; // BC7_TrySingleColor: error of the fixed candidate (FLT_MAX when not tried)
-    int pad[3];
+    // Not part of the unit (the seed pass never writes it): entry b < 16 keeps the secondary index set of block b's best
+    // mode 4 / 5 candidate out of the registers until the block is packed.  It lives in this padding because gfx950
+    // allocates LDS in 1280-byte granules and the kernel sits exactly on 10 of them (12 workgroups per CU).
+    u32 parkedIdx2[2];
+    int pad;
 };
 
 struct WorkState
@@ -500,6 +504,89 @@ struct WorkState
     u32 idxLo, idxHi;   // primary indexes, 4 bits per pixel
     u32 idx2Lo, idx2Hi; // secondary indexes (modes 4/5)
 };
+
+// Fix-ups + bit packing of a mode 4 / mode 5 block (reference BC67.cpp:2003-2203) by one lane: with the mode a template
+// parameter every field sits at a constant bit position, so the 66 fields cost a shift-or each instead of the generic
+// packer's per-lane field arithmetic (the kernel keeps that one for the other modes).
+template <int MODE>
+__device__ __forceinline__ void packDualPlane(const WorkState &work, u32 &w0, u32 &w1, u32 &w2, u32 &w3)
+{
+    constexpr int rgbBits = (MODE == 4) ? 5 : 7, alphaBits = (MODE == 4) ? 6 : 8, alphaIndexBits = (MODE == 4) ? 3 : 2;
+    constexpr u32 idxOnes = 0x33333333u, idx2Ones = (MODE == 4) ? 0x77777777u : 0x33333333u;
+    u32 iLo = work.idxLo, iHi = work.idxHi, jLo = work.idx2Lo, jHi = work.idx2Hi;
+    // the anchor (pixel 0) of either index set must have its top bit clear: complement the set and exchange the
+    // endpoints it interpolates (every 4-bit slot holds at most the set's maximum, so the complement is an XOR)
+    bool flipRGB = ((iLo >> 1) & 1u) != 0;
+    bool flipAlpha = ((jLo >> (alphaIndexBits - 1)) & 1u) != 0;
+    if (flipRGB)
+    {
+        iLo ^= idxOnes;
+        iHi ^= idxOnes;
+    }
+    if (flipAlpha)
+    {
+        jLo ^= idx2Ones;
+        jHi ^= idx2Ones;
+    }
+    const int indexSelector = (MODE == 4) ? work.partOrIS : 0;
+    if (indexSelector)
+    {
+        const bool t = flipRGB;
+        flipRGB = flipAlpha;
+        flipAlpha = t;
+    }
+    u32 e0 = work.ep[0][0], e1 = work.ep[0][1];
+    if (flipRGB)
+    {
+        const u32 a = e0, b = e1;
+        e0 = (a & 0xff000000u) | (b & 0x00ffffffu);
+        e1 = (b & 0xff000000u) | (a & 0x00ffffffu);
+    }
+    if (flipAlpha)
+    {
+        const u32 a = e0, b = e1;
+        e0 = (a & 0x00ffffffu) | (b & 0xff000000u);
+        e1 = (b & 0x00ffffffu) | (a & 0xff000000u);
+    }
+    u64 lo = 0, hi = 0;
+    auto put = [&](u32 value, int off) {
+        const u64 v = (u64)value;
+        if (off < 64)
+        {
+            lo |= v << off;
+            if (off > 56)
+                hi |= v >> (64 - off); // fields are at most 8 bits wide
+        }
+        else
+            hi |= v << (off - 64);
+    };
+    put(1u << MODE, 0);
+    put((u32)work.rotation, MODE + 1);
+    if (MODE == 4)
+        put((u32)indexSelector, 7);
+    constexpr int epBase = 8;
+#pragma unroll
+    for (int g = 0; g < 6; g++)
+    {
+        const u32 e = (g & 1) ? e1 : e0;
+        put(((e >> (8 * (g >> 1))) & 0xffu) >> (8 - rgbBits), epBase + g * rgbBits);
+    }
+    constexpr int alphaBase = epBase + 6 * rgbBits;
+    put((e0 >> 24) >> (8 - alphaBits), alphaBase);
+    put((e1 >> 24) >> (8 - alphaBits), alphaBase + alphaBits);
+    constexpr int idxBase = alphaBase + 2 * alphaBits;
+#pragma unroll
+    for (int px = 0; px < 16; px++)
+        put(((px < 8 ? iLo : iHi) >> (4 * (px & 7))) & 0xfu, idxBase + 2 * px - (px > 0 ? 1 : 0));
+    constexpr int idx2Base = idxBase + 31;
+#pragma unroll
+    for (int px = 0; px < 16; px++)
+        put(((px < 8 ? jLo : jHi) >> (4 * (px & 7))) & 0xfu, idx2Base + alphaIndexBits * px - (px > 0 ? 1 : 0));
+    w0 = (u32)lo;
+    w1 = (u32)(lo >> 32);
+    w2 = (u32)hi;
+    w3 = (u32)(hi >> 32);
+}
 
 // In-place channel rotation of the packed pixels: rotation r > 0 exchanges channel r-1 with
 // alpha (reference BC67.cpp:1695-1698).  The exchange is an involution.
@@ -1577,7 +1664,6 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     const bool prune = !HARD && A.prune != 0; // HARD: the bounds have been applied by the first launch
     BlockScatter bs;
     float lbRot[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    float lbMode6 = 0.0f;
     int rotOrder[4] = {0, 1, 2, 3};
     if (prune)
     {
@@ -1597,7 +1683,10 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
 #pragma unroll
             for (int i = 0; i < 10; i++)
                 m.cov[i] = bs.S[i];
-            lbMode6 = shapeErrorLowerBound<4>(m, 16.0f, A.delta4);
+            const float lbMode6 = shapeErrorLowerBound<4>(m, 16.0f, A.delta4);
+            // mode 6 is the first single-plane stage: its bound waits where that stage looks for it
+            if (c == 0)
+                s_bound[0][lane >> 2] = lbMode6;
         }
         // rotation r codes channel r-1 (alpha for r = 0) on its own; the other three share a line
         if (!HARD)
@@ -1801,15 +1890,15 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                     // index selector 1: the 2-bit set is the alpha plane (BC67.cpp:1953-1957)
                     work.idxLo = bA.idxLo;
                     work.idxHi = bA.idxHi;
-                    work.idx2Lo = b.idxLo;
-                    work.idx2Hi = b.idxHi;
+                    s_unit[lane >> 2].parkedIdx2[0] = b.idxLo;
+                    s_unit[lane >> 2].parkedIdx2[1] = b.idxHi;
                 }
                 else
                 {
                     work.idxLo = b.idxLo;
                     work.idxHi = b.idxHi;
-                    work.idx2Lo = bA.idxLo;
-                    work.idx2Hi = bA.idxHi;
+                    s_unit[lane >> 2].parkedIdx2[0] = bA.idxLo;
+                    s_unit[lane >> 2].parkedIdx2[1] = bA.idxHi;
                 }
             }
         }
@@ -1894,8 +1983,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 __syncthreads();
                 if (boundSet == 3)
                 {
-                    if (c == 0)
-                        s_bound[0][blk] = lbMode6;
+                    // written when the block statistics were computed
                 }
                 else
                 {
@@ -2404,6 +2492,18 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     // ===================== fix-ups + bit packing (reference BC67.cpp:2003-2203) ==========
     {
         const int mode = work.mode;
+        u32 w0, w1, w2, w3;
+        if (mode == 4 || mode == 5)
+        {
+            work.idx2Lo = s_unit[lane >> 2].parkedIdx2[0];
+            work.idx2Hi = s_unit[lane >> 2].parkedIdx2[1];
+        }
+        if (mode == 4)
+            packDualPlane<4>(work, w0, w1, w2, w3);
+        else if (mode == 5)
+            packDualPlane<5>(work, w0, w1, w2, w3);
+        else
+        {
         // mode description bit-fields (BC7 format)
         const int numSubsetsTab[8] = {3, 2, 3, 2, 1, 1, 1, 2};
         const int partitionBitsTab[8] = {4, 6, 6, 6, 0, 0, 0, 6};
@@ -2425,7 +2525,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 alphaIndexBits = alphaIndexBitsTab[m];
                 pBitMode = pBitModeTab[m];
             }
-        const bool separateAlpha = (mode == 4 || mode == 5);
+        constexpr bool separateAlpha = false; // modes 4 and 5 have gone to packDualPlane; their branches below fold away
         const bool combinedAlpha = (mode == 6 || mode == 7);
         const int partition = work.partOrIS;
         const int indexSelector = work.partOrIS;
@@ -2604,7 +2704,10 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 put((u32)((idx2 >> (4 * px)) & 0xfull), idx2Base + px * alphaIndexBits - (px > 0 ? 1 : 0), alphaIndexBits - (px == 0 ? 1 : 0));
             }
         }
-        u32 w0 = (u32)lo, w1 = (u32)(lo >> 32), w2 = (u32)hi, w3 = (u32)(hi >> 32);
+        w0 = (u32)lo;
+        w1 = (u32)(lo >> 32);
+        w2 = (u32)hi;
+        w3 = (u32)(hi >> 32);
 #pragma unroll
         for (int step = 1; step <= 2; step <<= 1)
         {
@@ -2612,6 +2715,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             w1 |= __shfl_xor(w1, step);
             w2 |= __shfl_xor(w2, step);
             w3 |= __shfl_xor(w3, step);
+        }
         }
 
         if (HARD)
