@@ -1487,9 +1487,10 @@ __device__ __forceinline__ float subsetBound2D(const Sums2D &m, float invScaleSq
 {
     if (m.n < 2)
         return 0.0f;
-    const int a = m.n * m.uu - m.u * m.u;
-    const int c = m.n * m.vv - m.v * m.v;
-    const int b = m.n * m.uv - m.u * m.v;
+    // |sum u|, |sum v| <= 16 * 2040 fit 24 bits: v_mul_i32_i24 is a full-rate instruction, v_mul_lo_u32 is not
+    const int a = m.n * m.uu - __mul24(m.u, m.u);
+    const int c = m.n * m.vv - __mul24(m.v, m.v);
+    const int b = m.n * m.uv - __mul24(m.u, m.v);
     const float fa = (float)a, fc = (float)c, fb = (float)b;
     const float half = (fa + fc) * 0.5f;
     const float diff = (fa - fc) * 0.5f;
