@@ -1236,10 +1236,15 @@ struct BlockScatter
     float meanW[4];  // weighted centroid
 };
 
-__device__ __forceinline__ void blockScatter(const u32 (&pix)[16], const CvttBc7Args &A, BlockScatter &bs)
+// raw sums of the 16 pixels: s[ch] = sum x, p[tri(r, c)] = sum x_r x_c
+__device__ __forceinline__ void blockRawSums(const u32 (&pix)[16], int (&s)[4], int (&p)[10])
 {
-    int s[4] = {0, 0, 0, 0};
-    int p[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        s[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+        p[i] = 0;
 #pragma unroll
     for (int px = 0; px < 16; px++)
     {
@@ -1257,6 +1262,10 @@ __device__ __forceinline__ void blockScatter(const u32 (&pix)[16], const CvttBc7
             for (int c = 0; c <= r; c++)
                 p[tri(r, c)] = mad24(x[r], x[c], p[tri(r, c)]);
     }
+}
+
+__device__ __forceinline__ void scatterFromRaw(const int (&s)[4], const int (&p)[10], const CvttBc7Args &A, BlockScatter &bs)
+{
 #pragma unroll
     for (int r = 0; r < 4; r++)
     {
@@ -1269,6 +1278,78 @@ __device__ __forceinline__ void blockScatter(const u32 (&pix)[16], const CvttBc7
             bs.S[tri(r, c)] = (float)v * (A.w[r] * A.w[c] * 0.0625f);
         }
     }
+}
+
+// Exact branch-and-bound, second tier: the bound of a subset in all of its channels.  The 2-D projection of the first
+// tier keeps one of the three (two) residual directions of a subset; on low-variance content with noise in every
+// channel that leaves most partitions alive.  Raw integer sums of the member pixels of a subset -> scatter matrix ->
+// shapeErrorLowerBound, for the partitions that survived the first tier only.
+struct RawSums
+{
+    int n;
+    int s[4];
+    int p[10];
+};
+
+__device__ __forceinline__ void maskedRawSums(const u32 (&pix)[16], u32 mask, RawSums &r)
+{
+    r.n = __popc(mask & 0xffffu);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        r.s[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+        r.p[i] = 0;
+#pragma unroll
+    for (int px = 0; px < 16; px++)
+    {
+        // a pixel that is not a member counts as (0, 0, 0, 0)
+        const u32 pk = fetchPixel(pix[px]) & (u32)__builtin_amdgcn_sbfe(mask, px, 1);
+        int x[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++)
+        {
+            x[ch] = byteI(pk, ch);
+            r.s[ch] += x[ch];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++)
+                r.p[tri(a, b)] = mad24(x[a], x[b], r.p[tri(a, b)]);
+    }
+}
+
+__device__ __forceinline__ void rawSumsSub(RawSums &d, const RawSums &a)
+{
+    d.n -= a.n;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        d.s[i] -= a.s[i];
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+        d.p[i] -= a.p[i];
+}
+
+// n*sum(xy) - sum(x)*sum(y) is an exact integer below 2^24, so the matrix entries carry the rounding of two float
+// products only, which the margins of shapeErrorLowerBound cover
+template <int N>
+__device__ __forceinline__ float subsetBoundFull(const RawSums &r, const float (&w)[4], float delta)
+{
+    if (r.n < 2)
+        return 0.0f;
+    const float n = (float)r.n;
+    const float inv = __builtin_amdgcn_rcpf(n);
+    Moments<N> m;
+#pragma unroll
+    for (int a = 0; a < N; a++)
+#pragma unroll
+        for (int b = 0; b <= a; b++)
+        {
+            const int v = __mul24(r.n, r.p[tri(a, b)]) - __mul24(r.s[a], r.s[b]);
+            m.cov[tri(a, b)] = (float)v * (w[a] * w[b] * inv);
+        }
+    return shapeErrorLowerBound<N>(m, n, delta);
 }
 
 // bound of a shape made of all 16 pixels restricted to three channels (a < b < c)
@@ -1533,7 +1614,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     __shared__ float s_bound[64][16]; // error lower bound of every partition of the current mode, per block
     __shared__ u32 s_pix[16][16];     // the 16 blocks of this wave
     __shared__ u32 s_blkFlags[16];    // wantPCA4 of the block's group
-    __shared__ float s_scatter[16][14]; // scatter matrix + centroid of every block, parked here during the dual-plane search
+    __shared__ int s_scatter[16][14]; // raw sums (sum x per channel, sum x_r x_c) of every block: the scatter matrix of the bounds and the totals of the second tier come from here
     __shared__ u32 s_item[32];        // offers of the round: block | partition << 8
     __shared__ uint8_t s_myItems[16][32]; // the items a block offered this round
     __shared__ UnitRec s_unit[64];    // PCA seeds per (item, subset)
@@ -1668,15 +1749,19 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     int rotOrder[4] = {0, 1, 2, 3};
     if (prune)
     {
-        blockScatter(pix, A, bs);
-        if (c == 0)
         {
+            int rs[4], rp[10];
+            blockRawSums(pix, rs, rp);
+            if (c == 0)
+            {
 #pragma unroll
-            for (int i = 0; i < 10; i++)
-                s_scatter[lane >> 2][i] = bs.S[i];
+                for (int i = 0; i < 10; i++)
+                    s_scatter[lane >> 2][i] = rp[i];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                s_scatter[lane >> 2][10 + i] = bs.meanW[i];
+                for (int i = 0; i < 4; i++)
+                    s_scatter[lane >> 2][10 + i] = rs[i];
+            }
+            scatterFromRaw(rs, rp, A, bs);
         }
         if (!HARD)
         {
@@ -1934,6 +2019,9 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     // shape wave-uniform.
     const int blk = lane >> 2;
     int boundsFor = -1; // which bound set s_bound holds: 0 = two subsets RGBA, 1 = two subsets RGB, 2 = three subsets RGB, 3 = mode 6
+    int tier2For = -1;  // ... and for which set the second-tier bounds below have been merged into it,
+    u32 tier2Done = 0;  // for which of this lane's partitions (bit k = partition 4k + c)
+    bool tier2Pays = true;
     // static alpha error of the RGB modes, whole block (BC67.cpp:1250-1264)
     float staticAlphaBlock = 0.0f;
     if (prune)
@@ -1999,12 +2087,16 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                     {
                         // take the block statistics back from LDS (they were not kept in registers across the search)
                         BlockScatter bsL;
+                        {
+                            int rs[4], rp[10];
 #pragma unroll
-                        for (int i = 0; i < 10; i++)
-                            bsL.S[i] = s_scatter[blk][i];
+                            for (int i = 0; i < 10; i++)
+                                rp[i] = s_scatter[blk][i];
 #pragma unroll
-                        for (int i = 0; i < 4; i++)
-                            bsL.meanW[i] = s_scatter[blk][10 + i];
+                            for (int i = 0; i < 4; i++)
+                                rs[i] = s_scatter[blk][10 + i];
+                            scatterFromRaw(rs, rp, A, bsL);
+                        }
                         makeProjection(pix, bsL, A, use4, scale, P);
                     }
                     PROF_MARK(7)
@@ -2066,6 +2158,76 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             aliveBits |= alive ? (1u << k) : 0u;
         }
 
+        if (prune && numSubsets >= 2)
+        {
+            // second tier: full-dimension bounds of the partitions that are still alive and have none yet.  A partition
+            // costs about a fifth of a chain pass here and a seed pass plus chain passes if it stays.
+            if (tier2For != boundSet)
+            {
+                tier2For = boundSet;
+                tier2Done = 0;
+            }
+            const u32 todo = aliveBits & ~tier2Done;
+            if (tier2Pays && __ballot(todo != 0) != 0)
+            {
+                const u32 aliveBefore = aliveBits;
+                const bool use4 = (boundSet == 0);
+                float lw[4];
+#pragma unroll
+                for (int ch = 0; ch < 4; ch++)
+                    lw[ch] = A.w[ch];
+                // the rest of the block: its raw sums are in LDS since the block bounds
+                auto rest = [&](RawSums &d, const RawSums &a) {
+                    d.n = 16 - a.n;
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        d.s[i] = s_scatter[blk][10 + i] - a.s[i];
+#pragma unroll
+                    for (int i = 0; i < 10; i++)
+                        d.p[i] = s_scatter[blk][i] - a.p[i];
+                };
+                // every lane walks its own list: as many rounds as the longest list, not as many as there are slots in use
+                u32 rem = todo;
+                while (__ballot(rem != 0) != 0)
+                {
+                    if (rem != 0)
+                    {
+                        const int k = __ffs((int)rem) - 1;
+                        rem &= rem - 1u;
+                        const int partition = 4 * k + c;
+                        float lb;
+                        RawSums s0, s1;
+                        if (numSubsets == 2)
+                        {
+                            maskedRawSums(pix, T->partition2[partition], s1);
+                            rest(s0, s1);
+                            lb = use4 ? subsetBoundFull<4>(s1, lw, A.delta4) : subsetBoundFull<3>(s1, lw, A.delta3);
+                            lb += use4 ? subsetBoundFull<4>(s0, lw, A.delta4) : subsetBoundFull<3>(s0, lw, A.delta3);
+                        }
+                        else
+                        {
+                            maskedRawSums(pix, T->subsetMask3[partition][0], s1);
+                            rest(s0, s1);
+                            lb = subsetBoundFull<3>(s1, lw, A.delta3);
+                            maskedRawSums(pix, T->subsetMask3[partition][1], s1);
+                            rawSumsSub(s0, s1);
+                            lb += subsetBoundFull<3>(s1, lw, A.delta3);
+                            lb += subsetBoundFull<3>(s0, lw, A.delta3);
+                        }
+                        if (!use4)
+                            lb += staticAlphaBlock;
+                        if (lb > s_bound[partition][blk])
+                            s_bound[partition][blk] = lb;
+                        if (lb > work.err)
+                            aliveBits &= ~(1u << k);
+                    }
+                }
+                tier2Done |= todo;
+                // content on which these bounds remove nothing (errors dominated by quantisation, not by the fit of
+                // a line) does not get them again in the later stages of this wave
+                tier2Pays = __ballot(aliveBits != aliveBefore) != 0;
+            }
+        }
         if (!PT && !HARD && mode == 7 && A.hardCap != 0)
         {
             // A wave with many partitions to search runs for tens of chain passes.  That only matters when it starts
