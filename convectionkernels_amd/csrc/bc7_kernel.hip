@@ -29,12 +29,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
+#include <type_traits>
 
 #include "cvtt_device.h"
 
 constexpr int kMaxPTRefine = 6; // BC7_RespectPunchThrough: refine rounds whose trial errors fit the LDS table
-#ifndef CVTT_BOUND_GRID
-#define CVTT_BOUND_GRID 2000.0f // half-range of the integer grid the projected points are rounded to
+// half-range of the integer grid the projected points are rounded to: 12-bit coordinates summed with v_dot2_i32_i16, or
+// 8-bit ones summed with v_dot4_i32_i8 (half the instructions, bounds looser by the coarser rounding)
+constexpr float kBoundGrid16 = 2000.0f, kBoundLimit16 = 2040.0f;
+constexpr float kBoundGrid8 = 124.0f, kBoundLimit8 = 127.0f;
+// which grid the first-tier bounds of the RGBA partitions (mode 7) and of the RGB partitions (modes 0-3) use: with the
+// second tier behind them the cheaper bounds win on RGBA noise (+3 %), the tighter ones on opaque content (+5 %)
+#ifndef CVTT_GRID8_RGBA
+#define CVTT_GRID8_RGBA true
+#endif
+#ifndef CVTT_GRID8_RGB
+#define CVTT_GRID8_RGB false
 #endif
 // minimum waves per SIMD the register allocator must leave room for (512 VGPR+AGPR / waves)
 #ifndef CVTT_BC7_WAVES
@@ -1414,15 +1424,19 @@ __device__ __forceinline__ void topEigenvector(const float (&M)[10], float (&e)[
         e[i] = v[i] * inv;
 }
 
+__device__ __forceinline__ int dot4s(u32 a, u32 b, int acc) { return __builtin_amdgcn_sdot4((int)a, (int)b, acc, false); }
+template <bool G8>
 struct Proj2D
 {
-    u32 U[8], V[8];            // int16 pairs: pixel 2k in the low half, 2k+1 in the high half
+    // G8: int8 quadruples, pixel 4k + j in byte j; else int16 pairs, pixel 2k in the low half, 2k+1 in the high half
+    u32 U[G8 ? 4 : 8], V[G8 ? 4 : 8];
     int tU, tV, tUU, tVV, tUV; // sums over all 16 pixels
 };
 
 // Project the block on its two leading principal axes (channels 0..2 only when !use4).
+template <bool G8>
 __device__ __forceinline__ void makeProjection(const u32 (&pix)[16], const BlockScatter &bs, const CvttBc7Args &A,
-                                               bool use4, float scale, Proj2D &P)
+                                               bool use4, float scale, Proj2D<G8> &P)
 {
     float M[10];
 #pragma unroll
@@ -1505,6 +1519,41 @@ __device__ __forceinline__ void makeProjection(const u32 (&pix)[16], const Block
         o2 = __fmaf_rn(e2[ch] * scale, bs.meanW[ch], o2);
     }
     P.tU = P.tV = P.tUU = P.tVV = P.tUV = 0;
+    if constexpr (G8)
+    {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        u32 ub = 0, vb = 0;
+#pragma unroll
+        for (int h = 0; h < 4; h++)
+        {
+            const u32 pk = fetchPixel(pix[4 * k + h]);
+            float fu = -o1, fv = -o2;
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++)
+            {
+                const float x = byteF(pk, ch);
+                fu = __fmaf_rn(g1[ch], x, fu);
+                fv = __fmaf_rn(g2[ch], x, fv);
+            }
+            // clamping is a projection on a box: it never increases distances either
+            fu = fminf(fmaxf(fu, -kBoundLimit8), kBoundLimit8);
+            fv = fminf(fmaxf(fv, -kBoundLimit8), kBoundLimit8);
+            ub |= ((u32)(int)rintf(fu) & 0xffu) << (8 * h);
+            vb |= ((u32)(int)rintf(fv) & 0xffu) << (8 * h);
+        }
+        P.U[k] = ub;
+        P.V[k] = vb;
+        P.tU = dot4s(ub, 0x01010101u, P.tU);
+        P.tV = dot4s(vb, 0x01010101u, P.tV);
+        P.tUU = dot4s(ub, ub, P.tUU);
+        P.tVV = dot4s(vb, vb, P.tVV);
+        P.tUV = dot4s(ub, vb, P.tUV);
+    }
+    }
+    else
+    {
 #pragma unroll
     for (int k = 0; k < 8; k++)
     {
@@ -1522,8 +1571,8 @@ __device__ __forceinline__ void makeProjection(const u32 (&pix)[16], const Block
                 fv = __fmaf_rn(g2[ch], x, fv);
             }
             // clamping is a projection on a box: it never increases distances either
-            fu = fminf(fmaxf(fu, -2040.0f), 2040.0f);
-            fv = fminf(fmaxf(fv, -2040.0f), 2040.0f);
+            fu = fminf(fmaxf(fu, -kBoundLimit16), kBoundLimit16);
+            fv = fminf(fmaxf(fv, -kBoundLimit16), kBoundLimit16);
             uu[h] = (int)rintf(fu);
             vv[h] = (int)rintf(fv);
         }
@@ -1535,6 +1584,7 @@ __device__ __forceinline__ void makeProjection(const u32 (&pix)[16], const Block
         P.tVV = dot2(P.V[k], P.V[k], P.tVV);
         P.tUV = dot2(P.U[k], P.V[k], P.tUV);
     }
+    }
 }
 
 struct Sums2D
@@ -1542,10 +1592,29 @@ struct Sums2D
     int n, u, v, uu, vv, uv;
 };
 
-__device__ __forceinline__ void maskedSums(const Proj2D &P, u32 mask, Sums2D &m)
+template <bool G8>
+__device__ __forceinline__ void maskedSums(const Proj2D<G8> &P, u32 mask, Sums2D &m)
 {
     m.n = __popc(mask);
     m.u = m.v = m.uu = m.vv = m.uv = 0;
+    if constexpr (G8)
+    {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        // four mask bits -> four 0x00 / 0xff bytes
+        const u32 bits = (((mask >> (4 * k)) & 0xfu) * 0x00204081u) & 0x01010101u;
+        const u32 sel = (bits << 8) - bits;
+        const u32 um = P.U[k] & sel, vm = P.V[k] & sel;
+        m.u = dot4s(um, 0x01010101u, m.u);
+        m.v = dot4s(vm, 0x01010101u, m.v);
+        m.uu = dot4s(um, P.U[k], m.uu);
+        m.vv = dot4s(vm, P.V[k], m.vv);
+        m.uv = dot4s(um, P.V[k], m.uv);
+    }
+    }
+    else
+    {
 #pragma unroll
     for (int k = 0; k < 8; k++)
     {
@@ -1558,6 +1627,7 @@ __device__ __forceinline__ void maskedSums(const Proj2D &P, u32 mask, Sums2D &m)
         m.uu = dot2(um, P.U[k], m.uu);
         m.vv = dot2(vm, P.V[k], m.vv);
         m.uv = dot2(um, P.V[k], m.uv);
+    }
     }
 }
 
@@ -2077,12 +2147,14 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 else
                 {
                     const bool use4 = (boundSet == 0);
+                    auto boundsOnGrid = [&](auto g8) {
+                    constexpr bool G8 = decltype(g8)::value;
                     const float wsum = A.wSq[0] + A.wSq[1] + A.wSq[2] + (use4 ? A.wSq[3] : 0.0f);
-                    const float scale = CVTT_BOUND_GRID / (255.0f * __builtin_amdgcn_sqrtf(wsum)); // wave-uniform
+                    const float scale = (G8 ? kBoundGrid8 : kBoundGrid16) / (255.0f * __builtin_amdgcn_sqrtf(wsum)); // wave-uniform
                     const float invScaleSq = 1.0f / (scale * scale);
                     // rounding the projected points moves each by at most sqrt(2)/2 grid units
                     const float delta = (use4 ? A.delta4 : A.delta3) + 0.7072f / scale;
-                    Proj2D P;
+                    Proj2D<G8> P;
                     PROF_MARK(2)
                     {
                         // take the block statistics back from LDS (they were not kept in registers across the search)
@@ -2134,6 +2206,11 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                             lb += staticAlphaBlock;
                         s_bound[partition][blk] = lb;
                     }
+                    };
+                    if (use4 ? CVTT_GRID8_RGBA : CVTT_GRID8_RGB)
+                        boundsOnGrid(std::true_type{});
+                    else
+                        boundsOnGrid(std::false_type{});
                 }
                 __syncthreads();
                 boundsFor = boundSet;
