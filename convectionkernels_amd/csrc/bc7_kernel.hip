@@ -1285,7 +1285,8 @@ __device__ __forceinline__ void scatterFromRaw(const int (&s)[4], const int (&p)
         {
             // 16*sum(xy) - sum(x)*sum(y): an exact integer below 2^24
             const int v = 16 * p[tri(r, c)] - __mul24(s[r], s[c]);
-            bs.S[tri(r, c)] = (float)v * (A.w[r] * A.w[c] * 0.0625f);
+            // (no product of two weights on its own: the optimiser would keep all ten of them in registers for the whole kernel)
+            bs.S[tri(r, c)] = (((float)v * 0.0625f) * A.w[r]) * A.w[c];
         }
     }
 }
@@ -1357,7 +1358,7 @@ __device__ __forceinline__ float subsetBoundFull(const RawSums &r, const float (
         for (int b = 0; b <= a; b++)
         {
             const int v = __mul24(r.n, r.p[tri(a, b)]) - __mul24(r.s[a], r.s[b]);
-            m.cov[tri(a, b)] = (float)v * (w[a] * w[b] * inv);
+            m.cov[tri(a, b)] = (((float)v * inv) * w[a]) * w[b]; // see scatterFromRaw
         }
     return shapeErrorLowerBound<N>(m, n, delta);
 }

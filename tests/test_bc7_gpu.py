@@ -164,7 +164,8 @@ def test_single_colour_flag_on_dark_content(gpu_ctx, oracle_lib):
 
 def test_second_launch_hand_over_is_invisible(gpu_ctx, oracle_lib, monkeypatch):
     """Blocks with many live mode-7 partitions are finished by a second launch (bc7_kernel.hip, HARD).  Off, with three
-    slots only (most such blocks find none and search on themselves) and with the defaults, the output is the oracle's."""
+    slots only (most such blocks find none and search on themselves), with a slot for every block and with the defaults
+    (off below half a million blocks; the full-size hash tests run with it on), the output is the oracle's."""
     api = _api()
     rcp = oracle_lib.probe_rcp()
     blocks = np.concatenate([content.mixed_ldr_blocks(777, 40), content.config_blocks(9, 256, 256)])
@@ -172,7 +173,7 @@ def test_second_launch_hand_over_is_invisible(gpu_ctx, oracle_lib, monkeypatch):
     exp = oracle_lib.encode_bc7(blocks, np.frombuffer(opt.tobytes(), np.uint8).copy(),
                                 np.frombuffer(plan.tobytes(), np.uint8).copy(), rcp, threads=8)
     for env in ({"CVTTMI_BC7_HARD_MIN": "0"}, {"CVTTMI_BC7_HARD_CAP": "3", "CVTTMI_BC7_HARD_MIN": "2"},
-                {"CVTTMI_BC7_HARD_MIN": "2", "CVTTMI_BC7_HARD_DIV": "1000000"}, {}):
+                {"CVTTMI_BC7_HARD_CAP": "4096", "CVTTMI_BC7_HARD_MIN": "2", "CVTTMI_BC7_HARD_DIV": "1000000"}, {}):
         for k in ("CVTTMI_BC7_HARD_MIN", "CVTTMI_BC7_HARD_CAP", "CVTTMI_BC7_HARD_DIV"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
