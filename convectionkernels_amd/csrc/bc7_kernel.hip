@@ -14,7 +14,8 @@
 //     total-least-squares residual minus the allowance for rounding, cvtt_kernel_common.h) is compared with the
 //     block's best error so far; a candidate that cannot pass the reference's commit test is skipped, which leaves
 //     the output bit-identical.  Whole-block bounds order and prune the four rotations of modes 4/5 and mode 6;
-//     bounds of all 64 partitions (2-D projection, v_dot2 masked sums) go to LDS per mode family.
+//     bounds of all 64 partitions (2-D projection, v_dot4 / v_dot2 masked sums) go to LDS per mode family, and the
+//     partitions they leave alive get the same bound in all channels of each subset (raw integer sums, second tier).
 //   * dual-plane modes 4/5: a block is owned by a lane QUAD, sub-lane = seed point; the block is held channel-major,
 //     the float index selection and refiner sums are the reference's operations, the integer error comes from level
 //     tables + v_perm_b32 + v_dot4_u32_u8 (evalDualFast; evalDual for slow indexing).
@@ -25,7 +26,10 @@
 //     reference's candidate order), so the evaluation order is free.
 //   * BC7_RespectPunchThrough (separate instantiation): the commit rule couples the 8 blocks of a group per trial;
 //     every trial's error is recorded in LDS and the rule is replayed over 8-lane ballot slices.
-//   * the quad packs the (up to 66) bit fields of its block in parallel and sub-lane 0 stores the 16 bytes.
+//   * modes 4 / 5 are packed by one lane at constant bit positions; for the other modes the quad packs the (up to 66)
+//     bit fields of its block in parallel; sub-lane 0 stores the 16 bytes.
+//   * large inputs: a wave that would still have many mode-7 partitions to search near the end of the grid hands those
+//     blocks to a second launch (HARD instantiation, 16 waves per block) and a commit launch picks the winner.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
