@@ -1335,6 +1335,55 @@ __device__ __forceinline__ void maskedRawSums(const u32 (&pix)[16], u32 mask, Ra
     }
 }
 
+// channel-major copy of a block: P[ch][g] = channel ch of pixels 4g .. 4g+3 (the layout of the dual-plane search)
+__device__ __forceinline__ void channelMajor(const u32 (&pix)[16], u32 (&P)[4][4])
+{
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+    {
+        const u32 a = fetchPixel(pix[4 * g]), b = fetchPixel(pix[4 * g + 1]), cc = fetchPixel(pix[4 * g + 2]), d = fetchPixel(pix[4 * g + 3]);
+        const u32 ab02 = __builtin_amdgcn_perm(b, a, 0x06020400u); // a0 b0 a2 b2
+        const u32 ab13 = __builtin_amdgcn_perm(b, a, 0x07030501u); // a1 b1 a3 b3
+        const u32 cd02 = __builtin_amdgcn_perm(d, cc, 0x06020400u);
+        const u32 cd13 = __builtin_amdgcn_perm(d, cc, 0x07030501u);
+        P[0][g] = __builtin_amdgcn_perm(cd02, ab02, 0x05040100u); // a0 b0 c0 d0
+        P[2][g] = __builtin_amdgcn_perm(cd02, ab02, 0x07060302u); // a2 b2 c2 d2
+        P[1][g] = __builtin_amdgcn_perm(cd13, ab13, 0x05040100u);
+        P[3][g] = __builtin_amdgcn_perm(cd13, ab13, 0x07060302u);
+    }
+}
+
+// the same sums from the channel-major copy: four pixels per v_dot4_u32_u8
+__device__ __forceinline__ void maskedRawSumsCM(const u32 (&P)[4][4], u32 mask, RawSums &r)
+{
+    r.n = __popc(mask & 0xffffu);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        r.s[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+        r.p[i] = 0;
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+    {
+        // four mask bits -> four 0x00 / 0xff bytes
+        const u32 bits = (((mask >> (4 * g)) & 0xfu) * 0x00204081u) & 0x01010101u;
+        const u32 sel = (bits << 8) - bits;
+        u32 m[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++)
+        {
+            m[ch] = P[ch][g] & sel;
+            r.s[ch] = (int)__builtin_amdgcn_udot4(m[ch], 0x01010101u, (u32)r.s[ch], false);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++)
+                r.p[tri(a, b)] = (int)__builtin_amdgcn_udot4(m[a], P[b][g], (u32)r.p[tri(a, b)], false);
+    }
+}
+
 __device__ __forceinline__ void rawSumsSub(RawSums &d, const RawSums &a)
 {
     d.n -= a.n;
@@ -2268,6 +2317,8 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                     for (int i = 0; i < 10; i++)
                         d.p[i] = s_scatter[blk][i] - a.p[i];
                 };
+                u32 CM[4][4];
+                channelMajor(pix, CM);
                 // every lane walks its own list: as many rounds as the longest list, not as many as there are slots in use
                 u32 rem = todo;
                 while (__ballot(rem != 0) != 0)
@@ -2281,17 +2332,17 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                         RawSums s0, s1;
                         if (numSubsets == 2)
                         {
-                            maskedRawSums(pix, T->partition2[partition], s1);
+                            maskedRawSumsCM(CM, T->partition2[partition], s1);
                             rest(s0, s1);
                             lb = use4 ? subsetBoundFull<4>(s1, lw, A.delta4) : subsetBoundFull<3>(s1, lw, A.delta3);
                             lb += use4 ? subsetBoundFull<4>(s0, lw, A.delta4) : subsetBoundFull<3>(s0, lw, A.delta3);
                         }
                         else
                         {
-                            maskedRawSums(pix, T->subsetMask3[partition][0], s1);
+                            maskedRawSumsCM(CM, T->subsetMask3[partition][0], s1);
                             rest(s0, s1);
                             lb = subsetBoundFull<3>(s1, lw, A.delta3);
-                            maskedRawSums(pix, T->subsetMask3[partition][1], s1);
+                            maskedRawSumsCM(CM, T->subsetMask3[partition][1], s1);
                             rawSumsSub(s0, s1);
                             lb += subsetBoundFull<3>(s1, lw, A.delta3);
                             lb += subsetBoundFull<3>(s0, lw, A.delta3);
