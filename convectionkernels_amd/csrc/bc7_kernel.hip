@@ -42,13 +42,14 @@ constexpr int kMaxPTRefine = 6; // BC7_RespectPunchThrough: refine rounds whose 
 // 8-bit ones summed with v_dot4_i32_i8 (half the instructions, bounds looser by the coarser rounding)
 constexpr float kBoundGrid16 = 2000.0f, kBoundLimit16 = 2040.0f;
 constexpr float kBoundGrid8 = 124.0f, kBoundLimit8 = 127.0f;
-// which grid the first-tier bounds of the RGBA partitions (mode 7) and of the RGB partitions (modes 0-3) use: with the
-// second tier behind them the cheaper bounds win on RGBA noise (+3 %), the tighter ones on opaque content (+5 %)
+// which grid the first-tier bounds of the RGBA partitions (mode 7) and of the RGB partitions (modes 0-3) use.  With the
+// second tier behind them the cheaper bounds win everywhere (RGBA noise +3 %, photo-like opaque content +6 %, opaque
+// noise equal); the 12-bit grid stays selectable for experiments.
 #ifndef CVTT_GRID8_RGBA
 #define CVTT_GRID8_RGBA true
 #endif
 #ifndef CVTT_GRID8_RGB
-#define CVTT_GRID8_RGB false
+#define CVTT_GRID8_RGB true
 #endif
 // minimum waves per SIMD the register allocator must leave room for (512 VGPR+AGPR / waves)
 #ifndef CVTT_BC7_WAVES
