@@ -1279,6 +1279,45 @@ __device__ __forceinline__ void blockRawSums(const u32 (&pix)[16], int (&s)[4], 
     }
 }
 
+// the same, by the four lanes of the quad that holds the block: sub-lane c sums pixels c, c+4, c+8, c+12 and the quad adds up
+__device__ __forceinline__ void blockRawSumsQuad(const u32 (&pix)[16], int c, int (&s)[4], int (&p)[10])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        s[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+        p[i] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+        const u32 p0 = pix[4 * j], p1 = pix[4 * j + 1], p2 = pix[4 * j + 2], p3 = pix[4 * j + 3];
+        const u32 pk = fetchPixel(c == 0 ? p0 : c == 1 ? p1 : c == 2 ? p2 : p3);
+        int x[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++)
+        {
+            x[ch] = byteI(pk, ch);
+            s[ch] += x[ch];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int cc = 0; cc <= r; cc++)
+                p[tri(r, cc)] = mad24(x[r], x[cc], p[tri(r, cc)]);
+    }
+#pragma unroll
+    for (int step = 1; step <= 2; step <<= 1)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            s[i] += __shfl_xor(s[i], step);
+#pragma unroll
+        for (int i = 0; i < 10; i++)
+            p[i] += __shfl_xor(p[i], step);
+    }
+}
+
 __device__ __forceinline__ void scatterFromRaw(const int (&s)[4], const int (&p)[10], const CvttBc7Args &A, BlockScatter &bs)
 {
 #pragma unroll
@@ -1576,14 +1615,16 @@ __device__ __forceinline__ void makeProjection(const u32 (&pix)[16], const Block
     P.tU = P.tV = P.tUU = P.tVV = P.tUV = 0;
     if constexpr (G8)
     {
-#pragma unroll
-    for (int k = 0; k < 4; k++)
+    // the four lanes of a quad hold the same block: sub-lane c projects pixels 4c .. 4c+3 and the quad exchanges the words
+    const int c = (int)threadIdx.x & 3;
+    u32 myU = 0, myV = 0;
     {
         u32 ub = 0, vb = 0;
 #pragma unroll
         for (int h = 0; h < 4; h++)
         {
-            const u32 pk = fetchPixel(pix[4 * k + h]);
+            const u32 p0 = pix[h], p1 = pix[4 + h], p2 = pix[8 + h], p3 = pix[12 + h];
+            const u32 pk = fetchPixel(c == 0 ? p0 : c == 1 ? p1 : c == 2 ? p2 : p3);
             float fu = -o1, fv = -o2;
 #pragma unroll
             for (int ch = 0; ch < 4; ch++)
@@ -1598,6 +1639,14 @@ __device__ __forceinline__ void makeProjection(const u32 (&pix)[16], const Block
             ub |= ((u32)(int)rintf(fu) & 0xffu) << (8 * h);
             vb |= ((u32)(int)rintf(fv) & 0xffu) << (8 * h);
         }
+        myU = ub;
+        myV = vb;
+    }
+    const int quadBase = (int)threadIdx.x & ~3;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        const u32 ub = (u32)__shfl((int)myU, quadBase + k), vb = (u32)__shfl((int)myV, quadBase + k);
         P.U[k] = ub;
         P.V[k] = vb;
         P.tU = dot4s(ub, 0x01010101u, P.tU);
@@ -1876,7 +1925,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     {
         {
             int rs[4], rp[10];
-            blockRawSums(pix, rs, rp);
+            blockRawSumsQuad(pix, c, rs, rp);
             if (c == 0)
             {
 #pragma unroll
