@@ -1456,19 +1456,6 @@ __device__ __forceinline__ float subsetBoundFull(const RawSums &r, const float (
     return shapeErrorLowerBound<N>(m, n, delta);
 }
 
-// bound of a shape made of all 16 pixels restricted to three channels (a < b < c)
-__device__ __forceinline__ float planeBound(const BlockScatter &bs, int a, int b, int c, float delta)
-{
-    Moments<3> m;
-    m.cov[0] = bs.S[tri(a, a)];
-    m.cov[1] = bs.S[tri(b, a)];
-    m.cov[2] = bs.S[tri(b, b)];
-    m.cov[3] = bs.S[tri(c, a)];
-    m.cov[4] = bs.S[tri(c, b)];
-    m.cov[5] = bs.S[tri(c, c)];
-    return shapeErrorLowerBound<3>(m, 16.0f, delta);
-}
-
 // dominant eigenvector of a symmetric PSD 4x4 (power iteration from the column of the
 // largest diagonal entry).  Accuracy only affects how tight the bounds are, never their
 // validity: the caller orthonormalises whatever comes back.
@@ -1956,10 +1943,20 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             const float d1 = 0.5000005f * __builtin_amdgcn_sqrtf(s012 - A.wSq[0] + A.wSq[3]) * 1.000001f;
             const float d2 = 0.5000005f * __builtin_amdgcn_sqrtf(s012 - A.wSq[1] + A.wSq[3]) * 1.000001f;
             const float d3 = 0.5000005f * __builtin_amdgcn_sqrtf(s012 - A.wSq[2] + A.wSq[3]) * 1.000001f;
-            lbRot[0] = planeBound(bs, 0, 1, 2, d0);
-            lbRot[1] = planeBound(bs, 1, 2, 3, d1);
-            lbRot[2] = planeBound(bs, 0, 2, 3, d2);
-            lbRot[3] = planeBound(bs, 0, 1, 3, d3);
+            // sub-lane r bounds rotation r (its three channels picked by selects, so that the quad runs the bound once)
+            Moments<3> m;
+            auto pick = [&](int i0, int i1, int i2, int i3) { return c == 0 ? bs.S[i0] : c == 1 ? bs.S[i1] : c == 2 ? bs.S[i2] : bs.S[i3]; };
+            // channel triples (a < b < c'): rotation 0: 0 1 2, 1: 1 2 3, 2: 0 2 3, 3: 0 1 3
+            m.cov[0] = pick(tri(0, 0), tri(1, 1), tri(0, 0), tri(0, 0)); // (a, a)
+            m.cov[1] = pick(tri(1, 0), tri(2, 1), tri(2, 0), tri(1, 0)); // (b, a)
+            m.cov[2] = pick(tri(1, 1), tri(2, 2), tri(2, 2), tri(1, 1)); // (b, b)
+            m.cov[3] = pick(tri(2, 0), tri(3, 1), tri(3, 0), tri(3, 0)); // (c', a)
+            m.cov[4] = pick(tri(2, 1), tri(3, 2), tri(3, 2), tri(3, 1)); // (c', b)
+            m.cov[5] = pick(tri(2, 2), tri(3, 3), tri(3, 3), tri(3, 3)); // (c', c')
+            const float mine = shapeErrorLowerBound<3>(m, 16.0f, c == 0 ? d0 : c == 1 ? d1 : c == 2 ? d2 : d3);
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                lbRot[r] = __shfl(mine, (lane & ~3) | r);
         }
         // search the rotations in the order of their bounds summed over the wave: the likely
         // winner first, so that the others meet a tight best error
