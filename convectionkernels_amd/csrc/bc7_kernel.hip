@@ -1945,7 +1945,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             const float d3 = 0.5000005f * __builtin_amdgcn_sqrtf(s012 - A.wSq[2] + A.wSq[3]) * 1.000001f;
             // sub-lane r bounds rotation r (its three channels picked by selects, so that the quad runs the bound once)
             Moments<3> m;
-            auto pick = [&](int i0, int i1, int i2, int i3) { return c == 0 ? bs.S[i0] : c == 1 ? bs.S[i1] : c == 2 ? bs.S[i2] : bs.S[i3]; };
+#define pick(i0, i1, i2, i3) (c == 0 ? bs.S[i0] : c == 1 ? bs.S[i1] : c == 2 ? bs.S[i2] : bs.S[i3]) /* literal indexes: bs.S stays in registers */
             // channel triples (a < b < c'): rotation 0: 0 1 2, 1: 1 2 3, 2: 0 2 3, 3: 0 1 3
             m.cov[0] = pick(tri(0, 0), tri(1, 1), tri(0, 0), tri(0, 0)); // (a, a)
             m.cov[1] = pick(tri(1, 0), tri(2, 1), tri(2, 0), tri(1, 0)); // (b, a)
@@ -1953,6 +1953,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             m.cov[3] = pick(tri(2, 0), tri(3, 1), tri(3, 0), tri(3, 0)); // (c', a)
             m.cov[4] = pick(tri(2, 1), tri(3, 2), tri(3, 2), tri(3, 1)); // (c', b)
             m.cov[5] = pick(tri(2, 2), tri(3, 3), tri(3, 3), tri(3, 3)); // (c', c')
+#undef pick
             const float mine = shapeErrorLowerBound<3>(m, 16.0f, c == 0 ? d0 : c == 1 ? d1 : c == 2 ? d2 : d3);
 #pragma unroll
             for (int r = 0; r < 4; r++)
