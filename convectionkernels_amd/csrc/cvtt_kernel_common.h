@@ -13,7 +13,23 @@ namespace
 {
 typedef uint32_t u32;
 typedef uint64_t u64;
-typedef float v2f __attribute__((ext_vector_type(2))); // v_pk_add_f32 / v_pk_mul_f32 operands
+// Two-element float values.  Deliberately NOT v_pk_add_f32 / v_pk_mul_f32: on gfx950 a packed instruction occupies both
+// halves of the SIMD's float datapath for its 4 cycles, while two plain v_mul_f32 / v_add_f32 / v_sub_f32 take the same
+// 2 x ~2.3 cycles AND can each be overlapped with an instruction of another wave (conversions, min/max, v_perm, compares
+// ... see profiles/r02/valu_peak.json: the pair matrix).  Measured on BASELINE config 2: scalar + -fno-slp-vectorize
+// (the Makefile default; LLVM's SLP pass otherwise re-packs) 542 vs 515 Mblocks/s.  -DCVTT_PACKED_F32 restores the packed
+// form for A/B runs.
+#ifdef CVTT_PACKED_F32
+typedef float v2f __attribute__((ext_vector_type(2)));
+#else
+struct v2f
+{
+    float x, y;
+};
+__device__ __forceinline__ v2f operator+(v2f a, v2f b) { return v2f{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ v2f operator-(v2f a, v2f b) { return v2f{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ v2f operator*(v2f a, v2f b) { return v2f{a.x * b.x, a.y * b.y}; }
+#endif
 
 // ---- lane arithmetic helpers -------------------------------------------------------
 // MINPS/MAXPS operand order (reference ParallelMath.h:522-559): second operand wins on

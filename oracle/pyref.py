@@ -141,6 +141,27 @@ class RefLib:
                                   options.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(int(signed)))
         return out.reshape(n, 8)
 
+    MT_FORMATS = {"bc7": (0, 64, 16), "bc1": (1, 64, 8), "bc6hu": (2, 128, 16), "bc6hs": (3, 128, 16), "etc2": (4, 64, 8), "etc2rgba": (5, 64, 16)}
+
+    def encode_mt(self, fmt, blocks, options, plan=None, threads=1, budget_s=5.0, chunk_blocks=64):
+        """Time-bounded multi-threaded run (std::thread inside the shim, no Python in the loop): returns
+        (out[:done], done_blocks, seconds).  Only the prefix that was finished within the budget is returned."""
+        code, in_bytes, out_bytes = self.MT_FORMATS[fmt]
+        b = np.ascontiguousarray(blocks)
+        n = b.nbytes // in_bytes
+        out = np.zeros(n * out_bytes, np.uint8)
+        done = ctypes.c_uint64(0)
+        secs = ctypes.c_double(0.0)
+        self.lib.ref_encode_mt.restype = ctypes.c_int
+        rc = self.lib.ref_encode_mt(ctypes.c_int(code), out.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n),
+                                    options.ctypes.data_as(ctypes.c_void_p), plan.ctypes.data_as(ctypes.c_void_p) if plan is not None else None,
+                                    ctypes.c_int(threads), ctypes.c_double(budget_s), ctypes.c_size_t(chunk_blocks),
+                                    ctypes.byref(done), ctypes.byref(secs))
+        if rc != 0:
+            raise RuntimeError("ref_encode_mt rc=%d" % rc)
+        d = int(done.value)
+        return out.reshape(n, out_bytes)[:d], d, float(secs.value)
+
     def decode_bc6h(self, bc, signed=False):
         bc, pb = _u8(bc)
         n = bc.size // 16

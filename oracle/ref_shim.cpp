@@ -14,6 +14,11 @@
 #include <string.h>
 #include <xmmintrin.h>
 
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include <vector>
+
 #include "ConvectionKernels.h"
 #include "ConvectionKernels_BC6H_IO.h"
 
@@ -218,5 +223,73 @@ extern "C"
         cvtt::PixelBlockU8 *o = reinterpret_cast<cvtt::PixelBlockU8 *>(outBlocks);
         for (size_t b = 0; b + cvtt::NumParallelBlocks <= numBlocks; b += cvtt::NumParallelBlocks)
             cvtt::Kernels::DecodeBC7(o + b, bc + b * 16);
+    }
+    // Time-bounded multi-threaded run for bench.py's cpu_baseline: `numThreads` std::threads claim chunks of
+    // `chunkBlocks` blocks (a multiple of 8) in ascending order -- the reference's own one-worker-per-group caller
+    // pattern (etc2packer.cpp:215-281) -- until the input is exhausted or `budgetSeconds` have passed; every claimed chunk
+    // is finished, so on return exactly the prefix [0, *blocksDone) of `out` is valid.
+    // format: 0 = BC7 (plan used), 1 = BC1, 2 = BC6HU, 3 = BC6HS, 4 = ETC2 RGB, 5 = ETC2 RGBA.
+    int ref_encode_mt(int format, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const void *optionsBytes, const void *planBytes,
+                      int numThreads, double budgetSeconds, size_t chunkBlocks, uint64_t *blocksDone, double *seconds)
+    {
+        if (format < 0 || format > 5 || numThreads < 1 || chunkBlocks == 0 || chunkBlocks % cvtt::NumParallelBlocks != 0)
+            return -1;
+        cvtt::Options o;
+        memcpy(&o, optionsBytes, sizeof(o));
+        cvtt::BC7EncodingPlan plan;
+        if (planBytes)
+            memcpy(&plan, planBytes, sizeof(plan));
+        const size_t inBytes = (format == 2 || format == 3) ? 128 : 64;
+        const size_t outBytes = (format == 1 || format == 4) ? 8 : 16;
+        const size_t numChunks = numBlocks / chunkBlocks;
+        std::atomic<size_t> next(0);
+        std::atomic<int> failed(0);
+        const auto t0 = std::chrono::steady_clock::now();
+        auto worker = [&]() {
+            cvtt::ETC2CompressionData *etc = NULL;
+            if (format >= 4)
+            {
+                etc = cvtt::Kernels::AllocETC2Data(shimAlloc, NULL, o);
+                if (!etc)
+                {
+                    failed = 1;
+                    return;
+                }
+            }
+            for (;;)
+            {
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > budgetSeconds)
+                    break;
+                const size_t c = next.fetch_add(1);
+                if (c >= numChunks)
+                    break;
+                for (size_t b = c * chunkBlocks; b < (c + 1) * chunkBlocks; b += cvtt::NumParallelBlocks)
+                {
+                    const uint8_t *in = blocks + b * inBytes;
+                    uint8_t *dst = out + b * outBytes;
+                    switch (format)
+                    {
+                    case 0: cvtt::Kernels::EncodeBC7(dst, reinterpret_cast<const cvtt::PixelBlockU8 *>(in), o, plan); break;
+                    case 1: cvtt::Kernels::EncodeBC1(dst, reinterpret_cast<const cvtt::PixelBlockU8 *>(in), o); break;
+                    case 2: cvtt::Kernels::EncodeBC6HU(dst, reinterpret_cast<const cvtt::PixelBlockF16 *>(in), o); break;
+                    case 3: cvtt::Kernels::EncodeBC6HS(dst, reinterpret_cast<const cvtt::PixelBlockF16 *>(in), o); break;
+                    case 4: cvtt::Kernels::EncodeETC2(dst, reinterpret_cast<const cvtt::PixelBlockU8 *>(in), o, etc); break;
+                    default: cvtt::Kernels::EncodeETC2RGBA(dst, reinterpret_cast<const cvtt::PixelBlockU8 *>(in), o, etc); break;
+                    }
+                }
+            }
+            if (etc)
+                cvtt::Kernels::ReleaseETC2Data(etc, shimFree);
+        };
+        std::vector<std::thread> threads;
+        for (int t = 1; t < numThreads; t++)
+            threads.emplace_back(worker);
+        worker();
+        for (size_t t = 0; t < threads.size(); t++)
+            threads[t].join();
+        *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const size_t claimed = next.load() < numChunks ? next.load() : numChunks;
+        *blocksDone = (uint64_t)(claimed * chunkBlocks);
+        return failed.load() ? -2 : 0;
     }
 }
