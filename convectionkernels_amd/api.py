@@ -190,6 +190,7 @@ _EXPORTS = (
     "cvttmi_encode_etc1_device", "cvttmi_encode_etc1",
     "cvttmi_encode_etc2_punchthrough_alpha_device", "cvttmi_encode_etc2_punchthrough_alpha",
     "cvttmi_default_bc7_fine_tuning", "cvttmi_bc7_plan_from_quality", "cvttmi_bc7_plan_from_fine_tuning",
+    "cvttmi_host_alloc", "cvttmi_host_free", "cvttmi_host_register", "cvttmi_host_unregister",
 )
 
 _lib = None
@@ -255,6 +256,10 @@ def load_library():
     lib.cvttmi_bc7_plan_from_quality.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_bc7_plan_from_fine_tuning.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.cvttmi_default_bc7_fine_tuning.argtypes = [ctypes.c_void_p]
+    lib.cvttmi_host_alloc.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    lib.cvttmi_host_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.cvttmi_host_register.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.cvttmi_host_unregister.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.cvttmi_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_set_exhaustive.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_timing_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
@@ -262,14 +267,43 @@ def load_library():
     return lib
 
 
+def library_fatbin_sha256(path=None):
+    """SHA-256 of the device code (.hip_fatbin section) of the library that load_library() uses: identifies the kernel
+    objects a profile was taken with (bench.py only quotes profiles/rNN/summary.json counters when it matches)."""
+    import hashlib
+    import struct
+    path = path or os.environ.get("CVTTMI_LIB", _LIB_PATH)
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"\x7fELF" or data[4] != 2:
+        return hashlib.sha256(data).hexdigest()
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+    stroff = secs[shstrndx][4]
+    for name_off, _type, _flags, _addr, off, size, *_ in secs:
+        end = data.index(b"\0", stroff + name_off)
+        if data[stroff + name_off:end] == b".hip_fatbin":
+            return hashlib.sha256(data[off:off + size]).hexdigest()
+    return hashlib.sha256(data).hexdigest()
+
+
 def exported_symbols():
     return _EXPORTS
 
 
 class Context:
-    """One encoder context on one HIP device (tables in HBM, staging buffers, rcp table)."""
+    """One encoder context on one HIP device (tables in HBM, staging and work buffers, rcp table).
+
+    Concurrency: a context owns ONE set of device work buffers (the BC7 hand-over list, the BC6H scratch, the host-path
+    staging ring).  Calls on different streams are ordered by the library itself (every call makes its stream wait for the
+    context's previous launch, cvtt_mi355x.h "Streams"), and the host-pointer calls of one context are serialised by a lock
+    here, so sharing a context between threads or streams is safe but not concurrent -- use one Context per worker thread
+    (they are cheap: ~10 KB of tables + the work buffers) to overlap independent jobs."""
 
     def __init__(self, device=0):
+        import threading
+        self._host_lock = threading.Lock()
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         rc = self._lib.cvttmi_create(ctypes.byref(self._h), int(device))
@@ -293,6 +327,43 @@ class Context:
             msg = self._lib.cvttmi_last_error(self._h)
             raise CvttError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
 
+    # -- argument checks shared by every entry point: a wrong buffer must raise here, never reach a kernel or memcpy --
+    @staticmethod
+    def _host_out(out, n, out_bytes, dtype=np.uint8, shape=None):
+        """the caller's numpy result buffer, or a fresh one"""
+        if out is None:
+            return np.empty(shape if shape is not None else (n, out_bytes), dtype)
+        need = n * out_bytes
+        if not (isinstance(out, np.ndarray) and out.flags["C_CONTIGUOUS"] and out.flags["WRITEABLE"] and out.nbytes == need
+                and out.dtype.itemsize == np.dtype(dtype).itemsize):
+            raise CvttError("out must be a writable C-contiguous numpy array of exactly %d bytes (%d blocks x %d), %d-byte elements"
+                            % (need, n, out_bytes, np.dtype(dtype).itemsize))
+        return out
+
+    def _device_in(self, t, what="blocks"):
+        import torch
+        if not (isinstance(t, torch.Tensor) and t.is_cuda):
+            raise CvttError("%s must be a numpy array or a CUDA tensor (got %s)" % (what, type(t).__name__ if not isinstance(t, torch.Tensor) else "a CPU tensor"))
+        if t.device.index != self.device:
+            raise CvttError("%s lives on cuda:%d but this context was created for cuda:%d" % (what, t.device.index, self.device))
+        return t.contiguous()
+
+    def _device_out(self, out, n, out_bytes, like, dtype=None, shape=None):
+        """the caller's CUDA result tensor, or a fresh one on the input's device"""
+        import torch
+        dtype = dtype or torch.uint8
+        if out is None:
+            return torch.empty(shape if shape is not None else (n, out_bytes), dtype=dtype, device=like.device)
+        need = n * out_bytes
+        if not (isinstance(out, torch.Tensor) and out.is_cuda and out.device == like.device and out.is_contiguous()
+                and out.numel() * out.element_size() == need and out.element_size() == torch.empty((), dtype=dtype).element_size()):
+            raise CvttError("out must be a contiguous CUDA tensor on %s of exactly %d bytes (%d blocks x %d)" % (like.device, need, n, out_bytes))
+        return out
+
+    def _stream(self, stream, device):
+        import torch
+        return torch.cuda.current_stream(device).cuda_stream if stream is None else stream
+
     # -- reciprocal table (host RCPPS probe; see include/cvtt_mi355x.h) --
     def get_rcp_table(self):
         out = np.zeros(17, np.float32)
@@ -303,6 +374,36 @@ class Context:
         lut = np.ascontiguousarray(lut, np.float32)
         assert lut.size == 17
         self._check(self._lib.cvttmi_set_rcp_table(self._h, lut.ctypes.data), "set_rcp_table")
+
+    # -- page-locked host memory for the host-pointer (numpy) entry points --
+    def host_empty(self, shape, dtype=np.uint8):
+        """numpy array in page-locked memory (cvttmi_host_alloc): the numpy entry points move it over PCIe in place,
+        pipelined with the search, instead of staging it through a copy.  Freed when the array and its views are gone."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        p = ctypes.c_void_p()
+        self._check(self._lib.cvttmi_host_alloc(self._h, ctypes.byref(p), nbytes), "host_alloc")
+        lib, h, addr = self._lib, self._h, p.value
+
+        class _Owner:
+            def __del__(self_inner):
+                try:
+                    lib.cvttmi_host_free(h, ctypes.c_void_p(addr))
+                except Exception:  # noqa
+                    pass
+        buf = (ctypes.c_uint8 * max(1, nbytes)).from_address(addr)
+        buf._owner = _Owner()
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def host_register(self, array):
+        """page-lock an existing C-contiguous numpy array in place (undo with host_unregister before freeing it)"""
+        a = np.ascontiguousarray(array)
+        if a.ctypes.data != array.ctypes.data:
+            raise CvttError("array must be C-contiguous")
+        self._check(self._lib.cvttmi_host_register(self._h, a.ctypes.data, a.nbytes), "host_register")
+
+    def host_unregister(self, array):
+        self._check(self._lib.cvttmi_host_unregister(self._h, array.ctypes.data), "host_unregister")
 
     def set_exhaustive(self, on=True):
         """search every candidate like the reference (default: exact branch-and-bound pruning)"""
@@ -330,20 +431,20 @@ class Context:
             n = b.size // 64
             if b.size % 64 or n % NumParallelBlocks:
                 raise CvttError("blocks must hold a multiple of 8 PixelBlockU8")
-            res = np.empty((n, 16), np.uint8) if out is None else out
-            self._check(self._lib.cvttmi_encode_bc7(self._h, res.ctypes.data, b.ctypes.data, n,
-                                                    ctypes.addressof(options), ctypes.addressof(plan)), "encode_bc7")
+            res = self._host_out(out, n, 16)
+            with self._host_lock:
+                self._check(self._lib.cvttmi_encode_bc7(self._h, res.ctypes.data, b.ctypes.data, n,
+                                                        ctypes.addressof(options), ctypes.addressof(plan)), "encode_bc7")
             return res
         import torch
-        if not (isinstance(blocks, torch.Tensor) and blocks.is_cuda and blocks.dtype == torch.uint8):
+        b = self._device_in(blocks)
+        if b.dtype != torch.uint8:
             raise CvttError("blocks must be a numpy uint8 array or a CUDA uint8 tensor")
-        b = blocks.contiguous()
         n = b.numel() // 64
         if b.numel() % 64 or n % NumParallelBlocks:
             raise CvttError("blocks must hold a multiple of 8 PixelBlockU8")
-        res = torch.empty((n, 16), dtype=torch.uint8, device=b.device) if out is None else out
-        if stream is None:
-            stream = torch.cuda.current_stream(b.device).cuda_stream
+        res = self._device_out(out, n, 16, b)
+        stream = self._stream(stream, b.device)
         self._check(self._lib.cvttmi_encode_bc7_device(self._h, res.data_ptr(), b.data_ptr(), n,
                                                        ctypes.addressof(options), ctypes.addressof(plan),
                                                        ctypes.c_void_p(stream)), "encode_bc7_device")
@@ -358,20 +459,17 @@ class Context:
             n = b.nbytes // in_bytes
             if b.nbytes % in_bytes or n % NumParallelBlocks:
                 raise CvttError("blocks must hold a multiple of 8 pixel blocks")
-            res = np.empty((n, out_bytes), np.uint8) if out is None else out
-            self._check(host_fn(self._h, res.ctypes.data, b.ctypes.data, n, ctypes.addressof(options)), what)
+            res = self._host_out(out, n, out_bytes)
+            with self._host_lock:
+                self._check(host_fn(self._h, res.ctypes.data, b.ctypes.data, n, ctypes.addressof(options)), what)
             return res
-        import torch
-        if not (isinstance(blocks, torch.Tensor) and blocks.is_cuda):
-            raise CvttError("blocks must be a numpy array or a CUDA tensor")
-        b = blocks.contiguous()
+        b = self._device_in(blocks)
         nbytes = b.numel() * b.element_size()
         n = nbytes // in_bytes
         if nbytes % in_bytes or n % NumParallelBlocks:
             raise CvttError("blocks must hold a multiple of 8 pixel blocks")
-        res = torch.empty((n, out_bytes), dtype=torch.uint8, device=b.device) if out is None else out
-        if stream is None:
-            stream = torch.cuda.current_stream(b.device).cuda_stream
+        res = self._device_out(out, n, out_bytes, b)
+        stream = self._stream(stream, b.device)
         self._check(dev_fn(self._h, res.data_ptr(), b.data_ptr(), n, ctypes.addressof(options), ctypes.c_void_p(stream)), what)
         return res
 
@@ -466,18 +564,19 @@ class Context:
             if b.size % 16 or n % NumParallelBlocks:
                 raise CvttError("packed must hold a multiple of 8 16-byte blocks")
             res = np.empty((n, 16, 4), np.int16 if hdr else np.uint8)
-            rc = (self._lib.cvttmi_decode_bc6h(self._h, res.ctypes.data, b.ctypes.data, n, sg) if hdr
-                  else self._lib.cvttmi_decode_bc7(self._h, res.ctypes.data, b.ctypes.data, n))
+            with self._host_lock:
+                rc = (self._lib.cvttmi_decode_bc6h(self._h, res.ctypes.data, b.ctypes.data, n, sg) if hdr
+                      else self._lib.cvttmi_decode_bc7(self._h, res.ctypes.data, b.ctypes.data, n))
             self._check(rc, "decode")
             return res
         import torch
-        b = packed.contiguous()
-        n = b.numel() * b.element_size() // 16
-        if n % NumParallelBlocks:
+        b = self._device_in(packed, "packed")
+        nbytes = b.numel() * b.element_size()
+        n = nbytes // 16
+        if nbytes % 16 or n % NumParallelBlocks:
             raise CvttError("packed must hold a multiple of 8 16-byte blocks")
         res = torch.empty((n, 16, 4), dtype=torch.int16 if hdr else torch.uint8, device=b.device)
-        if stream is None:
-            stream = torch.cuda.current_stream(b.device).cuda_stream
+        stream = self._stream(stream, b.device)
         rc = (self._lib.cvttmi_decode_bc6h_device(self._h, res.data_ptr(), b.data_ptr(), n, sg, ctypes.c_void_p(stream)) if hdr
               else self._lib.cvttmi_decode_bc7_device(self._h, res.data_ptr(), b.data_ptr(), n, ctypes.c_void_p(stream)))
         self._check(rc, "decode")
@@ -512,6 +611,8 @@ class Context:
         import torch
         if not (isinstance(image, torch.Tensor) and image.is_cuda and image.dim() == 3 and image.shape[2] == 4):
             raise CvttError("image must be a CUDA tensor of shape (H, W, 4)")
+        if image.device.index != self.device:
+            raise CvttError("image lives on cuda:%d but this context was created for cuda:%d" % (image.device.index, self.device))
         if image.stride(2) != 1 or image.stride(1) != 4:
             image = image.contiguous()
         h, w = int(image.shape[0]), int(image.shape[1])
@@ -529,6 +630,7 @@ class Context:
     def compact_rows(self, packed, width, height, stream=None):
         """drop the blocks that only pad the last group of every block row: (padded N, B) -> (ceil(H/4)*ceil(W/4), B)"""
         import torch
+        packed = self._device_in(packed, "packed")
         bpb = int(packed.shape[1])
         out = torch.empty((((height + 3) // 4) * ((width + 3) // 4), bpb), dtype=torch.uint8, device=packed.device)
         if stream is None:

@@ -14,6 +14,7 @@
 #include <xmmintrin.h>
 #include <math.h>
 
+#include <mutex>
 #include <string>
 
 #include "cvtt_device.h"
@@ -63,17 +64,30 @@ struct cvttmi_context
     // different plans never race with an in-flight kernel
     static const int kPlanSlots = 8;
     CvttBc7DevicePlan *dPlans;
+    CvttBc7DevicePlan *pinnedPlans; // the staged plans in pinned memory: sources of the asynchronous uploads
     cvttmi_bc7_plan lastPlan[kPlanSlots];
     bool planValid[kPlanSlots];
+    hipEvent_t evPlan[kPlanSlots];  // recorded after the last launch that reads the slot
+    bool planEventValid[kPlanSlots];
+    hipEvent_t evPlanUp[kPlanSlots]; // recorded after the slot's upload, on the stream that did it
+    hipStream_t planUpStream[kPlanSlots];
     int nextPlanSlot;
-    // host-buffer staging
-    void *pinnedIn;
-    void *pinnedOut;
-    size_t pinnedInBytes, pinnedOutBytes;
-    void *dIn;
-    void *dOut;
-    size_t dInBytes, dOutBytes;
-    hipStream_t stream;
+    // host-pointer entry points: a two-deep pipeline of chunks, each slot with its own staging and stream, so that the
+    // upload of chunk i+1 and the download of chunk i-1 overlap the search of chunk i
+    struct PipeSlot
+    {
+        void *pinnedIn, *pinnedOut, *dIn, *dOut;
+        hipStream_t stream;
+        hipEvent_t done;
+    } pipe[2];
+    size_t pipeInBytes, pipeOutBytes;
+    hipStream_t stream; // = pipe[0].stream: the context's private stream
+    // calls may arrive from several host threads and on several streams, but the work buffers below exist once:
+    // `mu` serialises the host side of a call, `evLast` orders its launches after the previous call's
+    std::recursive_mutex mu;
+    hipEvent_t evLast;
+    hipStream_t lastStream;
+    bool lastValid;
     void *dScratch;       // kernel work space (BC6H endpoint history), grown on demand
     size_t dScratchBytes;
     bool exhaustive; // search every candidate even when it provably cannot win
@@ -196,69 +210,195 @@ namespace
         return CVTTMI_OK;
     }
 
-    int stagePlan(cvttmi_context *ctx, const cvttmi_bc7_plan *plan, hipStream_t stream, const CvttBc7DevicePlan **dPlanOut)
+    // The launches of this call use the context's one set of work buffers: make `stream` wait for the previous call's
+    // launches when those went to a different stream (same stream: already ordered).
+    void orderAfterPrevious(cvttmi_context *ctx, hipStream_t stream)
+    {
+        if (ctx->lastValid && ctx->lastStream != stream)
+            (void)hipStreamWaitEvent(stream, ctx->evLast, 0);
+    }
+    void markLaunch(cvttmi_context *ctx, hipStream_t stream)
+    {
+        if (hipEventRecord(ctx->evLast, stream) == hipSuccess)
+        {
+            ctx->lastStream = stream;
+            ctx->lastValid = true;
+        }
+    }
+
+    // Upload of a plan into the ring of device slots, asynchronously on the launch stream.  A slot is rewritten only
+    // after the last launch that read it has finished (its event; normally long past), never with a device-wide sync.
+    int stagePlan(cvttmi_context *ctx, const cvttmi_bc7_plan *plan, hipStream_t stream, const CvttBc7DevicePlan **dPlanOut, int *slotOut)
     {
         for (int i = 0; i < cvttmi_context::kPlanSlots; i++)
         {
             if (ctx->planValid[i] && memcmp(&ctx->lastPlan[i], plan, sizeof(*plan)) == 0)
             {
+                // uploaded on another stream: that copy must have landed before this stream's kernel reads the slot
+                if (ctx->planUpStream[i] != stream)
+                    (void)hipStreamWaitEvent(stream, ctx->evPlanUp[i], 0);
                 *dPlanOut = ctx->dPlans + i;
+                *slotOut = i;
                 return CVTTMI_OK;
             }
         }
         const int slot = ctx->nextPlanSlot;
         ctx->nextPlanSlot = (slot + 1) % cvttmi_context::kPlanSlots;
-        // the slot may still be read by an earlier launch on another stream: be conservative
-        hipError_t e = hipDeviceSynchronize();
-        if (e != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "hipDeviceSynchronize", e);
+        hipError_t e;
+        if (ctx->planEventValid[slot] && (e = hipEventSynchronize(ctx->evPlan[slot])) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "hipEventSynchronize(plan slot)", e);
         memcpy(&ctx->lastPlan[slot], plan, sizeof(*plan));
         ctx->planValid[slot] = true;
-        CvttBc7DevicePlan staged;
+        CvttBc7DevicePlan &staged = ctx->pinnedPlans[slot];
         memset(&staged, 0, sizeof(staged));
         staged.plan = *plan;
-        for (int i = 0; i < plan->rgbNumShapesToEvaluate; i++)
+        // the counts index fixed-size lists: never read past them, whatever the caller wrote
+        const int numRGB = plan->rgbNumShapesToEvaluate > 243 ? 243 : plan->rgbNumShapesToEvaluate;
+        const int numRGBA = plan->rgbaNumShapesToEvaluate > 129 ? 129 : plan->rgbaNumShapesToEvaluate;
+        staged.plan.rgbNumShapesToEvaluate = static_cast<uint8_t>(numRGB);
+        staged.plan.rgbaNumShapesToEvaluate = static_cast<uint8_t>(numRGBA);
+        for (int i = 0; i < numRGB; i++)
         {
             const int shape = plan->rgbShapeList[i];
-            staged.rgbListed[shape >> 5] |= 1u << (shape & 31);
+            if (shape < 243)
+                staged.rgbListed[shape >> 5] |= 1u << (shape & 31);
         }
-        for (int i = 0; i < plan->rgbaNumShapesToEvaluate; i++)
+        for (int i = 0; i < numRGBA; i++)
         {
             const int shape = plan->rgbaShapeList[i];
             if (shape < 129)
                 staged.rgbaListed[shape >> 5] |= 1u << (shape & 31);
         }
-        e = hipMemcpy(ctx->dPlans + slot, &staged, sizeof(staged), hipMemcpyHostToDevice);
+        e = hipMemcpyAsync(ctx->dPlans + slot, &staged, sizeof(staged), hipMemcpyHostToDevice, stream);
         if (e != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "hipMemcpy(plan)", e);
-        (void)stream;
+            return fail(ctx, CVTTMI_E_HIP, "hipMemcpyAsync(plan)", e);
+        if ((e = hipEventRecord(ctx->evPlanUp[slot], stream)) != hipSuccess)
+            return fail(ctx, CVTTMI_E_HIP, "hipEventRecord(plan upload)", e);
+        ctx->planUpStream[slot] = stream;
         *dPlanOut = ctx->dPlans + slot;
+        *slotOut = slot;
         return CVTTMI_OK;
     }
 
-    int ensureStaging(cvttmi_context *ctx, size_t inBytes, size_t outBytes)
+    void freePipe(cvttmi_context *ctx)
     {
+        for (int i = 0; i < 2; i++)
+        {
+            cvttmi_context::PipeSlot &S = ctx->pipe[i];
+            if (S.pinnedIn) (void)hipHostFree(S.pinnedIn);
+            if (S.pinnedOut) (void)hipHostFree(S.pinnedOut);
+            if (S.dIn) (void)hipFree(S.dIn);
+            if (S.dOut) (void)hipFree(S.dOut);
+            S.pinnedIn = S.pinnedOut = S.dIn = S.dOut = NULL;
+        }
+        ctx->pipeInBytes = ctx->pipeOutBytes = 0;
+    }
+
+    int ensurePipe(cvttmi_context *ctx, size_t inBytes, size_t outBytes)
+    {
+        if (ctx->pipeInBytes >= inBytes && ctx->pipeOutBytes >= outBytes)
+            return CVTTMI_OK;
+        (void)hipStreamSynchronize(ctx->pipe[0].stream);
+        (void)hipStreamSynchronize(ctx->pipe[1].stream);
+        inBytes = inBytes > ctx->pipeInBytes ? inBytes : ctx->pipeInBytes;
+        outBytes = outBytes > ctx->pipeOutBytes ? outBytes : ctx->pipeOutBytes;
+        freePipe(ctx);
         hipError_t e;
-        if (ctx->pinnedInBytes < inBytes)
+        for (int i = 0; i < 2; i++)
         {
-            if (ctx->pinnedIn) hipHostFree(ctx->pinnedIn);
-            if (ctx->dIn) hipFree(ctx->dIn);
-            ctx->pinnedIn = ctx->dIn = NULL;
-            ctx->pinnedInBytes = ctx->dInBytes = 0;
-            if ((e = hipHostMalloc(&ctx->pinnedIn, inBytes)) != hipSuccess) return fail(ctx, CVTTMI_E_HIP, "hipHostMalloc", e);
-            if ((e = hipMalloc(&ctx->dIn, inBytes)) != hipSuccess) return fail(ctx, CVTTMI_E_HIP, "hipMalloc", e);
-            ctx->pinnedInBytes = ctx->dInBytes = inBytes;
+            cvttmi_context::PipeSlot &S = ctx->pipe[i];
+            if ((e = hipHostMalloc(&S.pinnedIn, inBytes)) != hipSuccess || (e = hipHostMalloc(&S.pinnedOut, outBytes)) != hipSuccess ||
+                (e = hipMalloc(&S.dIn, inBytes)) != hipSuccess || (e = hipMalloc(&S.dOut, outBytes)) != hipSuccess)
+            {
+                freePipe(ctx);
+                return fail(ctx, CVTTMI_E_HIP, "staging allocation", e);
+            }
         }
-        if (ctx->pinnedOutBytes < outBytes)
+        ctx->pipeInBytes = inBytes;
+        ctx->pipeOutBytes = outBytes;
+        return CVTTMI_OK;
+    }
+
+    // page-locked (hipHostMalloc / hipHostRegister) host memory can be the source / target of an asynchronous copy
+    bool isPinnedHost(const void *p)
+    {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, p) != hipSuccess)
         {
-            if (ctx->pinnedOut) hipHostFree(ctx->pinnedOut);
-            if (ctx->dOut) hipFree(ctx->dOut);
-            ctx->pinnedOut = ctx->dOut = NULL;
-            ctx->pinnedOutBytes = ctx->dOutBytes = 0;
-            if ((e = hipHostMalloc(&ctx->pinnedOut, outBytes)) != hipSuccess) return fail(ctx, CVTTMI_E_HIP, "hipHostMalloc", e);
-            if ((e = hipMalloc(&ctx->dOut, outBytes)) != hipSuccess) return fail(ctx, CVTTMI_E_HIP, "hipMalloc", e);
-            ctx->pinnedOutBytes = ctx->dOutBytes = outBytes;
+            (void)hipGetLastError(); // pageable memory: not an error for us
+            return false;
         }
+        return attr.type == hipMemoryTypeHost;
+    }
+
+    // The host-pointer entry points: `numBlocks` blocks of `inBpb` bytes in host memory -> `outBpb` bytes each in host
+    // memory through `launch(dOut, dIn, n, stream)`, in chunks of 2^17 blocks (8 MiB of PixelBlockU8; measured best of 2^16..2^19) dealt to two pipeline slots with their own
+    // stream, so the PCIe transfers of neighbouring chunks run beside the kernels of the current one (the kernels
+    // themselves stay ordered through the context's work buffers).  Page-locked caller memory (cvttmi_host_alloc /
+    // cvttmi_host_register) is transferred in place; pageable memory goes through the slots' pinned staging, the CPU copy
+    // of the next chunk overlapping the device work of the current one.
+    template <class Launch>
+    int hostPipeline(cvttmi_context *ctx, uint8_t *out, const uint8_t *in, size_t numBlocks, size_t inBpb, size_t outBpb, Launch launch)
+    {
+        static const int chunkLog2 = getenv("CVTTMI_HOST_CHUNK_LOG2") ? atoi(getenv("CVTTMI_HOST_CHUNK_LOG2")) : 17;
+        const size_t kChunk = (size_t)1 << (chunkLog2 < 10 ? 10 : chunkLog2 > 24 ? 24 : chunkLog2);
+        const size_t chunk = numBlocks < kChunk ? numBlocks : kChunk;
+        int rc = ensurePipe(ctx, chunk * inBpb, chunk * outBpb);
+        if (rc != CVTTMI_OK)
+            return rc;
+        const bool inPinned = isPinnedHost(in) && isPinnedHost(in + numBlocks * inBpb - 1);
+        const bool outPinned = isPinnedHost(out) && isPinnedHost(out + numBlocks * outBpb - 1);
+        const size_t numChunks = (numBlocks + chunk - 1) / chunk;
+        hipError_t e;
+        auto finish = [&](size_t c) -> int {
+            cvttmi_context::PipeSlot &S = ctx->pipe[c & 1];
+            hipError_t fe = hipEventSynchronize(S.done);
+            if (fe != hipSuccess)
+                return fail(ctx, CVTTMI_E_HIP, "kernel execution", fe);
+            if (!outPinned)
+            {
+                const size_t n = (numBlocks - c * chunk) < chunk ? (numBlocks - c * chunk) : chunk;
+                memcpy(out + c * chunk * outBpb, S.pinnedOut, n * outBpb);
+            }
+            return CVTTMI_OK;
+        };
+        for (size_t c = 0; c < numChunks; c++)
+        {
+            cvttmi_context::PipeSlot &S = ctx->pipe[c & 1];
+            if (c >= 2 && (rc = finish(c - 2)) != CVTTMI_OK)
+                return rc;
+            const size_t first = c * chunk;
+            const size_t n = (numBlocks - first) < chunk ? (numBlocks - first) : chunk;
+            const void *src = in + first * inBpb;
+            if (!inPinned)
+            {
+                memcpy(S.pinnedIn, src, n * inBpb);
+                src = S.pinnedIn;
+            }
+            if ((e = hipMemcpyAsync(S.dIn, src, n * inBpb, hipMemcpyHostToDevice, S.stream)) != hipSuccess)
+                return fail(ctx, CVTTMI_E_HIP, "H2D", e);
+            if ((rc = launch(S.dOut, S.dIn, n, S.stream)) != CVTTMI_OK)
+                return rc;
+            void *dst = outPinned ? static_cast<void *>(out + first * outBpb) : S.pinnedOut;
+            if ((e = hipMemcpyAsync(dst, S.dOut, n * outBpb, hipMemcpyDeviceToHost, S.stream)) != hipSuccess)
+                return fail(ctx, CVTTMI_E_HIP, "D2H", e);
+            if ((e = hipEventRecord(S.done, S.stream)) != hipSuccess)
+                return fail(ctx, CVTTMI_E_HIP, "hipEventRecord", e);
+        }
+        for (size_t c = numChunks >= 2 ? numChunks - 2 : 0; c < numChunks; c++)
+            if ((rc = finish(c)) != CVTTMI_OK)
+                return rc;
+        return CVTTMI_OK;
+    }
+
+    // common front of the host-pointer entry points
+    int hostPrologue(cvttmi_context *ctx, const void *out, const void *in, const void *options, size_t numBlocks)
+    {
+        if (!out || !in || !options || (numBlocks % 8) != 0 || numBlocks > 0xfffffff0u)
+            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
         return CVTTMI_OK;
     }
 
@@ -450,12 +590,20 @@ extern "C"
         ctx->device = device;
         ctx->dTables = NULL;
         ctx->dPlans = NULL;
+        ctx->pinnedPlans = NULL;
         ctx->nextPlanSlot = 0;
         for (int i = 0; i < cvttmi_context::kPlanSlots; i++)
-            ctx->planValid[i] = false;
-        ctx->pinnedIn = ctx->pinnedOut = ctx->dIn = ctx->dOut = NULL;
-        ctx->pinnedInBytes = ctx->pinnedOutBytes = ctx->dInBytes = ctx->dOutBytes = 0;
+        {
+            ctx->planValid[i] = ctx->planEventValid[i] = false;
+            ctx->evPlan[i] = ctx->evPlanUp[i] = NULL;
+            ctx->planUpStream[i] = NULL;
+        }
+        memset(ctx->pipe, 0, sizeof(ctx->pipe));
+        ctx->pipeInBytes = ctx->pipeOutBytes = 0;
         ctx->stream = NULL;
+        ctx->evLast = ctx->evStart = ctx->evStop = NULL;
+        ctx->lastStream = NULL;
+        ctx->lastValid = false;
         ctx->dScratch = NULL;
         ctx->dScratchBytes = 0;
         ctx->timing = false;
@@ -473,20 +621,25 @@ extern "C"
         ctx->hardCapOverride = getenv("CVTTMI_BC7_HARD_CAP") ? atoi(getenv("CVTTMI_BC7_HARD_CAP")) : 0;
         fillTables(ctx->hostTables);
         hipError_t e;
-        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->dHardCount), 256)) != hipSuccess ||
-            (e = hipMalloc(reinterpret_cast<void **>(&ctx->dHardRec), sizeof(CvttBc7HardRec) * cvttmi_context::kHardSlots)) != hipSuccess ||
-            (e = hipMalloc(reinterpret_cast<void **>(&ctx->dHardCand), sizeof(CvttBc7HardCand) * cvttmi_context::kHardSlots * kHardWaves)) != hipSuccess ||
-            (e = hipMalloc(reinterpret_cast<void **>(&ctx->dTables), sizeof(CvttDeviceTables))) != hipSuccess ||
-            (e = hipMalloc(reinterpret_cast<void **>(&ctx->dPlans), sizeof(CvttBc7DevicePlan) * cvttmi_context::kPlanSlots)) != hipSuccess ||
-            (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
-            (e = hipEventCreate(&ctx->evStart)) != hipSuccess || (e = hipEventCreate(&ctx->evStop)) != hipSuccess)
+        bool ok =
+            (e = hipMalloc(reinterpret_cast<void **>(&ctx->dHardCount), 256)) == hipSuccess &&
+            (e = hipMalloc(reinterpret_cast<void **>(&ctx->dHardRec), sizeof(CvttBc7HardRec) * cvttmi_context::kHardSlots)) == hipSuccess &&
+            (e = hipMalloc(reinterpret_cast<void **>(&ctx->dHardCand), sizeof(CvttBc7HardCand) * cvttmi_context::kHardSlots * kHardWaves)) == hipSuccess &&
+            (e = hipMalloc(reinterpret_cast<void **>(&ctx->dTables), sizeof(CvttDeviceTables))) == hipSuccess &&
+            (e = hipMalloc(reinterpret_cast<void **>(&ctx->dPlans), sizeof(CvttBc7DevicePlan) * cvttmi_context::kPlanSlots)) == hipSuccess &&
+            (e = hipHostMalloc(reinterpret_cast<void **>(&ctx->pinnedPlans), sizeof(CvttBc7DevicePlan) * cvttmi_context::kPlanSlots)) == hipSuccess &&
+            (e = hipStreamCreate(&ctx->pipe[0].stream)) == hipSuccess && (e = hipStreamCreate(&ctx->pipe[1].stream)) == hipSuccess &&
+            (e = hipEventCreateWithFlags(&ctx->pipe[0].done, hipEventDisableTiming)) == hipSuccess &&
+            (e = hipEventCreateWithFlags(&ctx->pipe[1].done, hipEventDisableTiming)) == hipSuccess &&
+            (e = hipEventCreateWithFlags(&ctx->evLast, hipEventDisableTiming)) == hipSuccess &&
+            (e = hipEventCreate(&ctx->evStart)) == hipSuccess && (e = hipEventCreate(&ctx->evStop)) == hipSuccess;
+        for (int i = 0; ok && i < cvttmi_context::kPlanSlots; i++)
+            ok = (e = hipEventCreateWithFlags(&ctx->evPlan[i], hipEventDisableTiming)) == hipSuccess &&
+                 (e = hipEventCreateWithFlags(&ctx->evPlanUp[i], hipEventDisableTiming)) == hipSuccess;
+        ctx->stream = ctx->pipe[0].stream;
+        if (!ok || uploadTables(ctx) != CVTTMI_OK)
         {
-            delete ctx;
-            return CVTTMI_E_HIP;
-        }
-        if (uploadTables(ctx) != CVTTMI_OK)
-        {
-            delete ctx;
+            cvttmi_destroy(ctx); // frees whatever was created: every handle above starts out NULL
             return CVTTMI_E_HIP;
         }
         *out = ctx;
@@ -497,22 +650,64 @@ extern "C"
     {
         if (!ctx)
             return;
-        hipSetDevice(ctx->device);
-        hipDeviceSynchronize();
-        if (ctx->dTables) hipFree(ctx->dTables);
-        if (ctx->dPlans) hipFree(ctx->dPlans);
-        if (ctx->pinnedIn) hipHostFree(ctx->pinnedIn);
-        if (ctx->pinnedOut) hipHostFree(ctx->pinnedOut);
-        if (ctx->dIn) hipFree(ctx->dIn);
-        if (ctx->dOut) hipFree(ctx->dOut);
-        if (ctx->dScratch) hipFree(ctx->dScratch);
-        if (ctx->dHardCount) hipFree(ctx->dHardCount);
-        if (ctx->dHardRec) hipFree(ctx->dHardRec);
-        if (ctx->dHardCand) hipFree(ctx->dHardCand);
-        if (ctx->stream) hipStreamDestroy(ctx->stream);
-        hipEventDestroy(ctx->evStart);
-        hipEventDestroy(ctx->evStop);
+        (void)hipSetDevice(ctx->device);
+        (void)hipDeviceSynchronize();
+        if (ctx->dTables) (void)hipFree(ctx->dTables);
+        if (ctx->dPlans) (void)hipFree(ctx->dPlans);
+        if (ctx->pinnedPlans) (void)hipHostFree(ctx->pinnedPlans);
+        freePipe(ctx);
+        if (ctx->dScratch) (void)hipFree(ctx->dScratch);
+        if (ctx->dHardCount) (void)hipFree(ctx->dHardCount);
+        if (ctx->dHardRec) (void)hipFree(ctx->dHardRec);
+        if (ctx->dHardCand) (void)hipFree(ctx->dHardCand);
+        for (int i = 0; i < 2; i++)
+        {
+            if (ctx->pipe[i].stream) (void)hipStreamDestroy(ctx->pipe[i].stream);
+            if (ctx->pipe[i].done) (void)hipEventDestroy(ctx->pipe[i].done);
+        }
+        for (int i = 0; i < cvttmi_context::kPlanSlots; i++)
+        {
+            if (ctx->evPlan[i]) (void)hipEventDestroy(ctx->evPlan[i]);
+            if (ctx->evPlanUp[i]) (void)hipEventDestroy(ctx->evPlanUp[i]);
+        }
+        if (ctx->evLast) (void)hipEventDestroy(ctx->evLast);
+        if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
+        if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
         delete ctx;
+    }
+
+    // Page-locked host memory for the host-pointer entry points: they transfer such buffers in place (no staging copy).
+    int cvttmi_host_alloc(cvttmi_context *ctx, void **ptr, size_t bytes)
+    {
+        if (!ctx || !ptr)
+            return CVTTMI_E_INVALID;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess)
+            e = hipHostMalloc(ptr, bytes ? bytes : 1);
+        return e == hipSuccess ? CVTTMI_OK : fail(ctx, CVTTMI_E_HIP, "hipHostMalloc", e);
+    }
+    int cvttmi_host_free(cvttmi_context *ctx, void *ptr)
+    {
+        if (!ctx)
+            return CVTTMI_E_INVALID;
+        hipError_t e = ptr ? hipHostFree(ptr) : hipSuccess;
+        return e == hipSuccess ? CVTTMI_OK : fail(ctx, CVTTMI_E_HIP, "hipHostFree", e);
+    }
+    int cvttmi_host_register(cvttmi_context *ctx, void *ptr, size_t bytes)
+    {
+        if (!ctx || !ptr || !bytes)
+            return CVTTMI_E_INVALID;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess)
+            e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+        return e == hipSuccess ? CVTTMI_OK : fail(ctx, CVTTMI_E_HIP, "hipHostRegister", e);
+    }
+    int cvttmi_host_unregister(cvttmi_context *ctx, void *ptr)
+    {
+        if (!ctx || !ptr)
+            return CVTTMI_E_INVALID;
+        hipError_t e = hipHostUnregister(ptr);
+        return e == hipSuccess ? CVTTMI_OK : fail(ctx, CVTTMI_E_HIP, "hipHostUnregister", e);
     }
 
     const char *cvttmi_last_error(const cvttmi_context *ctx)
@@ -610,22 +805,9 @@ extern "C"
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
-        const size_t inBytes = numBlocks * 16, outBytes = numBlocks * (format == 0 ? 64 : 128);
-        int rc = ensureStaging(ctx, inBytes, outBytes);
-        if (rc != CVTTMI_OK)
-            return rc;
-        memcpy(ctx->pinnedIn, bc, inBytes);
-        if ((e = hipMemcpyAsync(ctx->dIn, ctx->pinnedIn, inBytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "H2D", e);
-        rc = decodeDevice(ctx, ctx->dOut, ctx->dIn, numBlocks, format, ctx->stream);
-        if (rc != CVTTMI_OK)
-            return rc;
-        if ((e = hipMemcpyAsync(ctx->pinnedOut, ctx->dOut, outBytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "D2H", e);
-        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "kernel execution", e);
-        memcpy(blocks, ctx->pinnedOut, outBytes);
-        return CVTTMI_OK;
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+        return hostPipeline(ctx, reinterpret_cast<uint8_t *>(blocks), reinterpret_cast<const uint8_t *>(bc), numBlocks, 16, (format == 0 ? 64 : 128),
+                            [&](void *dOut, const void *dIn, size_t n, hipStream_t st) { return decodeDevice(ctx, dOut, dIn, n, format, st); });
     }
 
     int cvttmi_decode_bc7_device(cvttmi_context *ctx, void *d_blocks, const void *d_bc, size_t numBlocks, void *hipStream)
@@ -758,9 +940,11 @@ extern "C"
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
         hipStream_t stream = static_cast<hipStream_t>(hipStream);
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
 
         const CvttBc7DevicePlan *dPlan = NULL;
-        int rc = stagePlan(ctx, plan, stream, &dPlan);
+        int planSlot = 0;
+        int rc = stagePlan(ctx, plan, stream, &dPlan, &planSlot);
         if (rc != CVTTMI_OK)
             return rc;
 
@@ -794,11 +978,19 @@ extern "C"
             args.delta4 = static_cast<float>(0.5 * sqrt(s4) * 1.000001);
         }
 
+        // the hand-over list exists once per context: launches that use it are ordered after the previous one that did
+        // (the plan ring is protected by its own per-slot events)
+        if (args.hardCap)
+            orderAfterPrevious(ctx, stream);
         if (ctx->timing)
             hipEventRecord(ctx->evStart, stream);
         e = cvttmi_launch_bc7(d_blocks, d_out, &args, ctx->dTables, dPlan, stream);
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_HIP, "bc7 kernel launch", e);
+        if (args.hardCap)
+            markLaunch(ctx, stream);
+        if (hipEventRecord(ctx->evPlan[planSlot], stream) == hipSuccess)
+            ctx->planEventValid[planSlot] = true;
         if (ctx->timing)
         {
             hipEventRecord(ctx->evStop, stream);
@@ -885,22 +1077,9 @@ extern "C"
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
-        const size_t inBytes = numBlocks * 64, outBytes = numBlocks * (mode == 1 ? 16 : 8);
-        int rc = ensureStaging(ctx, inBytes, outBytes);
-        if (rc != CVTTMI_OK)
-            return rc;
-        memcpy(ctx->pinnedIn, blocks, inBytes);
-        if ((e = hipMemcpyAsync(ctx->dIn, ctx->pinnedIn, inBytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "H2D", e);
-        rc = etc2Device(ctx, ctx->dOut, ctx->dIn, numBlocks, options, mode, ctx->stream);
-        if (rc != CVTTMI_OK)
-            return rc;
-        if ((e = hipMemcpyAsync(ctx->pinnedOut, ctx->dOut, outBytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "D2H", e);
-        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "kernel execution", e);
-        memcpy(out, ctx->pinnedOut, outBytes);
-        return CVTTMI_OK;
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+        return hostPipeline(ctx, reinterpret_cast<uint8_t *>(out), reinterpret_cast<const uint8_t *>(blocks), numBlocks, 64, (mode == 1 ? 16 : 8),
+                            [&](void *dOut, const void *dIn, size_t n, hipStream_t st) { return etc2Device(ctx, dOut, dIn, n, options, mode, st); });
     }
 
     int cvttmi_encode_etc2_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, void *hipStream)
@@ -956,22 +1135,9 @@ extern "C"
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
-        const size_t inBytes = numBlocks * 32, outBytes = numBlocks * 8;
-        int rc = ensureStaging(ctx, inBytes, outBytes);
-        if (rc != CVTTMI_OK)
-            return rc;
-        memcpy(ctx->pinnedIn, blocksS16, inBytes);
-        if ((e = hipMemcpyAsync(ctx->dIn, ctx->pinnedIn, inBytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "H2D", e);
-        rc = cvttmi_encode_etc2_alpha11_device(ctx, ctx->dOut, ctx->dIn, numBlocks, isSigned, options, ctx->stream);
-        if (rc != CVTTMI_OK)
-            return rc;
-        if ((e = hipMemcpyAsync(ctx->pinnedOut, ctx->dOut, outBytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "D2H", e);
-        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "kernel execution", e);
-        memcpy(out, ctx->pinnedOut, outBytes);
-        return CVTTMI_OK;
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+        return hostPipeline(ctx, reinterpret_cast<uint8_t *>(out), reinterpret_cast<const uint8_t *>(blocksS16), numBlocks, 32, 8,
+                            [&](void *dOut, const void *dIn, size_t n, hipStream_t st) { return cvttmi_encode_etc2_alpha11_device(ctx, dOut, dIn, n, isSigned, options, st); });
     }
 
     int cvttmi_encode_bc6h_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
@@ -987,6 +1153,8 @@ extern "C"
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
         hipStream_t stream = static_cast<hipStream_t>(hipStream);
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+        orderAfterPrevious(ctx, stream); // the endpoint-history scratch exists once per context
         CvttBc6hArgs args;
         fillWeightArgs(options, args.w, args.wSq, args.rcpW);
         args.flags = options->flags;
@@ -1020,6 +1188,7 @@ extern "C"
             if (e != hipSuccess)
                 return fail(ctx, CVTTMI_E_HIP, "bc6h kernel launch", e);
         }
+        markLaunch(ctx, stream);
         if (ctx->timing)
         {
             hipEventRecord(ctx->evStop, stream);
@@ -1044,22 +1213,9 @@ extern "C"
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
-        const size_t inBytes = numBlocks * 128, outBytes = numBlocks * 16;
-        int rc = ensureStaging(ctx, inBytes, outBytes);
-        if (rc != CVTTMI_OK)
-            return rc;
-        memcpy(ctx->pinnedIn, blocks, inBytes);
-        if ((e = hipMemcpyAsync(ctx->dIn, ctx->pinnedIn, inBytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "H2D", e);
-        rc = cvttmi_encode_bc6h_device(ctx, ctx->dOut, ctx->dIn, numBlocks, options, isSigned, ctx->stream);
-        if (rc != CVTTMI_OK)
-            return rc;
-        if ((e = hipMemcpyAsync(ctx->pinnedOut, ctx->dOut, outBytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "D2H", e);
-        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "kernel execution", e);
-        memcpy(out, ctx->pinnedOut, outBytes);
-        return CVTTMI_OK;
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+        return hostPipeline(ctx, reinterpret_cast<uint8_t *>(out), reinterpret_cast<const uint8_t *>(blocks), numBlocks, 128, 16,
+                            [&](void *dOut, const void *dIn, size_t n, hipStream_t st) { return cvttmi_encode_bc6h_device(ctx, dOut, dIn, n, options, isSigned, st); });
     }
 
     int cvttmi_encode_bc1_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
@@ -1159,22 +1315,9 @@ extern "C"
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
-        const size_t inBytes = numBlocks * 64, outBytes = numBlocks * ((format == 4 || format == 5) ? 8 : 16);
-        int rc = ensureStaging(ctx, inBytes, outBytes);
-        if (rc != CVTTMI_OK)
-            return rc;
-        memcpy(ctx->pinnedIn, blocks, inBytes);
-        if ((e = hipMemcpyAsync(ctx->dIn, ctx->pinnedIn, inBytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "H2D", e);
-        rc = s3tcDevice(ctx, ctx->dOut, ctx->dIn, numBlocks, options, format, ctx->stream);
-        if (rc != CVTTMI_OK)
-            return rc;
-        if ((e = hipMemcpyAsync(ctx->pinnedOut, ctx->dOut, outBytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "D2H", e);
-        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "kernel execution", e);
-        memcpy(out, ctx->pinnedOut, outBytes);
-        return CVTTMI_OK;
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+        return hostPipeline(ctx, reinterpret_cast<uint8_t *>(out), reinterpret_cast<const uint8_t *>(blocks), numBlocks, 64, ((format == 4 || format == 5) ? 8 : 16),
+                            [&](void *dOut, const void *dIn, size_t n, hipStream_t st) { return s3tcDevice(ctx, dOut, dIn, n, options, format, st); });
     }
 
     int cvttmi_encode_bc2_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, void *hipStream)
@@ -1206,22 +1349,9 @@ extern "C"
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
-        const size_t inBytes = numBlocks * 64, outBytes = numBlocks * 8;
-        int rc = ensureStaging(ctx, inBytes, outBytes);
-        if (rc != CVTTMI_OK)
-            return rc;
-        memcpy(ctx->pinnedIn, blocks, inBytes);
-        if ((e = hipMemcpyAsync(ctx->dIn, ctx->pinnedIn, inBytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "H2D", e);
-        rc = cvttmi_encode_bc1_device(ctx, ctx->dOut, ctx->dIn, numBlocks, options, ctx->stream);
-        if (rc != CVTTMI_OK)
-            return rc;
-        if ((e = hipMemcpyAsync(ctx->pinnedOut, ctx->dOut, outBytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "D2H", e);
-        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "kernel execution", e);
-        memcpy(out, ctx->pinnedOut, outBytes);
-        return CVTTMI_OK;
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+        return hostPipeline(ctx, reinterpret_cast<uint8_t *>(out), reinterpret_cast<const uint8_t *>(blocks), numBlocks, 64, 8,
+                            [&](void *dOut, const void *dIn, size_t n, hipStream_t st) { return cvttmi_encode_bc1_device(ctx, dOut, dIn, n, options, st); });
     }
 
     int cvttmi_encode_bc7(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
@@ -1236,21 +1366,8 @@ extern "C"
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
-        const size_t inBytes = numBlocks * 64, outBytes = numBlocks * 16;
-        int rc = ensureStaging(ctx, inBytes, outBytes);
-        if (rc != CVTTMI_OK)
-            return rc;
-        memcpy(ctx->pinnedIn, blocks, inBytes);
-        if ((e = hipMemcpyAsync(ctx->dIn, ctx->pinnedIn, inBytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "H2D", e);
-        rc = cvttmi_encode_bc7_device(ctx, ctx->dOut, ctx->dIn, numBlocks, options, plan, ctx->stream);
-        if (rc != CVTTMI_OK)
-            return rc;
-        if ((e = hipMemcpyAsync(ctx->pinnedOut, ctx->dOut, outBytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "D2H", e);
-        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "kernel execution", e);
-        memcpy(out, ctx->pinnedOut, outBytes);
-        return CVTTMI_OK;
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+        return hostPipeline(ctx, reinterpret_cast<uint8_t *>(out), reinterpret_cast<const uint8_t *>(blocks), numBlocks, 64, 16,
+                            [&](void *dOut, const void *dIn, size_t n, hipStream_t st) { return cvttmi_encode_bc7_device(ctx, dOut, dIn, n, options, plan, st); });
     }
 }

@@ -73,3 +73,56 @@ def pipelined_gather_steps(num_steps, encode_step, outs, gathered, group=None):
     for work in pending:
         work.wait()
     return overlapped
+
+
+def shard_ranges(block_rows, blocks_per_row, world):
+    """[first_block, last_block) of every rank's shard."""
+    return [shard_block_rows(block_rows, blocks_per_row, r, world) for r in range(world)]
+
+
+def gather_to_root(local, ranges, full, root=0, group=None, async_op=False):
+    """The one exchange of the path: the packed blocks of every shard go to `root` -- grouped point-to-point
+    sends (ncclSend / ncclRecv inside one group with the `nccl` = RCCL backend, each peer over its own xGMI link; no ring,
+    nothing travels to the other ranks).  `root` receives every shard straight into its slice full[lo:hi] of the output;
+    its own shard is copied there unless `local` already is that slice.  Ragged shards need no padding.
+    Returns the list of pending works when `async_op` (wait on them before reusing `local` / reading `full`)."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    lo, hi = ranges[rank]
+    if world == 1:
+        if full is not None and hi > lo and local.data_ptr() != full[lo:hi].data_ptr():
+            full[lo:hi].copy_(local)
+        return []
+    ops = []
+    if rank == root:
+        for r, (a, b) in enumerate(ranges):
+            if r != root and b > a:
+                ops.append(dist.P2POp(dist.irecv, full[a:b], r, group))
+        if hi > lo and local.data_ptr() != full[lo:hi].data_ptr():
+            full[lo:hi].copy_(local)
+    elif hi > lo:
+        ops.append(dist.P2POp(dist.isend, local, root, group))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    if async_op:
+        return works
+    for w in works:
+        w.wait()
+    return []
+
+
+def pipelined_steps(num_steps, encode_step, exchange):
+    """`num_steps` steps of encode + exchange with two buffer sets: `encode_step(i, buf)` fills buffer set `buf` = i & 1
+    on the current stream, `exchange(i, buf)` starts the exchange that reads it and returns its pending works; a buffer
+    set is reused only after the exchange that read it has completed, so the exchange of step i overlaps the search of
+    step i + 1.  All works are waited for before returning."""
+    pending = []
+    for i in range(num_steps):
+        buf = i & 1
+        if len(pending) >= 2:
+            for w in pending.pop(0):
+                w.wait()
+        encode_step(i, buf)
+        pending.append(exchange(i, buf))
+    for works in pending:
+        for w in works:
+            w.wait()

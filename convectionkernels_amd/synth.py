@@ -9,10 +9,11 @@ import numpy as np
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
-def splitmix64(seed, n):
-    """n draws of SplitMix64 starting from state `seed` (uint64 array)."""
+def splitmix64(seed, n, start=0):
+    """Draws start .. start+n-1 of SplitMix64 from state `seed` (uint64 array); the generator is counter based, so a
+    shard of a stream is generated without the draws before it."""
     with np.errstate(over="ignore"):
-        s = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * np.arange(1, n + 1, dtype=np.uint64)
+        s = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * np.arange(start + 1, start + n + 1, dtype=np.uint64)
         z = s
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
@@ -27,6 +28,17 @@ def random_bytes(seed, nbytes):
 
 def image_rgba8(seed, width, height, opaque=False):
     img = random_bytes(seed, width * height * 4).reshape(height, width, 4)
+    if opaque:
+        img[..., 3] = 255
+    return img
+
+
+def image_rgba8_rows(seed, width, height, row0, row1, opaque=False):
+    """Pixel rows [row0, row1) of image_rgba8(seed, width, height): what one rank of a block-row sharded job needs."""
+    assert 0 <= row0 <= row1 <= height and (width * 4) % 8 == 0
+    first = row0 * width * 4 // 8
+    count = (row1 - row0) * width * 4 // 8
+    img = splitmix64(seed, count, start=first).view(np.uint8).reshape(row1 - row0, width, 4).copy()
     if opaque:
         img[..., 3] = 255
     return img
@@ -48,3 +60,41 @@ def image_f16bits(seed, width, height):
     out[..., :3] = half
     out[..., 3] = 0x3C00
     return out.view(np.int16)
+
+
+def content_families(n, seed=2026):
+    """Eight synthetic content families of n PixelBlockU8 each, (n, 16, 4) uint8 -- the throughput of the BC7 search
+    depends on content because its pruning does: uniform noise (BASELINE configs), opaque noise, smooth
+    gradients with and without alpha, photo-like low-variance blocks, two-colour blocks, punch-through alpha and
+    near-opaque alpha.  Used by bench.py's `content_families` key, tools/family_bench.py and tools/stress_parity.py."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    yy, xx = np.divmod(np.arange(16), 4)
+    f = {}
+    f["noise"] = rng.integers(0, 256, (n, 16, 4), dtype=np.uint8)
+    o = rng.integers(0, 256, (n, 16, 4), dtype=np.uint8)
+    o[:, :, 3] = 255
+    f["opaque noise"] = o
+    c0 = rng.integers(0, 256, (n, 1, 4)).astype(np.float32)
+    dx = rng.normal(0, 10, (n, 1, 4)).astype(np.float32)
+    dy = rng.normal(0, 10, (n, 1, 4)).astype(np.float32)
+    g = np.clip(np.rint(c0 + xx[None, :, None] * dx + yy[None, :, None] * dy), 0, 255).astype(np.uint8)
+    f["gradient rgba"] = g.copy()
+    g2 = g.copy()
+    g2[:, :, 3] = 255
+    f["gradient opaque"] = g2
+    ph = np.clip(np.rint(c0 + rng.normal(0, 5, (n, 16, 4))), 0, 255).astype(np.uint8)
+    ph[n // 2:, :, 3] = 255
+    f["photo-like"] = ph
+    ca = rng.integers(0, 256, (n, 1, 4), dtype=np.uint8)
+    cb = rng.integers(0, 256, (n, 1, 4), dtype=np.uint8)
+    m = rng.integers(0, 2, (n, 16, 1)).astype(bool)
+    tc = np.where(m, ca, cb).astype(np.uint8)
+    tc[::2, :, 3] = 255
+    f["two colours"] = tc
+    pt = rng.integers(0, 256, (n, 16, 4), dtype=np.uint8)
+    pt[:, :, 3] = np.where(rng.integers(0, 2, (n, 16)) > 0, 255, 0)
+    f["punch-through alpha"] = pt
+    hi = rng.integers(0, 256, (n, 16, 4), dtype=np.uint8)
+    hi[:, :, 3] = rng.integers(248, 256, (n, 16))
+    f["alpha 248..255"] = hi
+    return f

@@ -128,11 +128,23 @@ const char *cvttmi_last_error(const cvttmi_context *ctx);
 int cvttmi_set_rcp_table(cvttmi_context *ctx, const float lut[17]);
 int cvttmi_get_rcp_table(const cvttmi_context *ctx, float lut[17]);
 
+/* Page-locked host memory.  The host-pointer entry points below (the ones the reference's own callers bind,
+ * ConvectionKernels.h:242-256 take host pointers) move caller buffers that are page-locked straight over PCIe, in
+ * chunks pipelined with the search; pageable buffers go through the context's staging buffers first (one extra CPU
+ * copy each way).  cvttmi_host_alloc / cvttmi_host_free give such memory; cvttmi_host_register / _unregister
+ * page-lock an existing allocation for as long as it is reused (registering costs about as much as one copy). */
+int cvttmi_host_alloc(cvttmi_context *ctx, void **ptr, size_t bytes);
+int cvttmi_host_free(cvttmi_context *ctx, void *ptr);
+int cvttmi_host_register(cvttmi_context *ctx, void *ptr, size_t bytes);
+int cvttmi_host_unregister(cvttmi_context *ctx, void *ptr);
+
 /* ---- device-resident entry points: d_blocks / d_out are HBM pointers on the context's
  * device; the launch is asynchronous on `hipStream` (a hipStream_t, NULL = default).
- * A context owns device work space that its BC7 and BC6H launches use (hand-over list, endpoint
- * history): calls on ONE context must be issued on one stream at a time; use a context per
- * stream to encode concurrently. ---- */
+ * Streams: a context owns ONE set of device work space (BC7 hand-over list and plan ring, BC6H endpoint
+ * history).  The library orders the launches itself -- a call on another stream than the context's previous call
+ * first makes its stream wait (hipStreamWaitEvent) for that call's launches -- and a mutex serialises the host side
+ * of concurrent calls, so any stream / thread mix is SAFE on one context; it is not concurrent: use one context per
+ * stream (or per worker thread, the reference's caller model, etc2packer.cpp:215-281) to overlap independent jobs. ---- */
 
 /* replaces cvtt::Kernels::EncodeBC7 (ConvectionKernels_API.cpp:41-54): numBlocks * 64 B
  * of PixelBlockU8 in, numBlocks * 16 B out. */

@@ -13,6 +13,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest` (no -m) on a machine without a GPU skips the gpu tests; `-m gpu` there still fails loudly (the
+    gpu_ctx fixture), so a GPU run can never pass on a silent skip."""
+    if config.getoption("-m"):
+        return
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no HIP device visible (select with -m gpu to make this an error)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     """The plain-C restatement (test infrastructure); built on demand with gcc."""

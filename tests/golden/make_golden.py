@@ -211,6 +211,25 @@ def main():
     if "--skip-images" in sys.argv:
         return
     plan = ref.default_plan()
+    if "--only-5b" in sys.argv:
+        # config 5b (BC7 16384^2, seed 5, Flags::Ultra = slow indexing + BC7_TrySingleColor): ~15 CPU-minutes on 8 cores,
+        # std::threads inside the shim; merged into the existing config_hashes.json
+        path = os.path.join(HERE, "config_hashes.json")
+        hashes = json.load(open(path))
+        assert hashes["rcp_hex"] == [int(x) for x in rcp.view(np.uint32)]
+        from convectionkernels_amd.api import Flags
+        ultra = pyref.make_options(flags=Flags.Ultra)  # ConvectionKernels.h:68
+        b = content.config_blocks(5, 16384, 16384)
+        out, done, secs = fast.encode_mt("bc7", b, ultra, plan, threads=os.cpu_count() or 8, budget_s=1e9, chunk_blocks=512)
+        assert done == b.shape[0]
+        hashes["config5b_bc7_16384_seed5_ultra"] = hashlib.sha256(out.tobytes()).hexdigest()
+        band = out.shape[0] // 4
+        hashes["config5b_band_hashes"] = [hashlib.sha256(out[i * band:(i + 1) * band].tobytes()).hexdigest() for i in range(4)]
+        np.save(os.path.join(HERE, "config5b_bc7_16384_seed5_ultra_head.npy"), out[:512])
+        print("config5b", hashes["config5b_bc7_16384_seed5_ultra"], "%.0f s" % secs, flush=True)
+        with open(path, "w") as f:
+            json.dump(hashes, f, indent=1)
+        return
     if "--only-big-images" in sys.argv:
         # configs 3, 4, 5 (BC6HU 4096^2, ETC2 RGBA 4096^2, BC7 16384^2): ~10 CPU-minutes on 8 cores;
         # merged into the existing config_hashes.json

@@ -1,0 +1,73 @@
+"""bench.py as the driver calls it (CPU side): `--gpus N` must never silently run a smaller job, the self-spawn path
+starts N ranks, and the N > 1 mode shards ONE image by block rows and gathers the packed blocks on rank 0.  The
+multi-rank rehearsal runs with --dry-run (gloo, a stand-in for the encoder: the product has no CPU path)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env.update(kw)
+    return env
+
+
+def _no_gpu():
+    import torch
+    return not torch.cuda.is_available()
+
+
+def test_gpus_2_without_gpus_fails_loudly():
+    import pytest
+    if not _no_gpu():
+        pytest.skip("a GPU is present")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "GPU" in p.stderr
+    assert '"n_gpus"' not in p.stdout  # no line that could be mistaken for a result
+
+
+def test_world_size_mismatch_is_refused():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--dry-run"], env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr and '"n_gpus"' not in p.stdout
+
+
+def test_one_gpu_without_gpu_fails_loudly():
+    import pytest
+    if not _no_gpu():
+        pytest.skip("a GPU is present")
+    p = subprocess.run([sys.executable, BENCH, "--steps", "1", "--warmup", "0", "--no-cpu", "--no-extra"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and '"value"' not in p.stdout
+
+
+def test_self_spawn_two_ranks_dry_run():
+    """python bench.py --gpus 2 (no launcher): two gloo ranks, one image sharded by block rows, gather on rank 0"""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--size", "256", "--steps", "3", "--warmup", "1"],
+                       env=_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["dry_run"] is True and r["value"] is None
+    assert r["scaling"] == "strong" and r["steps"] == 3 and r["warmup"] == 1
+    assert r["config"]["blocks_per_rank"] == [2048, 2048]
+    assert "gather" in r["config"]["exchange"] and "rank 0" in r["config"]["exchange"]
+    assert "BASELINE configs[4]" in r["config"]["workload"]
+    assert r["output_check"]["matches_single_process"] is True
+
+
+def test_three_ranks_ragged_shards_dry_run():
+    """64 block rows over 3 ranks: 21 / 21 / 22 rows, no padding, same gathered image"""
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                        "--master-port", "29741", BENCH, "--gpus", "3", "--dry-run", "--size", "256", "--steps", "2", "--warmup", "0"],
+                       env=_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 3 and r["config"]["blocks_per_rank"] == [21 * 64, 21 * 64, 22 * 64]
+    assert r["output_check"]["matches_single_process"] is True

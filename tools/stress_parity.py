@@ -20,27 +20,8 @@ yy, xx = np.divmod(np.arange(16), 4)
 
 
 def families(n):
-    f = {}
-    f["noise"] = rng.integers(0, 256, (n, 16, 4), dtype=np.uint8)
-    o = rng.integers(0, 256, (n, 16, 4), dtype=np.uint8); o[:, :, 3] = 255
-    f["opaque noise"] = o
-    c0 = rng.integers(0, 256, (n, 1, 4)).astype(np.float32)
-    dx = rng.normal(0, 10, (n, 1, 4)).astype(np.float32); dy = rng.normal(0, 10, (n, 1, 4)).astype(np.float32)
-    g = np.clip(np.rint(c0 + xx[None, :, None] * dx + yy[None, :, None] * dy), 0, 255).astype(np.uint8)
-    f["gradient rgba"] = g.copy()
-    g2 = g.copy(); g2[:, :, 3] = 255
-    f["gradient opaque"] = g2
-    ph = np.clip(np.rint(c0 + rng.normal(0, 5, (n, 16, 4))), 0, 255).astype(np.uint8); ph[n // 2:, :, 3] = 255
-    f["photo-like"] = ph
-    ca = rng.integers(0, 256, (n, 1, 4), dtype=np.uint8); cb = rng.integers(0, 256, (n, 1, 4), dtype=np.uint8)
-    m = rng.integers(0, 2, (n, 16, 1)).astype(bool)
-    tc = np.where(m, ca, cb).astype(np.uint8); tc[::2, :, 3] = 255
-    f["two colours"] = tc
-    pt = rng.integers(0, 256, (n, 16, 4), dtype=np.uint8); pt[:, :, 3] = np.where(rng.integers(0, 2, (n, 16)) > 0, 255, 0)
-    f["punch-through alpha"] = pt
-    hi = rng.integers(0, 256, (n, 16, 4), dtype=np.uint8); hi[:, :, 3] = rng.integers(248, 256, (n, 16))
-    f["alpha 248..255"] = hi
-    return f
+    from convectionkernels_amd import synth
+    return synth.content_families(n, SEED)
 
 
 def ref_parallel(fn, blocks, per_out, threads):
