@@ -223,6 +223,17 @@ def test_config5_full_size_hash(gpu_ctx):
     for i in range(4):
         assert hashlib.sha256(out[i * band:(i + 1) * band].tobytes()).hexdigest() == h["config5_band_hashes"][i], "band %d" % i
     assert hashlib.sha256(out.tobytes()).hexdigest() == h["config5_bc7_16384_seed5"]
+    # BASELINE config 5b: the same image with Flags::Ultra (slow indexing + BC7_TrySingleColor, ConvectionKernels.h:68)
+    if "config5b_bc7_16384_seed5_ultra" in h:
+        img = torch.from_numpy(synth.image_rgba8(5, 16384, 16384)).cuda()
+        out = gpu_ctx.encode_image("bc7", img, api.Options(flags=api.Flags.Ultra), api.BC7EncodingPlan())
+        torch.cuda.synchronize()
+        del img
+        out = out.cpu().numpy()
+        assert _diff(out[:512], np.load(os.path.join(GOLD, "config5b_bc7_16384_seed5_ultra_head.npy"))).size == 0
+        for i in range(4):
+            assert hashlib.sha256(out[i * band:(i + 1) * band].tobytes()).hexdigest() == h["config5b_band_hashes"][i], "5b band %d" % i
+        assert hashlib.sha256(out.tobytes()).hexdigest() == h["config5b_bc7_16384_seed5_ultra"]
 
 
 def test_arithmetic_contract(gpu_ctx):
