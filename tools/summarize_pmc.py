@@ -64,6 +64,13 @@ try:
                                                "bytes_corrected": (2 * fetch + write) * 1024}
 except Exception as e:  # noqa
     summary["traffic_error"] = str(e)
+# which kernel objects these counters belong to: bench.py quotes them only while the loaded library still holds the same ones
+try:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from convectionkernels_amd import api
+    summary["kernel_object_sha256"] = api.library_fatbin_sha256()
+except Exception as e:  # noqa
+    summary["kernel_object_error"] = str(e)
 json.dump(summary, open(os.path.join(out_dir, "summary.json"), "w"), indent=1)
 print(json.dumps(summary.get("pmc_sq", [{}])[0].get("derived", {}), indent=1))
 print(json.dumps(summary.get("hbm_traffic_bytes_per_launch", {})))
