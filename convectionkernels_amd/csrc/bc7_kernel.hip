@@ -72,6 +72,14 @@ constexpr float kBoundGrid8 = 124.0f, kBoundLimit8 = 127.0f;
 // Developer-only phase profile (-DCVTT_BC7_PROFILE): wave cycles per phase, summed over waves.
 #ifdef CVTT_BC7_PROFILE
 __device__ unsigned long long g_bc7Prof[48];
+__device__ unsigned long long g_bc7Dup[8]; // chain rounds: total, same endpoints as a lower seed point this round, seen in an earlier round of the group
+extern "C" int cvttmi_bc7_dup_read(unsigned long long *out)
+{
+    unsigned long long zero[8] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bc7Dup), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bc7Dup), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
 #define PROF_DECL unsigned long long profT = __builtin_readcyclecounter(); unsigned long long profAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long profCnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define PROF_MARK(slot) { const unsigned long long now = __builtin_readcyclecounter(); profAcc[slot] += now - profT; profT = now; }
 #define PROF_FLUSH if (threadIdx.x == 0) { unsigned long long tot = 0; for (int i = 0; i < 8; i++) { atomicAdd(&g_bc7Prof[i], profAcc[i]); tot += profAcc[i]; } \
@@ -223,6 +231,9 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
     best.idxLo = best.idxHi = 0;
     if (!active)
         mask = 0;
+#ifdef CVTT_BC7_PROFILE
+    u32 profHist[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+#endif
 
     // static alpha error of RGB modes (reference BC67.cpp:1250-1264); zero on opaque blocks
     float staticAlphaError = 0.0f;
@@ -263,6 +274,34 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
     {
         const bool last = (refine == numRefine - 1);
         compressEndpoints(md, ep, pIter, isRGB);
+#ifdef CVTT_BC7_PROFILE
+        {
+            const u32 k0 = packEP(ep[0]), k1 = packEP(ep[1]);
+            const int ln = (int)threadIdx.x;
+            bool dupNow = false, dupOld = false;
+            for (int o = 0; o < 4; o++)
+            {
+                const int src = (ln & ~3) | o;
+                const u32 a0 = __shfl(k0, src), a1 = __shfl(k1, src);
+                const bool oAct = __shfl((int)active, src) != 0;
+                if (oAct && o < (ln & 3) && a0 == k0 && a1 == k1) dupNow = true;
+                for (int h = 0; h < refine && h < 4; h++)
+                {
+                    const u32 b0 = __shfl(profHist[h][0], src), b1 = __shfl(profHist[h][1], src);
+                    if (oAct && b0 == k0 && b1 == k1) dupOld = true;
+                }
+            }
+            if (refine < 4) { profHist[refine][0] = k0; profHist[refine][1] = k1; }
+            const u64 mA = __ballot(active), mN = __ballot(active && dupNow), mO = __ballot(active && !dupNow && dupOld);
+            if (ln == 0)
+            {
+                atomicAdd(&g_bc7Dup[0], (unsigned long long)__popcll(mA));
+                atomicAdd(&g_bc7Dup[1], (unsigned long long)__popcll(mN));
+                atomicAdd(&g_bc7Dup[2], (unsigned long long)__popcll(mO));
+                atomicAdd(&g_bc7Dup[3 + (refine < 3 ? refine : 3)], (unsigned long long)__popcll(mN | mO));
+            }
+        }
+#endif
 
         // IndexSelector<4>::Init (reference IndexSelector.h:27-77)
         float origin[4], axis[4];
@@ -2540,6 +2579,34 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             __syncthreads();
 
             // ---- PCA seed search: lane l takes unit l = (item, subset) ----
+            // The chain lanes of a batch walk the member pixels of their subsets in lock-step, i.e. as many steps as the
+            // largest subset of the batch has pixels: the units are therefore filed in ascending order of their pixel
+            // counts (a counting sort on ballots), so that a batch holds subsets of (nearly) one size.  Results are routed
+            // by UnitRec::slot, so the order of the units is free.  (The punch-through replay indexes units by item.)
+            int unitPos = lane;
+            {
+                int cnt = 0;
+                if (lane < numUnits && numSubsets >= 2 && !ptStage)
+                {
+                    const int item = (numSubsets == 2) ? (lane >> 1) : (lane / 3);
+                    const int sub = lane - item * numSubsets;
+                    const int upart = (int)(s_item[item] >> 8);
+                    cnt = __popc(T->shapeMask[(numSubsets == 2) ? T->shapes2[upart][sub] : T->shapes3[upart][sub]]);
+                }
+                if (numSubsets >= 2 && !ptStage)
+                {
+                    int base = 0;
+                    for (int v = 1; v < 16; v++)
+                    {
+                        const u64 m = __ballot(cnt == v);
+                        if (m == 0)
+                            continue;
+                        if (cnt == v)
+                            unitPos = base + (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                        base += __popcll(m);
+                    }
+                }
+            }
             if (lane < numUnits)
             {
                 const int item = (numSubsets == 1) ? lane : (numSubsets == 2) ? (lane >> 1) : (lane / 3);
@@ -2586,7 +2653,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 }
                 if (do4)
                     pcaEndpointsLDS<4>(lp, uMask, A.w, uu);
-                UnitRec &r = s_unit[lane];
+                UnitRec &r = s_unit[unitPos];
 #pragma unroll
                 for (int ch = 0; ch < 4; ch++)
                 {
