@@ -1013,7 +1013,16 @@ __device__ __forceinline__ u32 nibblesOf(u32 b4)
 // are the reference's operation for operation; the integer error sum(rec - px)^2 is evaluated per channel as
 // sum(rec^2) - 2 sum(rec * px) + sum(px^2) with the reconstructed bytes looked up by v_perm_b32 from the level table
 // and the sums taken by v_dot4_u32_u8 over four pixels at a time -- integers, so the result is the same number.
-__device__ __forceinline__ void evalDualFast(const u32 (&P)[4][4], int mode, int indexSelector, const Unfinished &uRGB,
+// Invariants of the block in rotated channel order (DualInv): sum(px^2) per channel, min / max of the separately coded
+// channel, and the refiner's sums of the pre-weighted pixels sum(x * w) -- ContributeUnweightedPW adds the same 16 values
+// in the same order whatever the indexes are (EndpointRefiner.h:78-92), so the sum is taken once per block.
+struct DualInv
+{
+    u32 sumSq[4];
+    int alphaMin, alphaMax;
+    float vs[4]; // [3]: the separately coded channel, weight 1
+};
+__device__ __forceinline__ void evalDualFast(const u32 (&P)[4][4], const DualInv &inv, int mode, int indexSelector, const Unfinished &uRGB,
                                              int numTweak, const float (&rw)[4], const float (&rwSq)[4],
                                              const float (&rrcpW)[4], u32 flags, const CvttDeviceTables *__restrict__ T,
                                              int numRefine, int lane, ShapeBest &bestRGB, ShapeBest &bestA)
@@ -1036,23 +1045,7 @@ __device__ __forceinline__ void evalDualFast(const u32 (&P)[4][4], int mode, int
     bestRGB.ep0 = bestRGB.ep1 = bestRGB.idxLo = bestRGB.idxHi = 0;
     bestA.ep0 = bestA.ep1 = bestA.idxLo = bestA.idxHi = 0;
 
-    // min / max of the separately coded channel and sum(px^2) per channel
-    int alphaMin = 255, alphaMax = 0;
-    u32 sumSq[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-    {
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-        {
-            const int a = byteI(P[3][g], k);
-            alphaMin = a < alphaMin ? a : alphaMin;
-            alphaMax = a > alphaMax ? a : alphaMax;
-        }
-#pragma unroll
-        for (int ch = 0; ch < 4; ch++)
-            sumSq[ch] = __builtin_amdgcn_udot4(P[ch][g], P[ch][g], sumSq[ch], false);
-    }
+    const int alphaMin = inv.alphaMin, alphaMax = inv.alphaMax;
 
     const int tweak = c;
     if (tweak < numTweak)
@@ -1125,7 +1118,7 @@ __device__ __forceinline__ void evalDualFast(const u32 (&P)[4][4], int mode, int
             const v2f rcpMax2 = {rgbRcpMax, alphaRcpMax};
 
             u32 s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-            v2f tv01 = {0.0f, 0.0f}, tv23 = {0.0f, 0.0f}, vs01 = {0.0f, 0.0f}, vs23 = {0.0f, 0.0f};
+            v2f tv01 = {0.0f, 0.0f}, tv23 = {0.0f, 0.0f};
             v2f tt2 = {0.0f, 0.0f}, ts2 = {0.0f, 0.0f}; // {RGB plane, alpha plane}
             u32 rgbLo = 0, rgbHi = 0, aLo = 0, aHi = 0; // 4 bits per pixel
 
@@ -1144,19 +1137,19 @@ __device__ __forceinline__ void evalDualFast(const u32 (&P)[4][4], int mode, int
                     dist = dist + p23.x;
                     const float fRGB = clampRound(dist, rgbMax);
                     const float fA = clampRound(p23.y, alphaMaxV);
-                    iR4 |= (u32)(int)fRGB << (8 * k);
-                    iA4 |= (u32)(int)fA << (8 * k);
+                    // the indexes are small integers: v_cvt_pk_u8_f32 converts and files one as byte k in one instruction
+                    iR4 = __builtin_amdgcn_cvt_pk_u8_f32(fRGB, (u32)k, iR4);
+                    iA4 = __builtin_amdgcn_cvt_pk_u8_f32(fA, (u32)k, iA4);
                     if (!last)
                     {
-                        // EndpointRefiner<3> with the rotated weights and EndpointRefiner<1> with weight 1
+                        // EndpointRefiner<3> with the rotated weights and EndpointRefiner<1> with weight 1; the sums of the
+                        // pre-weighted pixels themselves (vs) do not depend on the indexes: DualInv
                         const v2f f2 = {fRGB, fA};
                         const v2f t2 = f2 * rcpMax2;
                         const v2f tt = {t2.x, t2.x};
                         const v2f v01 = x01 * w01, v23 = x23 * w23;
                         tv01 = tv01 + tt * v01;
                         tv23 = tv23 + t2 * v23;
-                        vs01 = vs01 + v01;
-                        vs23 = vs23 + v23;
                         tt2 = tt2 + t2 * t2;
                         ts2 = ts2 + t2;
                     }
@@ -1183,7 +1176,7 @@ __device__ __forceinline__ void evalDualFast(const u32 (&P)[4][4], int mode, int
             u32 err[4];
 #pragma unroll
             for (int ch = 0; ch < 4; ch++)
-                err[ch] = s2[ch] + sumSq[ch] - 2u * s1[ch];
+                err[ch] = s2[ch] + inv.sumSq[ch] - 2u * s1[ch];
             float errorRGB, errorA;
             if (uniformErr)
             {
@@ -1218,7 +1211,7 @@ __device__ __forceinline__ void evalDualFast(const u32 (&P)[4][4], int mode, int
             if (!last)
             {
                 // EndpointRefiner<3> / <1>::GetRefinedEndpointsLDR, 16 contributions each
-                const float tv[4] = {tv01.x, tv01.y, tv23.x, tv23.y}, vs[4] = {vs01.x, vs01.y, vs23.x, vs23.y};
+                const float tv[4] = {tv01.x, tv01.y, tv23.x, tv23.y}, vs[4] = {inv.vs[0], inv.vs[1], inv.vs[2], inv.vs[3]};
                 {
                     const float ttRGB = tt2.x, tsRGB = ts2.x;
                     float adenom = (ttRGB * 16.0f - tsRGB * tsRGB) * wRcp16;
@@ -2072,7 +2065,44 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 P[3][g] = __builtin_amdgcn_perm(cd13, ab13, 0x07060302u);
             }
         }
+        // what every configuration of a rotation would otherwise recompute (DualInv), per original channel: sub-lane ch
+        // takes channel ch and parks the five values in rows 1..20 of s_bound, which is idle until the partition bounds
+        // (row 0 holds the mode-6 bound); a step then reads the rows its rotation needs instead of holding 20 registers
+        if (FAST)
+        {
+            u32 mine[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                mine[g] = (c == 0) ? P[0][g] : (c == 1) ? P[1][g] : (c == 2) ? P[2][g] : P[3][g];
+            const float wc = (c == 0) ? A.w[0] : (c == 1) ? A.w[1] : (c == 2) ? A.w[2] : A.w[3];
+            u32 sq = 0, su = 0;
+            int mn = 255, mx = 0;
+            float sw = 0.0f; // sum of x * w in pixel order: the refiner's m_v
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+            {
+                sq = __builtin_amdgcn_udot4(mine[g], mine[g], sq, false);
+                su = __builtin_amdgcn_udot4(mine[g], 0x01010101u, su, false);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const int a = byteI(mine[g], k);
+                    mn = a < mn ? a : mn;
+                    mx = a > mx ? a : mx;
+                    sw = sw + byteF(mine[g], k) * wc;
+                }
+            }
+            s_bound[1 + c][lane >> 2] = __builtin_bit_cast(float, sq);
+            s_bound[5 + c][lane >> 2] = __builtin_bit_cast(float, (u32)mn | ((u32)mx << 8));
+            s_bound[9 + c][lane >> 2] = sw;
+            s_bound[13 + c][lane >> 2] = (float)(int)su; // exact
+            __syncthreads();
+        }
         int curRotation = 0;
+#ifdef CVTT_BC7_PROFILE
+        float simKey[12], simErr[12];
+        int simN = 0;
+#endif
         for (int step = 0; step < 12; step++)
         {
             const int slot = step / 3, which = step - slot * 3;
@@ -2151,7 +2181,25 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             quadBroadcast(u, uRot, lane, rotation);
             ShapeBest b, bA;
             if (FAST)
-                evalDualFast(P, mode, indexSelector, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
+            {
+                DualInv inv;
+                const int sepCh = (rotation == 0) ? 3 : rotation - 1; // the original channel that is coded on its own
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    const int orig = (rotation == ch + 1) ? 3 : ch;
+                    inv.sumSq[ch] = __builtin_bit_cast(u32, s_bound[1 + orig][lane >> 2]);
+                    inv.vs[ch] = s_bound[9 + orig][lane >> 2];
+                }
+                inv.sumSq[3] = __builtin_bit_cast(u32, s_bound[1 + sepCh][lane >> 2]);
+                inv.vs[3] = s_bound[13 + sepCh][lane >> 2];
+                {
+                    const u32 mm = __builtin_bit_cast(u32, s_bound[5 + sepCh][lane >> 2]);
+                    inv.alphaMin = (int)(mm & 0xffu);
+                    inv.alphaMax = (int)(mm >> 8);
+                }
+                evalDualFast(P, inv, mode, indexSelector, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
+            }
             else
                 evalDual<FAST>(pix, mode, indexSelector, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
 
@@ -2170,7 +2218,12 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 const float lbp = (rotation == 0) ? lbRot[0] : (rotation == 1) ? lbRot[1] : (rotation == 2) ? lbRot[2] : lbRot[3];
                 const bool needed = valid && c == 0 && !(lbp > work.err);
                 PROF_COUNT(6, (needed && (bA.err + lbp > work.err)) ? 1 : 0)
-                PROF_COUNT(7, (needed && combined < work.err) ? 1 : 0)
+                if (needed && simN < 12)
+                {
+                    simKey[simN] = lbp + bA.err;
+                    simErr[simN] = combined;
+                    simN++;
+                }
             }
 #endif
             if (combined < work.err || (combined == work.err && seq < workSeq))
@@ -2199,6 +2252,31 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 }
             }
         }
+#ifdef CVTT_BC7_PROFILE
+        {
+            // how many colour planes an alpha-plane-first, best-key-first order would have to evaluate
+            float best = FLT_MAX;
+            int evald = 0;
+            u32 left = (1u << simN) - 1u;
+            while (left)
+            {
+                int pick = -1;
+                float pk = FLT_MAX;
+                for (int i = 0; i < 12; i++)
+                    if (((left >> i) & 1u) && (pick < 0 || simKey[i] < pk))
+                    {
+                        pick = i;
+                        pk = simKey[i];
+                    }
+                if (pk > best)
+                    break;
+                evald++;
+                best = simErr[pick] < best ? simErr[pick] : best;
+                left &= ~(1u << pick);
+            }
+            PROF_COUNT(7, evald)
+        }
+#endif
         if (!FAST && curRotation != 0)
         {
 #pragma unroll

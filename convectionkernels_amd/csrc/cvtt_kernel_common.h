@@ -326,11 +326,14 @@ __device__ __forceinline__ float shapeErrorLowerBound(const Moments<N> &m, float
             }
             t4 = __fmaf_rn((i == j ? 1.0f : 2.0f) * e, e, t4);
         }
-    // v_sqrt_f32 is accurate to 1 ulp; the 1e-4 margins cover it
+    // v_sqrt_f32 is accurate to 1 ulp; the 1e-4 margins cover it ("Soundness of the bounds": the computed
+    // lambdaUp exceeds lambda_max by at least 0.98e-4 * lambda_max, every rounding of S, of the trace and of this function
+    // moves r by less than 2e-6 * lambda_max, and `delta` carries its own 1e-6 margin for the sqrt / products below)
     const float lambdaUp = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(t4)) * 1.0001f;
     const float r = trace - lambdaUp;
     float lb = 0.0f;
-    if (r > n * delta * delta)
+    // t4 below 1e-30 (lambda_max < 2e-8: absurdly small channel weights) would be summed from denormal products: no bound
+    if (r > n * delta * delta && t4 > 1e-30f)
         lb = (r - 2.0f * delta * __builtin_amdgcn_sqrtf(n * r)) * 0.9999f;
     return lb > 0.0f ? lb : 0.0f; // NaN / inf inputs end up as "no bound"
 }

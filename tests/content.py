@@ -274,3 +274,76 @@ def dark_blocks(seed, n):
     b[m] = rng.integers(0, 256, (int(m.sum()), 4)); b[..., 3] = rng.integers(0, 2, (n, 16)) * 255; fam.append(b)
     b = rng.integers(0, 256, (n, 1, 4)).astype(np.uint8).repeat(16, 1); b[::3, ::2, :3] = 0; b[..., 3] = 255; fam.append(b)
     return np.concatenate(fam)
+
+
+def adversarial_bound_blocks(seed, n):
+    """(n,16,4) uint8, n a multiple of 64: content built to sit ON the edges of the BC7 branch-and-bound (DESIGN.md 4.1,
+    "soundness of the bounds"): subsets whose scatter matrix has rank one (trace == lambda_max: the bound's subtraction
+    cancels), the same with +-1 LSB noise (residual of the order of the rounding allowance n*delta^2, where the bound
+    switches on), with perpendicular noise of growing amplitude (the bound crosses the best error somewhere on the way),
+    two-colour blocks (every subset collinear), two lines split by a random mask, flat blocks with one outlier, and
+    their opaque / constant-alpha / binary-alpha / alpha-on-the-line variants.  Families change every 8 blocks and one
+    group in eight mixes them, so the group-wide booleans (BC67.cpp:1069, 1072) see every combination."""
+    assert n % 64 == 0
+    rng = _rng(seed)
+    k = np.arange(16)
+
+    def line(m, amp_perp=0, lsb=0.0):
+        c0 = rng.integers(0, 256, (m, 1, 4)).astype(np.float64)
+        d = rng.integers(-12, 13, (m, 1, 4)).astype(np.float64)
+        t = rng.permuted(np.tile(np.arange(16), (m, 1)), axis=1)[:, :, None] - 7.5
+        v = c0 + d * t
+        if amp_perp:
+            v = v + rng.integers(-amp_perp, amp_perp + 1, (m, 16, 4))
+        if lsb:
+            v = v + (rng.random((m, 16, 4)) < lsb) * rng.choice(np.array([-1, 1]), (m, 16, 4))
+        return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+    def two_colour(m, lsb=0.0):
+        a = rng.integers(0, 256, (m, 1, 4))
+        b = rng.integers(0, 256, (m, 1, 4))
+        mask = rng.integers(0, 2, (m, 16, 1)).astype(bool)
+        v = np.where(mask, a, b).astype(np.float64)
+        if lsb:
+            v = v + (rng.random((m, 16, 4)) < lsb) * rng.choice(np.array([-1, 1]), (m, 16, 4))
+        return np.clip(v, 0, 255).astype(np.uint8)
+
+    def two_lines(m, amp=0):
+        a, b = line(m, amp), line(m, amp)
+        mask = rng.integers(0, 2, (m, 16, 1)).astype(bool)
+        return np.where(mask, a, b)
+
+    def flat_outlier(m):
+        v = rng.integers(0, 256, (m, 1, 4)).repeat(16, 1)
+        px = rng.integers(0, 16, m)
+        v[np.arange(m), px] = rng.integers(0, 256, (m, 4))
+        return v.astype(np.uint8)
+
+    makers = [lambda m: line(m), lambda m: line(m, lsb=0.1), lambda m: line(m, lsb=0.5), lambda m: line(m, 1), lambda m: line(m, 2),
+              lambda m: line(m, 3), lambda m: line(m, 4), lambda m: line(m, 6), lambda m: line(m, 8), lambda m: line(m, 12),
+              lambda m: two_colour(m), lambda m: two_colour(m, 0.1), lambda m: two_colour(m, 0.5), lambda m: two_lines(m),
+              lambda m: two_lines(m, 1), lambda m: two_lines(m, 3), lambda m: flat_outlier(m)]
+    groups = n // 8
+    per = -(-groups // len(makers))
+    fam = np.concatenate([mk(per * 8).reshape(per, 8, 16, 4) for mk in makers])   # (len*per, 8, 16, 4), family-major
+    order = rng.permutation(fam.shape[0])[:groups]
+    out = fam[order].copy()
+    # one group in eight: every block from a different family
+    mixed = np.arange(groups) % 8 == 7
+    flatf = fam.reshape(-1, 16, 4)
+    out[mixed] = flatf[rng.integers(0, flatf.shape[0], (int(mixed.sum()), 8))]
+    out = out.reshape(groups * 8, 16, 4)
+    # alpha variants per group: as generated / opaque / constant / binary / 250-255 (the allowRGBModes threshold)
+    av = rng.integers(0, 5, groups).repeat(8)
+    out[av == 1, :, 3] = 255
+    c = rng.integers(0, 255, groups * 8)
+    sel = av == 2
+    out[sel, :, 3] = c[sel, None]
+    sel = av == 3
+    out[sel, :, 3] = rng.integers(0, 2, (int(sel.sum()), 16)) * 255
+    sel = av == 4
+    out[sel, :, 3] = rng.integers(250, 256, (int(sel.sum()), 16))
+    # inside an opaque group, one block in 16 gets a single translucent pixel (a block can be opaque in an alpha group)
+    one = (av == 1) & (rng.integers(0, 16, groups * 8) == 0)
+    out[one, 5, 3] = 200
+    return np.ascontiguousarray(out.astype(np.uint8))

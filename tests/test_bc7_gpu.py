@@ -91,6 +91,38 @@ def test_pruned_equals_exhaustive(gpu_ctx):
         gpu_ctx.set_exhaustive(False)
 
 
+def test_bounds_adversarial_content(gpu_ctx, oracle_lib):
+    """Soundness of the branch-and-bound on content built to sit on its edges (content.adversarial_bound_blocks:
+    rank-one scatter matrices, residuals of the order of the rounding allowance, two-colour and two-line blocks, +-1 LSB
+    noise, every alpha variant): pruned == exhaustive on 2^20 blocks with the default options and on 2^17 blocks for slow
+    indexing, the uniform metric, skewed weights and the single-colour flag; == the CPU oracle on the first 2^15."""
+    import torch
+    api = _api()
+    rcp = oracle_lib.probe_rcp()
+    gpu_ctx.set_rcp_table(rcp)
+    blocks = content.adversarial_bound_blocks(20260929, 1 << 20)
+    t = torch.from_numpy(blocks).cuda()
+    plan = api.BC7EncodingPlan()
+    try:
+        cases = [(api.Options(), 1 << 20), (api.Options(flags=api.Flags.Better), 1 << 17), (api.Options(flags=api.Flags.Default | api.Flags.Uniform), 1 << 17),
+                 (api.Options(redWeight=3.0, greenWeight=0.25, blueWeight=1.5, alphaWeight=0.1), 1 << 17), (api.Options(flags=api.Flags.Ultra), 1 << 16)]
+        for i, (opt, n) in enumerate(cases):
+            gpu_ctx.set_exhaustive(False)
+            a = gpu_ctx.encode_bc7(t[:n], opt, plan).cpu().numpy()
+            gpu_ctx.set_exhaustive(True)
+            b = gpu_ctx.encode_bc7(t[:n], opt, plan).cpu().numpy()
+            bad = _diff(a, b)
+            assert bad.size == 0, "case %d: pruned != exhaustive at blocks %s" % (i, bad[:8])
+            if i == 0:
+                m = 1 << 15
+                exp = oracle_lib.encode_bc7(blocks[:m], np.frombuffer(opt.tobytes(), np.uint8).copy(),
+                                            np.frombuffer(plan.tobytes(), np.uint8).copy(), rcp, threads=16)
+                bad = _diff(a[:m], exp)
+                assert bad.size == 0, "pruned != oracle at blocks %s" % bad[:8]
+    finally:
+        gpu_ctx.set_exhaustive(False)
+
+
 def test_device_tensor_path_and_ragged_sizes(gpu_ctx, oracle_lib):
     import torch
     api = _api()

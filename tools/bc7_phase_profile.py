@@ -24,6 +24,6 @@ for exhaustive in (False, True):
     print("   wave-cycle histogram (log2 buckets from 2^12):", list(buf[16:32]))
     print("   dual configs: quad-evaluations executed", buf[32], "needed by the block itself", buf[33],
           "| single-plane shapes: executed", buf[34], "needed", buf[35])
-    print("   dual configs an exact alpha-plane error would have pruned:", buf[38], "| that improved the block's best:", buf[39])
+    print("   dual configs an exact alpha-plane error would have pruned:", buf[38], "| colour planes an alpha-first, best-key-first order would evaluate:", buf[39])
     print("   waves by number of single-plane chain passes (log2 buckets 1, 2-3, 4-7, ... >=128):", list(buf[40:48]))
     print("   candidate partitions alive at stage start (all stages):", buf[36], "block-stages:", buf[37])
