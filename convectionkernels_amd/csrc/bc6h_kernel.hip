@@ -55,8 +55,12 @@ namespace
 //         written once per round, read only by the legality pass / at a commit
 constexpr int kEpqBase = 0, kMetaDwords = 36; // the 24 per-round errors live in registers (uniform dynamic index)
 constexpr int kScrEpq0 = 0, kScrIdx = 36, kScratchDwords = 84;
+// Waves per SIMD the register allocator must leave room for.  4 (128 VGPRs, 48 dwords of spill) instead of 3 (149, no
+// spill) measures +3.5 %: the shim feeds the kernel 2^18 blocks = 4 096 waves = 4 per SIMD at a time, which 3 slots take
+// in two rounds (3 + 1), and gfx950 overlaps the plain f32 instructions of an EVEN number of resident waves
+// (profiles/r02/valu_order.txt).
 #ifndef CVTT_BC6H_WAVES
-#define CVTT_BC6H_WAVES 3
+#define CVTT_BC6H_WAVES 4
 #endif
 
 __device__ __forceinline__ float divRoundUp(float a, float b)

@@ -34,6 +34,7 @@
 #include <stdint.h>
 #include <float.h>
 #include <type_traits>
+#include <stdlib.h>
 
 #include "cvtt_device.h"
 
@@ -54,6 +55,10 @@ constexpr float kBoundGrid8 = 124.0f, kBoundLimit8 = 127.0f;
 // minimum waves per SIMD the register allocator must leave room for (512 VGPR+AGPR / waves)
 #ifndef CVTT_BC7_WAVES
 #define CVTT_BC7_WAVES 3
+#endif
+// power iterations per principal axis of the projection the first-tier bounds are taken in (tightness only, never validity)
+#ifndef CVTT_EIG_ITERS
+#define CVTT_EIG_ITERS 6
 #endif
 
 #include "cvtt_kernel_common.h"
@@ -1506,7 +1511,7 @@ __device__ __forceinline__ void topEigenvector(const float (&M)[10], float (&e)[
 #pragma unroll
     for (int i = 0; i < 4; i++)
         v[i] = (k == 0) ? M[tri(i, 0)] : (k == 1) ? M[tri(i, 1)] : (k == 2) ? M[tri(i, 2)] : M[tri(i, 3)];
-    for (int it = 0; it < 6; it++)
+    for (int it = 0; it < CVTT_EIG_ITERS; it++)
     {
         float nv[4];
         float big = 0.0f;
@@ -3289,7 +3294,9 @@ extern "C" hipError_t cvttmi_launch_bc7(const void *d_blocks, void *d_out, const
         return hipSuccess;
     const bool fast = (args->flags & CVTTMI_FLAG_BC7_FAST_INDEXING) != 0;
     const bool pt = (args->flags & CVTTMI_FLAG_BC7_RESPECT_PUNCHTHROUGH) != 0;
-#define CVTT_LAUNCH(F, P, H, GRID) hipLaunchKernelGGL((cvttmi_bc7_kernel<F, P, H>), dim3(GRID), dim3(64), 0, stream, (const uint8_t *)d_blocks, (uint8_t *)d_out, *args, d_tables, d_plan)
+    // developer knob: extra (unused) dynamic LDS per workgroup, to pin the number of resident waves per SIMD in experiments
+    static const unsigned ldsPad = getenv("CVTTMI_BC7_LDS_PAD") ? (unsigned)atoi(getenv("CVTTMI_BC7_LDS_PAD")) : 0u;
+#define CVTT_LAUNCH(F, P, H, GRID) hipLaunchKernelGGL((cvttmi_bc7_kernel<F, P, H>), dim3(GRID), dim3(64), (H) ? 0u : ldsPad, stream, (const uint8_t *)d_blocks, (uint8_t *)d_out, *args, d_tables, d_plan)
     if (pt)
     {
         if (fast) CVTT_LAUNCH(true, true, false, waves); else CVTT_LAUNCH(false, true, false, waves);

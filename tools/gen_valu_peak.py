@@ -146,6 +146,28 @@ for _nx, _tx in [("add_u32", "v_add_u32 %0, %0, %[b]"), ("mul_f32", "v_mul_f32 %
                  ("cvt_ub0", "v_cvt_f32_ubyte0 %0, %0"), ("rcp", "v_rcp_f32 %0, %0"), ("dpp", "v_mov_b32_dpp %0, %0 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf")]:
     MIX.append(("dep1:%s" % _nx, [_tx]))
 
+# does the ORDER of a wave's instructions matter?  The same multiset of 64 instructions, clustered by kind (what a compiler
+# emits for an unrolled loop) and interleaved (a plain f32 instruction between any two of another kind)
+_CVT, _MUL, _ADD, _SUB = "v_cvt_f32_ubyte0 %{k}, %{k}", "v_mul_f32 %{k}, %{k}, %[c]", "v_add_f32 %{k}, %{k}, %[c]", "v_sub_f32 %{k}, %{k}, %[c]"
+_MIN, _MAX, _RND, _CVI = "v_min_f32 %{k}, %{k}, %[c]", "v_max_f32 %{k}, %{k}, %[c]", "v_rndne_f32 %{k}, %{k}", "v_cvt_i32_f32 %{k}, %{k}"
+_DOT, _PRM = "v_dot4_u32_u8 %{k}, %[b], %[c], %{k}", "v_perm_b32 %{k}, %{k}, %[b], %[c]"
+MIX.append(("seq:32cvt_then_32mul", [_CVT] * 32 + [_MUL] * 32))
+MIX.append(("seq:8cvt_8mul_x4", ([_CVT] * 8 + [_MUL] * 8) * 4))
+MIX.append(("seq:4cvt_4mul_x8", ([_CVT] * 4 + [_MUL] * 4) * 8))
+MIX.append(("seq:2cvt_2mul_x16", ([_CVT] * 2 + [_MUL] * 2) * 16))
+MIX.append(("seq:1cvt_3mul_x16", ([_CVT] + [_MUL] * 3) * 16))
+MIX.append(("seq:4cvt_12mul_x4", ([_CVT] * 4 + [_MUL] * 12) * 4))
+MIX.append(("seq:16cvt_48mul", [_CVT] * 16 + [_MUL] * 48))
+# the pixel step of the BC7 dual-plane search (bc7_kernel.hip evalDualFast), 1.6 pixels: as compiled, and interleaved
+_PIX = [_CVT] * 4 + [_SUB] * 4 + [_MUL] * 4 + [_ADD] * 3 + [_MIN, _MAX, _RND, _MIN, _MAX, _RND] + [_MUL] * 11 + [_ADD] * 7 + [_CVI] * 1
+_PIXI = [_CVT, _SUB, _MUL, _ADD, _CVT, _SUB, _MUL, _ADD, _CVT, _SUB, _MUL, _ADD, _CVT, _SUB, _MUL, _MUL, _MIN, _MUL, _MAX, _MUL, _RND, _MUL, _MIN,
+         _MUL, _MAX, _MUL, _RND, _MUL, _CVI, _MUL, _ADD, _MUL, _ADD, _MUL, _ADD, _MUL, _ADD, _ADD, _ADD, _ADD]
+assert sorted(_PIX) == sorted(_PIXI) and len(_PIX) == 40
+MIX.append(("seq:pixel_as_compiled", (_PIX * 2)[:64]))
+MIX.append(("seq:pixel_interleaved", (_PIXI * 2)[:64]))
+MIX.append(("seq:dot4_perm_block_then_mul", [_PRM] * 8 + [_DOT] * 16 + [_MUL] * 40))
+MIX.append(("seq:dot4_perm_spread_in_mul", ([_DOT, _MUL, _MUL, _PRM, _MUL, _DOT, _MUL, _MUL] * 8)))
+
 OPS64 = [
     ("v_pk_mul_f32", "v_pk_mul_f32 %{k}, %{k}, %[b]"),
     ("v_pk_add_f32", "v_pk_add_f32 %{k}, %{k}, %[b]"),
@@ -248,12 +270,12 @@ int main(int argc, char **argv)
     hipEvent_t ev0, ev1;
     CHECK(hipEventCreate(&ev0));
     CHECK(hipEventCreate(&ev1));
-    const int wlist[4] = {1, 2, 4, 8};
+    const int wlist[5] = {1, 2, 3, 4, 8};
     for (int op = 0; op < OP_COUNT; op++)
     {
         if (onlyOp >= 0 && op != onlyOp)
             continue;
-        for (int wi = 0; wi < 4; wi++)
+        for (int wi = 0; wi < 5; wi++)
         {
             const int W = wlist[wi];
             if (onlyW && W != onlyW)

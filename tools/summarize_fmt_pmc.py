@@ -35,6 +35,20 @@ for d in sorted(glob.glob(os.path.join(out_dir, "pmc_*"))):
                             "cycles_per_valu_inst": c["SQ_ACTIVE_INST_VALU"] * 4 / c["SQ_INSTS_VALU"]}
         except Exception as ex:  # noqa
             e["derived_error"] = str(ex)
+    # second pass: LDS / memory instruction counters of the same kernel
+    f2 = glob.glob(os.path.join(out_dir, "pmc2_" + fmt, "*counter_collection.csv"))
+    if f2:
+        d2 = {}
+        for r in csv.DictReader(open(f2[0])):
+            if "cvttmi" not in r["Kernel_Name"]:
+                continue
+            e2 = d2.setdefault((r["Kernel_Name"].split("(")[0], r["Dispatch_Id"]), {})
+            e2[r["Counter_Name"]] = e2.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        for (kname, _), c2 in d2.items():
+            if kname in last:
+                waves = last[kname]["grid"] / 64
+                last[kname]["mem"] = {k: round(v / waves, 1) for k, v in c2.items()}
+                last[kname]["mem_note"] = "per wave"
     summary[fmt] = list(last.values())
     st = glob.glob(os.path.join(out_dir, "trace_" + fmt, "*kernel_stats.csv"))
     if st:
