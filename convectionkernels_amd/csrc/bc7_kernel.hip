@@ -1786,6 +1786,17 @@ __device__ __forceinline__ float subsetBound2D(const Sums2D &m, float invScaleSq
 
 } // namespace
 
+// bit k of the result = bit 4k + c of m: the partitions sub-lane c of a quad looks after
+__device__ __forceinline__ u32 everyFourth(u64 m, int c)
+{
+    u64 x = (m >> c) & 0x1111111111111111ull;
+    x = (x | (x >> 3)) & 0x0303030303030303ull;
+    x = (x | (x >> 6)) & 0x000f000f000f000full;
+    x = (x | (x >> 12)) & 0x000000ff000000ffull;
+    x = (x | (x >> 24)) & 0xffffull;
+    return (u32)x;
+}
+
 // Broadcast the seeds computed by sub-lane `srcSub` of every quad to the whole quad.
 __device__ __forceinline__ void quadBroadcast(Unfinished &dst, const Unfinished &src, int lane, int srcSub)
 {
@@ -2359,6 +2370,8 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
             continue;
 
         // ---- bounds of every partition of this mode (shared by the modes with the same subsets/channels) ----
+        u32 freshAlive = 0;      // bit k: the bound of partition 4k + c, computed just now, does not exceed the block's best error
+        bool freshBounds = false;
         if (prune)
         {
             if (boundsFor != boundSet)
@@ -2429,7 +2442,9 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                         if (!use4)
                             lb += staticAlphaBlock;
                         s_bound[partition][blk] = lb;
+                        freshAlive |= (lb > work.err) ? 0u : (1u << k);
                     }
+                    freshBounds = true;
                     };
                     if (use4 ? CVTT_GRID8_RGBA : CVTT_GRID8_RGB)
                         boundsOnGrid(std::true_type{});
@@ -2447,16 +2462,20 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
         // The offers of a round are searched by the whole wave: one lane per chain. ----
         const int CP = md.numP * 4;         // chains per subset: p-bit combinations x seed points
         const int UPB = 64 / CP;            // subsets searched at once
-        u32 aliveBits = 0;
-        for (int k = 0; k * 4 < numPartitions; k++)
+        // bit k: partition 4k + c is enabled for this block and its bound does not rule it out
+        u32 aliveBits = (valid && laneRuns) ? everyFourth(enabled, c) : 0u; // `enabled` has no bits past the mode's partitions
+        if (mode == 7 && anyBlockHasAlpha && !blockHasNonMaxAlpha)
+            aliveBits &= everyFourth(mode7RGB, c); // BC67.cpp:1625-1635: this lane may not take the other partitions
+        if (prune)
         {
-            const int partition = 4 * k + c;
-            bool alive = valid && laneRuns && partition < numPartitions && ((enabled >> partition) & 1ull) != 0;
-            if (mode == 7 && anyBlockHasAlpha && !blockHasNonMaxAlpha && ((mode7RGB >> partition) & 1ull) == 0)
-                alive = false; // BC67.cpp:1625-1635: this lane may not take the partition
-            if (prune && alive)
-                alive = !(s_bound[partition][blk] > work.err);
-            aliveBits |= alive ? (1u << k) : 0u;
+            if (freshBounds)
+                aliveBits &= freshAlive; // compared while the bounds were computed: the best error has not moved since
+            else
+            {
+                for (int k = 0; k * 4 < numPartitions; k++)
+                    if (s_bound[4 * k + c][blk] > work.err)
+                        aliveBits &= ~(1u << k);
+            }
         }
 
         if (prune && numSubsets >= 2)
@@ -2531,6 +2550,9 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 tier2Pays = __ballot(aliveBits != aliveBefore) != 0;
             }
         }
+        // nothing left for any block of the wave (the rule on RGBA noise): on to the next mode
+        if (__ballot(aliveBits != 0) == 0)
+            continue;
         if (!PT && !HARD && mode == 7 && A.hardCap != 0)
         {
             // A wave with many partitions to search runs for tens of chain passes.  That only matters when it starts
@@ -2983,6 +3005,9 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
         }
     }
 
+#ifdef CVTT_BC7_PROFILE_SPLIT
+    PROF_MARK(3)
+#endif
     // ===================== fix-ups + bit packing (reference BC67.cpp:2003-2203) ==========
     {
         const int mode = work.mode;
