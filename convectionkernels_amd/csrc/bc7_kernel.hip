@@ -2345,28 +2345,37 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
     {
         ModeDesc md;
         int numSubsets, numPartitions, stage, boundSet;
+        switch (stageIter)
+        {
+        case 0: stage = 4; md = {6, 4, 4, 7, 0}; numSubsets = 1; numPartitions = 1; boundSet = 3; break;
+        case 1: stage = 5; md = {7, 2, 4, 5, 6}; numSubsets = 2; numPartitions = 64; boundSet = 0; break;
+        case 2: stage = 1; md = {1, 3, 2, 6, 7}; numSubsets = 2; numPartitions = 64; boundSet = 1; break;
+        case 3: stage = 3; md = {3, 2, 4, 7, 0}; numSubsets = 2; numPartitions = 64; boundSet = 1; break;
+        case 4: stage = 0; md = {0, 3, 4, 4, 5}; numSubsets = 3; numPartitions = 16; boundSet = 2; break;
+        default: stage = 2; md = {2, 2, 1, 5, 5}; numSubsets = 3; numPartitions = 64; boundSet = 2; break;
+        }
+        if (HARD && stageIter != 1)
+            continue; // the second launch searches mode-7 partitions only
+        const int mode = md.mode;
+        const bool isRGB = mode < 4;
+        // does this mode run for my group?  (wave-uniform skip when it runs for nobody -- before the plan is read: a
+        // scalar load from memory per stage that a wave of alpha blocks would wait on four times for nothing)
+        const bool laneRuns = isRGB ? allowRGBModes : (mode == 7 ? allowMode7 : true);
+        if (__ballot(laneRuns) == 0)
+            continue;
         u64 enabled;
         switch (stageIter)
         {
-        case 0: stage = 4; md = {6, 4, 4, 7, 0}; numSubsets = 1; numPartitions = 1; boundSet = 3; enabled = plan->mode6Enabled ? 1 : 0; break;
-        case 1: stage = 5; md = {7, 2, 4, 5, 6}; numSubsets = 2; numPartitions = 64; boundSet = 0; enabled = ~0ull; break; // dead mask in the reference (BC67.cpp:1592-1597)
-        case 2: stage = 1; md = {1, 3, 2, 6, 7}; numSubsets = 2; numPartitions = 64; boundSet = 1; enabled = plan->mode1PartitionEnabled; break;
-        case 3: stage = 3; md = {3, 2, 4, 7, 0}; numSubsets = 2; numPartitions = 64; boundSet = 1; enabled = plan->mode3PartitionEnabled; break;
-        case 4: stage = 0; md = {0, 3, 4, 4, 5}; numSubsets = 3; numPartitions = 16; boundSet = 2; enabled = plan->mode0PartitionEnabled & 0xffffull; break;
-        default: stage = 2; md = {2, 2, 1, 5, 5}; numSubsets = 3; numPartitions = 64; boundSet = 2; enabled = plan->mode2PartitionEnabled; break;
+        case 0: enabled = plan->mode6Enabled ? 1 : 0; break;
+        case 1: enabled = ~0ull; break; // dead mask in the reference (BC67.cpp:1592-1597)
+        case 2: enabled = plan->mode1PartitionEnabled; break;
+        case 3: enabled = plan->mode3PartitionEnabled; break;
+        case 4: enabled = plan->mode0PartitionEnabled & 0xffffull; break;
+        default: enabled = plan->mode2PartitionEnabled; break;
         }
         if (HARD)
-        {
-            // this wavefront's slice of the mode-7 partitions
-            if (stageIter != 1)
-                continue;
-            enabled = hardMine;
-        }
-        const int mode = md.mode;
-        const bool isRGB = mode < 4;
-        // does this mode run for my group?  (wave-uniform skip when it runs for nobody)
-        const bool laneRuns = isRGB ? allowRGBModes : (mode == 7 ? allowMode7 : true);
-        if (__ballot(laneRuns) == 0 || enabled == 0)
+            enabled = hardMine; // this wavefront's slice of the mode-7 partitions
+        if (enabled == 0)
             continue;
 
         // ---- bounds of every partition of this mode (shared by the modes with the same subsets/channels) ----
