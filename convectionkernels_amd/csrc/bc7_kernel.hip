@@ -219,7 +219,7 @@ template <int NRC, bool FAST, bool TRACE>
 __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount, const ModeDesc md, const Unfinished &u,
                                           int pIter, int tweak, bool active, const CvttBc7Args &A,
                                           const CvttDeviceTables *__restrict__ T, int numRefine, ShapeBest &best,
-                                          float *trialErr = nullptr, int captureRound = -1)
+                                          const float (&vs)[4], float *trialErr = nullptr, int captureRound = -1)
 {
     const bool isRGB = (NRC == 3);
     const int range = 1 << md.indexBits;
@@ -338,7 +338,7 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
         const v2f w01 = {A.w[0], A.w[1]}, w23 = {A.w[2], A.w[3]};
         u32 err[4] = {0, 0, 0, 0};
         float slowErr = 0.0f;
-        v2f tv01 = {0.0f, 0.0f}, tv23 = {0.0f, 0.0f}, vs01 = {0.0f, 0.0f}, vs23 = {0.0f, 0.0f};
+        v2f tv01 = {0.0f, 0.0f}, tv23 = {0.0f, 0.0f};
         float tt = 0.0f, ts = 0.0f;
         u64 idx = 0;
         u32 rem = mask;
@@ -419,8 +419,6 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
                     const v2f v01 = x01 * w01, v23 = x23 * w23; // channel 3 is unused when NRC == 3
                     tv01 = tv01 + t2 * v01;
                     tv23 = tv23 + t2 * v23;
-                    vs01 = vs01 + v01;
-                    vs23 = vs23 + v23;
                     tt = tt + t * t;
                     ts = ts + t;
                 }
@@ -462,7 +460,7 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
         if (!last)
         {
             // EndpointRefiner::GetRefinedEndpointsLDR (EndpointRefiner.h:99-152)
-            const float tv[4] = {tv01.x, tv01.y, tv23.x, tv23.y}, vs[4] = {vs01.x, vs01.y, vs23.x, vs23.y};
+            const float tv[4] = {tv01.x, tv01.y, tv23.x, tv23.y};
             float adenom = (tt * wCount - ts * ts) * wRcp;
             const bool adenomZero = (adenom == 0.0f);
             if (adenomZero)
@@ -528,11 +526,11 @@ struct FetchLDS
 };
 
 template <int N>
-__device__ __forceinline__ void pcaEndpointsLDS(const u32 *lp, u32 mask, const float (&w)[4], Unfinished &u)
+__device__ __forceinline__ void pcaEndpointsLDS(const u32 *lp, u32 mask, const float (&w)[4], Unfinished &u, float *sums)
 {
     const FetchLDS F = {lp, w};
     Moments<N> m;
-    pcaMomentsT<N>(F, mask, m);
+    pcaMomentsT<N>(F, mask, m, sums);
     pcaFinishT<N>(F, mask, w, m, u);
 }
 
@@ -541,16 +539,19 @@ struct UnitRec
 {
     float base[4];
     float offset[4];
-    u32 mask;
-    int numTweak;
-    int blk;
-    int slot; // item * 3 + subset: where the subset's result goes
+    u32 packed;  // mask | numTweak << 16 | blk << 20 | slot << 24  (slot = item * 3 + subset: where the subset's result goes)
     float scErr; // BC7_TrySingleColor: error of the fixed candidate (FLT_MAX when not tried)
+    // the refiner's m_v of the subset: sum of the pre-weighted member pixels in ascending order (EndpointRefiner.h:78-92).
+    // It does not depend on the indexes, so the seed lane takes it once for all chains and rounds of the unit.
+    float vs[4];
     // Not part of the unit (the seed pass never writes it): entry b < 16 keeps the secondary index set of block b's best
-    // mode 4 / 5 candidate out of the registers until the block is packed.  It lives in this padding because gfx950
-    // allocates LDS in 1280-byte granules and the kernel sits exactly on 10 of them (12 workgroups per CU).
+    // mode 4 / 5 candidate out of the registers until the block is packed.  It lives here because gfx950 allocates LDS in
+    // 1280-byte granules and the kernel sits exactly on 10 of them (12 workgroups per CU).
     u32 parkedIdx2[2];
-    int pad;
+    __device__ __forceinline__ u32 mask() const { return packed & 0xffffu; }
+    __device__ __forceinline__ int numTweak() const { return (int)((packed >> 16) & 7u); }
+    __device__ __forceinline__ int blk() const { return (int)((packed >> 20) & 15u); }
+    __device__ __forceinline__ int slot() const { return (int)(packed >> 24); }
 };
 
 struct WorkState
@@ -2749,10 +2750,11 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 for (int ch = 0; ch < 4; ch++)
                     uu.base[ch] = uu.offset[ch] = 0.0f;
                 const u32 *lp = &s_pix[ublk][0];
+                float vsum[4] = {0.0f, 0.0f, 0.0f, 0.0f}; // the refiner's m_v (UnitRec::vs); the PCA's first pass forms the same sums
                 if (do3)
                 {
                     Unfinished u3;
-                    pcaEndpointsLDS<3>(lp, uMask, A.w, u3);
+                    pcaEndpointsLDS<3>(lp, uMask, A.w, u3, vsum);
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++)
                     {
@@ -2766,7 +2768,23 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                     uu.offset[3] = 0.0f;
                 }
                 if (do4)
-                    pcaEndpointsLDS<4>(lp, uMask, A.w, uu);
+                    pcaEndpointsLDS<4>(lp, uMask, A.w, uu, vsum);
+                if (wanted && !do4)
+                {
+                    // no four-channel pass ran: alpha of an RGBA mode whose seeds come from the RGB pass, or every channel
+                    // of a shape the plan does not list (zero seeds, but its chains still run)
+#pragma unroll
+                    for (int ch = 0; ch < 4; ch++)
+                        if (ch == 3 ? !isRGB : !do3)
+                        {
+                            float a = 0.0f;
+#pragma unroll
+                            for (int px = 0; px < 16; px++)
+                                if ((uMask >> px) & 1u)
+                                    a = a + byteF(lp[px], ch) * A.w[ch];
+                            vsum[ch] = a;
+                        }
+                }
                 UnitRec &r = s_unit[unitPos];
 #pragma unroll
                 for (int ch = 0; ch < 4; ch++)
@@ -2774,10 +2792,10 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                     r.base[ch] = uu.base[ch];
                     r.offset[ch] = uu.offset[ch];
                 }
-                r.mask = uMask;
-                r.numTweak = seeds;
-                r.blk = ublk;
-                r.slot = item * 3 + sub;
+#pragma unroll
+                for (int ch = 0; ch < 4; ch++)
+                    r.vs[ch] = vsum[ch];
+                r.packed = uMask | ((u32)(seeds < 0 ? 0 : seeds) << 16) | ((u32)ublk << 20) | ((u32)(item * 3 + sub) << 24);
                 float scErr = FLT_MAX;
                 if ((A.flags & CVTTMI_FLAG_BC7_TRY_SINGLE_COLOR) && seeds > 0)
                 {
@@ -2825,8 +2843,8 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 const bool inRange = unit < numUnits;
                 const UnitRec &r = s_unit[inRange ? unit : 0];
                 const int tweak = chain & 3, pIter = chain >> 2;
-                const u32 uMask = r.mask;
-                const bool active = inRange && tweak < r.numTweak;
+                const u32 uMask = r.mask();
+                const bool active = inRange && tweak < r.numTweak();
                 int maxCount = active ? __popc(uMask) : 0;
 #pragma unroll
                 for (int step = 1; step < 64; step <<= 1)
@@ -2842,7 +2860,8 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                     uu.base[ch] = r.base[ch];
                     uu.offset[ch] = r.offset[ch];
                 }
-                const u32 *lp = &s_pix[r.blk][0];
+                const u32 *lp = &s_pix[r.blk()][0];
+                const float uvs[4] = {r.vs[0], r.vs[1], r.vs[2], r.vs[3]};
                 PROF_COUNT(2, 64)
                 PROF_COUNT(3, __popcll(__ballot(active)))
                 ShapeBest b;
@@ -2850,14 +2869,14 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 {
                     // record every trial; the lock-step commit rule is applied below
                     if (PT)
-                        evalChain<4, FAST, true>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b,
+                        evalChain<4, FAST, true>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b, uvs,
                                                  &s_trialErr[((inRange ? unit : 0) * 16 + chain) * numRefine], -1);
                     continue;
                 }
                 if (isRGB)
-                    evalChain<3, FAST, false>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b);
+                    evalChain<3, FAST, false>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b, uvs);
                 else
-                    evalChain<4, FAST, false>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b);
+                    evalChain<4, FAST, false>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b, uvs);
                 groupArgminBroadcast(b, lane, CP);
                 if (inRange && chain == 0)
                 {
@@ -2869,7 +2888,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                         b.idxLo = b.idxHi = 0;
                     }
                     // with no seed points the shape keeps its reset error FLT_MAX (BC67.cpp:1228-1242)
-                    u32 *dst = &s_res[r.slot][0];
+                    u32 *dst = &s_res[r.slot()][0];
                     dst[0] = __builtin_bit_cast(u32, b.err);
                     dst[1] = b.ep0;
                     dst[2] = b.ep1;
@@ -2890,7 +2909,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 const bool scanActive = item < numItems && lane < (numItems / 8) * perGroup;
                 const int unit = scanActive ? item * numSubsets + sub : 0;
                 const UnitRec &r = s_unit[unit];
-                const u32 bf = s_blkFlags[r.blk];
+                const u32 bf = s_blkFlags[r.blk()];
                 const bool isPT = (bf & 2u) != 0, nonZeroA = (bf & 4u) != 0, nonMaxA = (bf & 8u) != 0;
                 const int slice = lane & ~7;
                 float held = FLT_MAX; // shapeBestError
@@ -2905,7 +2924,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                         for (int rf = 0; rf < numRefine; rf++)
                         {
                             const int t = (pI * 4 + tw) * numRefine + rf;
-                            const bool run = scanActive && !allInvalid && tw < r.numTweak;
+                            const bool run = scanActive && !allInvalid && tw < r.numTweak();
                             const float e = run ? s_trialErr[unit * 16 * numRefine + t] : FLT_MAX;
                             const bool better = run && e < held;
                             const bool anyBetter = ((u32)(__ballot(better) >> slice) & 0xffu) != 0;
@@ -2927,7 +2946,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 // the payload of the held trial: run that chain again up to its round
                 const bool have = scanActive && last >= 0;
                 const int hChain = have ? last / numRefine : 0, hRound = have ? last - hChain * numRefine : 0;
-                int maxCount = have ? __popc(r.mask) : 0;
+                int maxCount = have ? __popc(r.mask()) : 0;
 #pragma unroll
                 for (int step = 1; step < 64; step <<= 1)
                 {
@@ -2943,7 +2962,8 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                     uu.offset[ch] = r.offset[ch];
                 }
                 ShapeBest b;
-                evalChain<4, FAST, true>(&s_pix[r.blk][0], r.mask, maxCount, md, uu, hChain >> 2, hChain & 3, have, A, T, numRefine, b,
+                const float uvs[4] = {r.vs[0], r.vs[1], r.vs[2], r.vs[3]};
+                evalChain<4, FAST, true>(&s_pix[r.blk()][0], r.mask(), maxCount, md, uu, hChain >> 2, hChain & 3, have, A, T, numRefine, b, uvs,
                                          nullptr, hRound);
                 if (scanActive)
                 {
@@ -2958,7 +2978,7 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                         b.ep0 = b.ep1 = 0xff000000u;
                         b.idxLo = b.idxHi = 0;
                     }
-                    u32 *dst = &s_res[r.slot][0];
+                    u32 *dst = &s_res[r.slot()][0];
                     dst[0] = __builtin_bit_cast(u32, b.err);
                     dst[1] = b.ep0;
                     dst[2] = b.ep1;

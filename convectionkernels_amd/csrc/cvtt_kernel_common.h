@@ -146,8 +146,10 @@ struct FetchLDR
 };
 
 // passes 0 and 1: centroid and scatter matrix of the pre-weighted pixels
+// `sums` (optional): the plain sums of the pre-weighted pixels before the division, i.e. what EndpointRefiner::
+// ContributeUnweightedPW accumulates as m_v over the same pixels in the same order
 template <int N, class Fetch>
-__device__ __forceinline__ void pcaMomentsT(const Fetch &F, u32 mask, Moments<N> &m)
+__device__ __forceinline__ void pcaMomentsT(const Fetch &F, u32 mask, Moments<N> &m, float *sums = nullptr)
 {
 #pragma unroll
     for (int ch = 0; ch < N; ch++)
@@ -165,6 +167,12 @@ __device__ __forceinline__ void pcaMomentsT(const Fetch &F, u32 mask, Moments<N>
                 m.centroid[ch] = m.centroid[ch] + v[ch];
             count = count + 1.0f;
         }
+    }
+    if (sums)
+    {
+#pragma unroll
+        for (int ch = 0; ch < N; ch++)
+            sums[ch] = m.centroid[ch];
     }
     const float denom = safeDenom(count);
 #pragma unroll
