@@ -203,6 +203,26 @@ struct EtcErr
         }
         return wu(r, g, b, px, pw);
     }
+    // The weighted metric for TWO colours at once in packed f32 lanes (v_pk_mul_f32 / v_pk_add_f32): each lane does
+    // ComputeErrorWeighted's operations in its order (product, difference, squares added left to right), so both results are
+    // the numbers the scalar form gives.  Only valid when !uniform (and, where the caller would use operator(), !fake).
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __device__ __forceinline__ void weigh2(f32x2 (&mw)[3], const int (&a)[3], const int (&b)[3]) const
+    {
+        mw[0] = f32x2{(float)a[0] * rw, (float)b[0] * rw};
+        mw[1] = f32x2{(float)a[1] * gw, (float)b[1] * gw};
+        mw[2] = f32x2{(float)a[2] * bw, (float)b[2] * bw};
+    }
+    __device__ __forceinline__ f32x2 err2(const f32x2 (&mw)[3], const float *pw) const
+    {
+        f32x2 d = mw[0] - f32x2{pw[0], pw[0]};
+        f32x2 e = d * d;
+        d = mw[1] - f32x2{pw[1], pw[1]};
+        e = e + d * d;
+        d = mw[2] - f32x2{pw[2], pw[2]};
+        e = e + d * d;
+        return e;
+    }
     // ComputeErrorUniform / ComputeErrorWeighted, ETC.cpp:59-80.  The line colours of the T modes are measured with
     // this even under ETC_UseFakeBT709 (ETC.cpp:600, 1133, 1150), against pre-weighted pixels that then hold luma/chroma
     __device__ __forceinline__ float wu(int r, int g, int b, const int *px, const float *pw) const
@@ -843,14 +863,29 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                     }
                     u32 selectors = 0;
                     float error = 0.0f;
+                    EtcErr::f32x2 lw01[3];
+                    E.weigh2(lw01, lc[0], lc[1]);
                     for (int px = 0; px < 16; px++)
                     {
                         float pixelError = S.isoErr[px];
                         u32 sel = 0;
+                        float e3[3];
+                        if (!E.uniform)
+                        {
+                            const EtcErr::f32x2 e01 = E.err2(lw01, S.pw[px]);
+                            e3[0] = e01.x;
+                            e3[1] = e01.y;
+                        }
+                        else
+                        {
+                            e3[0] = E.wu(lc[0][0], lc[0][1], lc[0][2], S.pix[px], S.pw[px]);
+                            e3[1] = E.wu(lc[1][0], lc[1][1], lc[1][2], S.pix[px], S.pw[px]);
+                        }
+                        e3[2] = E.wu(lc[2][0], lc[2][1], lc[2][2], S.pix[px], S.pw[px]); // sic: never the fake metric
 #pragma unroll
                         for (int i = 0; i < 3; i++)
                         {
-                            const float e = E.wu(lc[i][0], lc[i][1], lc[i][2], S.pix[px], S.pw[px]); // sic: never the fake metric
+                            const float e = e3[i];
                             if (e < pixelError)
                                 sel = (u32)(i + 1);
                             pixelError = sseMin(e, pixelError);
@@ -1058,10 +1093,22 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                         c1[ch] = u - modifier > 0 ? u - modifier : 0;
                     }
                     u32 signBits = 0;
+                    EtcErr::f32x2 cw[3];
+                    E.weigh2(cw, c0, c1);
                     for (int px = 0; px < 16; px++)
                     {
-                        const float e0 = E(c0[0], c0[1], c0[2], S.pix[px], S.pw[px]);
-                        const float e1 = E(c1[0], c1[1], c1[2], S.pix[px], S.pw[px]);
+                        float e0, e1;
+                        if (!FAKE && !E.uniform)
+                        {
+                            const EtcErr::f32x2 e01 = E.err2(cw, S.pw[px]);
+                            e0 = e01.x;
+                            e1 = e01.y;
+                        }
+                        else
+                        {
+                            e0 = E(c0[0], c0[1], c0[2], S.pix[px], S.pw[px]);
+                            e1 = E(c1[0], c1[1], c1[2], S.pix[px], S.pw[px]);
+                        }
                         if (e1 < e0)
                             signBits |= 1u << px;
                         S.u.h.err[r][px] = sseMin(e0, e1);
