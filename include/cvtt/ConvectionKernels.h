@@ -129,6 +129,11 @@ namespace cvtt
         void ConfigureBC7EncodingPlanFromQuality(BC7EncodingPlan &encodingPlan, int quality);
         bool ConfigureBC7EncodingPlanFromFineTuningParams(BC7EncodingPlan &encodingPlan, const BC7FineTuningParams &params);
 
+        // Deviation from the reference (documented): the reference derives the two chroma axes of the planar
+        // search from the weights of the Options given HERE (ETC.cpp:3117-3145) and keeps them in the data block; this
+        // library derives them from the Options of every Encode call (the GPU keeps no per-caller block).  The output is
+        // bit-identical whenever the red/green/blue weights at allocation and at encoding are equal -- the only use
+        // the reference's own caller makes of it (etc2packer.cpp:215-281).
         ETC2CompressionData *AllocETC2Data(allocFunc_t allocFunc, void *context, const Options &options);
         void ReleaseETC2Data(ETC2CompressionData *compressionData, freeFunc_t freeFunc);
         ETC1CompressionData *AllocETC1Data(allocFunc_t allocFunc, void *context);
