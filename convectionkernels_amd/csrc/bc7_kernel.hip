@@ -2560,6 +2560,9 @@ __global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const ui
                 tier2Pays = __ballot(aliveBits != aliveBefore) != 0;
             }
         }
+#ifdef CVTT_BC7_PROFILE_SPLIT
+        PROF_MARK(4)
+#endif
         // nothing left for any block of the wave (the rule on RGBA noise): on to the next mode
         if (__ballot(aliveBits != 0) == 0)
             continue;

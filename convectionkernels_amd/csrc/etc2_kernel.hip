@@ -1324,6 +1324,9 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                 S.dCount[lane] = n;
             }
             WAVE_SYNC();
+#ifdef CVTT_ETC_PROFILE
+            DBG_TAP(7); // base colours + duplicate removal
+#endif
             int prefix[17];
             prefix[0] = 0;
 #pragma unroll
@@ -1448,6 +1451,9 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                 }
             }
             WAVE_SYNC();
+#ifdef CVTT_ETC_PROFILE
+            DBG_TAP(5); // TestHalfBlock over all candidates
+#endif
 
             // ---- FindBestDifferentialCombination (ETC.cpp:219-362), wave-parallel scans ----
             const float blockBest0 = bestError;

@@ -106,3 +106,12 @@ def test_gpu_config3_full_size_hash(gpu_ctx):
     t = torch.from_numpy(content.config_blocks_hdr(3, 4096, 4096)).cuda()
     out = gpu_ctx.encode_bc6h(t, api.Options()).cpu().numpy()
     assert hashlib.sha256(out.tobytes()).hexdigest() == h["config3_bc6hu_4096_seed3"]
+
+
+def test_integer_endpoint_quantisation_equals_the_float_sequence():
+    """csrc/bc6h_kernel.hip quantises endpoints with an integer ceil(elem * 64 / 31) (one v_mul_hi_u32) instead of the
+    reference's rounded-up binary32 division (BC67.cpp:2425-2445): exhaustive equality over every value the colour-space
+    clamp lets through, unsigned and signed (tools/check_bc6h_quantize.py; no GPU needed)."""
+    import runpy
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runpy.run_path(os.path.join(root, "tools", "check_bc6h_quantize.py"), run_name="__main__")
