@@ -56,6 +56,10 @@ constexpr float kBoundGrid8 = 124.0f, kBoundLimit8 = 127.0f;
 #ifndef CVTT_BC7_WAVES
 #define CVTT_BC7_WAVES 3
 #endif
+// the same for the slow-indexing instantiation (Flags::Better / Ultra), whose three probes per pixel need more registers
+#ifndef CVTT_BC7_WAVES_SLOW
+#define CVTT_BC7_WAVES_SLOW 3
+#endif
 // power iterations per principal axis of the projection the first-tier bounds are taken in (tightness only, never validity)
 #ifndef CVTT_EIG_ITERS
 #define CVTT_EIG_ITERS 6
@@ -1817,7 +1821,7 @@ __device__ __forceinline__ void quadBroadcast(Unfinished &dst, const Unfinished 
 // best and leaves its best candidate, packed, in A.hardCand; cvttmi_bc7_hard_commit_kernel picks the winner.
 // Every candidate is compared by (error, position in the reference's order), so the split cannot change the result.
 template <bool FAST, bool PT, bool HARD>
-__global__ __launch_bounds__(64, CVTT_BC7_WAVES) void cvttmi_bc7_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVES_SLOW) void cvttmi_bc7_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
                                                         const CvttBc7Args A, const CvttDeviceTables *__restrict__ T,
                                                         const CvttBc7DevicePlan *__restrict__ dplan)
 {

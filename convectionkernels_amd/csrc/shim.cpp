@@ -72,14 +72,16 @@ struct cvttmi_context
     hipEvent_t evPlanUp[kPlanSlots]; // recorded after the slot's upload, on the stream that did it
     hipStream_t planUpStream[kPlanSlots];
     int nextPlanSlot;
-    // host-pointer entry points: a two-deep pipeline of chunks, each slot with its own staging and stream, so that the
-    // upload of chunk i+1 and the download of chunk i-1 overlap the search of chunk i
+    // host-pointer entry points: a pipeline of chunks, each slot with its own staging and stream, so that the uploads of
+    // the next chunks and the downloads of the previous ones overlap the search of the current one, and the searches of
+    // neighbouring chunks (small launches: a chunk is two or three waves per SIMD) fill the device together
+    static const int kPipeSlots = 4;
     struct PipeSlot
     {
         void *pinnedIn, *pinnedOut, *dIn, *dOut;
         hipStream_t stream;
         hipEvent_t done;
-    } pipe[2];
+    } pipe[kPipeSlots];
     size_t pipeInBytes, pipeOutBytes;
     hipStream_t stream; // = pipe[0].stream: the context's private stream
     // calls may arrive from several host threads and on several streams, but the work buffers below exist once:
@@ -282,7 +284,7 @@ namespace
 
     void freePipe(cvttmi_context *ctx)
     {
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < cvttmi_context::kPipeSlots; i++)
         {
             cvttmi_context::PipeSlot &S = ctx->pipe[i];
             if (S.pinnedIn) (void)hipHostFree(S.pinnedIn);
@@ -298,13 +300,13 @@ namespace
     {
         if (ctx->pipeInBytes >= inBytes && ctx->pipeOutBytes >= outBytes)
             return CVTTMI_OK;
-        (void)hipStreamSynchronize(ctx->pipe[0].stream);
-        (void)hipStreamSynchronize(ctx->pipe[1].stream);
+        for (int i = 0; i < cvttmi_context::kPipeSlots; i++)
+            (void)hipStreamSynchronize(ctx->pipe[i].stream);
         inBytes = inBytes > ctx->pipeInBytes ? inBytes : ctx->pipeInBytes;
         outBytes = outBytes > ctx->pipeOutBytes ? outBytes : ctx->pipeOutBytes;
         freePipe(ctx);
         hipError_t e;
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < cvttmi_context::kPipeSlots; i++)
         {
             cvttmi_context::PipeSlot &S = ctx->pipe[i];
             if ((e = hipHostMalloc(&S.pinnedIn, inBytes)) != hipSuccess || (e = hipHostMalloc(&S.pinnedOut, outBytes)) != hipSuccess ||
@@ -332,16 +334,21 @@ namespace
     }
 
     // The host-pointer entry points: `numBlocks` blocks of `inBpb` bytes in host memory -> `outBpb` bytes each in host
-    // memory through `launch(dOut, dIn, n, stream)`, in chunks of 2^17 blocks (8 MiB of PixelBlockU8; measured best of 2^16..2^19) dealt to two pipeline slots with their own
-    // stream, so the PCIe transfers of neighbouring chunks run beside the kernels of the current one (the kernels
-    // themselves stay ordered through the context's work buffers).  Page-locked caller memory (cvttmi_host_alloc /
+    // memory through `launch(dOut, dIn, n, stream)`, in chunks of 2^16 blocks (4 MiB of PixelBlockU8) dealt to four pipeline slots with their own
+    // stream, so the PCIe transfers of neighbouring chunks run beside the kernels of the current one and the kernels of
+    // neighbouring chunks -- one wave per SIMD each -- fill the device together (launches that use the context's work
+    // buffers stay ordered through them).  Measured on 4096^2 BC7, page-locked / pageable caller memory, Mblocks/s:
+    // 2 slots x 2^17: 431 / 295; 3 x 2^16: 463 / 350; 4 x 2^16: 517 / 355; 4 x 2^17: 360 / 360 (CVTTMI_HOST_SLOTS,
+    // CVTTMI_HOST_CHUNK_LOG2 select other settings for experiments).  Page-locked caller memory (cvttmi_host_alloc /
     // cvttmi_host_register) is transferred in place; pageable memory goes through the slots' pinned staging, the CPU copy
     // of the next chunk overlapping the device work of the current one.
     template <class Launch>
     int hostPipeline(cvttmi_context *ctx, uint8_t *out, const uint8_t *in, size_t numBlocks, size_t inBpb, size_t outBpb, Launch launch)
     {
-        static const int chunkLog2 = getenv("CVTTMI_HOST_CHUNK_LOG2") ? atoi(getenv("CVTTMI_HOST_CHUNK_LOG2")) : 17;
+        static const int chunkLog2 = getenv("CVTTMI_HOST_CHUNK_LOG2") ? atoi(getenv("CVTTMI_HOST_CHUNK_LOG2")) : 16;
         const size_t kChunk = (size_t)1 << (chunkLog2 < 10 ? 10 : chunkLog2 > 24 ? 24 : chunkLog2);
+        static const int slotsEnv = getenv("CVTTMI_HOST_SLOTS") ? atoi(getenv("CVTTMI_HOST_SLOTS")) : cvttmi_context::kPipeSlots;
+        const size_t kSlots = (size_t)(slotsEnv < 1 ? 1 : slotsEnv > cvttmi_context::kPipeSlots ? cvttmi_context::kPipeSlots : slotsEnv);
         const size_t chunk = numBlocks < kChunk ? numBlocks : kChunk;
         int rc = ensurePipe(ctx, chunk * inBpb, chunk * outBpb);
         if (rc != CVTTMI_OK)
@@ -351,7 +358,7 @@ namespace
         const size_t numChunks = (numBlocks + chunk - 1) / chunk;
         hipError_t e;
         auto finish = [&](size_t c) -> int {
-            cvttmi_context::PipeSlot &S = ctx->pipe[c & 1];
+            cvttmi_context::PipeSlot &S = ctx->pipe[c % kSlots];
             hipError_t fe = hipEventSynchronize(S.done);
             if (fe != hipSuccess)
                 return fail(ctx, CVTTMI_E_HIP, "kernel execution", fe);
@@ -364,8 +371,8 @@ namespace
         };
         for (size_t c = 0; c < numChunks; c++)
         {
-            cvttmi_context::PipeSlot &S = ctx->pipe[c & 1];
-            if (c >= 2 && (rc = finish(c - 2)) != CVTTMI_OK)
+            cvttmi_context::PipeSlot &S = ctx->pipe[c % kSlots];
+            if (c >= kSlots && (rc = finish(c - kSlots)) != CVTTMI_OK)
                 return rc;
             const size_t first = c * chunk;
             const size_t n = (numBlocks - first) < chunk ? (numBlocks - first) : chunk;
@@ -385,7 +392,7 @@ namespace
             if ((e = hipEventRecord(S.done, S.stream)) != hipSuccess)
                 return fail(ctx, CVTTMI_E_HIP, "hipEventRecord", e);
         }
-        for (size_t c = numChunks >= 2 ? numChunks - 2 : 0; c < numChunks; c++)
+        for (size_t c = numChunks >= kSlots ? numChunks - kSlots : 0; c < numChunks; c++)
             if ((rc = finish(c)) != CVTTMI_OK)
                 return rc;
         return CVTTMI_OK;
@@ -628,11 +635,12 @@ extern "C"
             (e = hipMalloc(reinterpret_cast<void **>(&ctx->dTables), sizeof(CvttDeviceTables))) == hipSuccess &&
             (e = hipMalloc(reinterpret_cast<void **>(&ctx->dPlans), sizeof(CvttBc7DevicePlan) * cvttmi_context::kPlanSlots)) == hipSuccess &&
             (e = hipHostMalloc(reinterpret_cast<void **>(&ctx->pinnedPlans), sizeof(CvttBc7DevicePlan) * cvttmi_context::kPlanSlots)) == hipSuccess &&
-            (e = hipStreamCreate(&ctx->pipe[0].stream)) == hipSuccess && (e = hipStreamCreate(&ctx->pipe[1].stream)) == hipSuccess &&
-            (e = hipEventCreateWithFlags(&ctx->pipe[0].done, hipEventDisableTiming)) == hipSuccess &&
-            (e = hipEventCreateWithFlags(&ctx->pipe[1].done, hipEventDisableTiming)) == hipSuccess &&
+
             (e = hipEventCreateWithFlags(&ctx->evLast, hipEventDisableTiming)) == hipSuccess &&
             (e = hipEventCreate(&ctx->evStart)) == hipSuccess && (e = hipEventCreate(&ctx->evStop)) == hipSuccess;
+        for (int i = 0; ok && i < cvttmi_context::kPipeSlots; i++)
+            ok = (e = hipStreamCreate(&ctx->pipe[i].stream)) == hipSuccess &&
+                 (e = hipEventCreateWithFlags(&ctx->pipe[i].done, hipEventDisableTiming)) == hipSuccess;
         for (int i = 0; ok && i < cvttmi_context::kPlanSlots; i++)
             ok = (e = hipEventCreateWithFlags(&ctx->evPlan[i], hipEventDisableTiming)) == hipSuccess &&
                  (e = hipEventCreateWithFlags(&ctx->evPlanUp[i], hipEventDisableTiming)) == hipSuccess;
@@ -660,7 +668,7 @@ extern "C"
         if (ctx->dHardCount) (void)hipFree(ctx->dHardCount);
         if (ctx->dHardRec) (void)hipFree(ctx->dHardRec);
         if (ctx->dHardCand) (void)hipFree(ctx->dHardCand);
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < cvttmi_context::kPipeSlots; i++)
         {
             if (ctx->pipe[i].stream) (void)hipStreamDestroy(ctx->pipe[i].stream);
             if (ctx->pipe[i].done) (void)hipEventDestroy(ctx->pipe[i].done);
