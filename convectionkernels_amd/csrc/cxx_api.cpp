@@ -1,6 +1,9 @@
 // C++ face (include/cvtt/ConvectionKernels.h) on top of the C ABI: same names and call
 // convention as the reference's cvtt::Kernels (reference ConvectionKernels_API.cpp:41-99,
-// 216-286), one process-wide context on HIP device CVTTMI_DEVICE (default 0).
+// 216-286).  One context PER CALLING THREAD on HIP device CVTTMI_DEVICE (default 0), created on the thread's first call
+// and destroyed when the thread ends: the reference is called by one worker thread per group of blocks
+// (etc2packer.cpp:215-281), and contexts are independent (own stream, staging and work buffers), so such callers run
+// side by side instead of queueing on one lock.
 #include "../../include/cvtt/ConvectionKernels.h"
 #include "../../include/cvtt_mi355x.h"
 
@@ -8,7 +11,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <mutex>
 #include <new>
 
 static_assert(sizeof(cvtt::Options) == sizeof(cvttmi_options), "cvtt::Options layout");
@@ -18,29 +20,38 @@ static_assert(sizeof(cvtt::PixelBlockU8) == 64 && sizeof(cvtt::PixelBlockF16) ==
 
 namespace
 {
-    std::mutex g_lock; // the context owns one set of staging buffers
-    cvttmi_context *g_ctx = NULL;
+    struct ThreadContext
+    {
+        cvttmi_context *ctx;
+        ThreadContext() : ctx(NULL) {}
+        ~ThreadContext()
+        {
+            if (ctx)
+                cvttmi_destroy(ctx);
+        }
+    };
+    thread_local ThreadContext t_ctx;
 
     cvttmi_context *context()
     {
-        if (!g_ctx)
+        if (!t_ctx.ctx)
         {
             const char *dev = getenv("CVTTMI_DEVICE");
-            const int rc = cvttmi_create(&g_ctx, dev ? atoi(dev) : 0);
+            const int rc = cvttmi_create(&t_ctx.ctx, dev ? atoi(dev) : 0);
             if (rc != CVTTMI_OK)
             {
                 fprintf(stderr, "cvtt (MI355X): no usable gfx950 device (cvttmi_create = %d); there is no CPU fallback\n", rc);
                 abort();
             }
         }
-        return g_ctx;
+        return t_ctx.ctx;
     }
 
     void check(int rc, const char *what)
     {
         if (rc != CVTTMI_OK)
         {
-            fprintf(stderr, "cvtt (MI355X): %s failed (%d): %s\n", what, rc, cvttmi_last_error(g_ctx));
+            fprintf(stderr, "cvtt (MI355X): %s failed (%d): %s\n", what, rc, cvttmi_last_error(t_ctx.ctx));
             abort();
         }
     }
@@ -89,19 +100,16 @@ namespace cvtt
 
         void EncodeBC7Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options, const BC7EncodingPlan &plan)
         {
-            std::lock_guard<std::mutex> g(g_lock);
             check(cvttmi_encode_bc7(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options),
                                     reinterpret_cast<const cvttmi_bc7_plan *>(&plan)), "EncodeBC7");
         }
         void EncodeBC1Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
         {
-            std::lock_guard<std::mutex> g(g_lock);
             check(cvttmi_encode_bc1(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeBC1");
         }
 #define CVTT_S3TC_BATCH(NAME, PIXELTYPE, CALL)                                                                                  \
         void NAME##Batch(uint8_t *pBC, const PIXELTYPE *pBlocks, size_t numBlocks, const Options &options)                      \
         {                                                                                                                       \
-            std::lock_guard<std::mutex> g(g_lock);                                                                              \
             check(CALL, #NAME);                                                                                                 \
         }                                                                                                                       \
         void NAME(uint8_t *pBC, const PIXELTYPE *pBlocks, const Options &options) { NAME##Batch(pBC, pBlocks, NumParallelBlocks, options); }
@@ -115,43 +123,35 @@ namespace cvtt
 
         void EncodeBC6HUBatch(uint8_t *pBC, const PixelBlockF16 *pBlocks, size_t numBlocks, const Options &options)
         {
-            std::lock_guard<std::mutex> g(g_lock);
             check(cvttmi_encode_bc6h(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), 0), "EncodeBC6HU");
         }
         void EncodeBC6HSBatch(uint8_t *pBC, const PixelBlockF16 *pBlocks, size_t numBlocks, const Options &options)
         {
-            std::lock_guard<std::mutex> g(g_lock);
             check(cvttmi_encode_bc6h(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), 1), "EncodeBC6HS");
         }
         void EncodeETC2PunchthroughAlphaBatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
         {
-            std::lock_guard<std::mutex> g(g_lock);
             check(cvttmi_encode_etc2_punchthrough_alpha(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeETC2PunchthroughAlpha");
         }
         void EncodeETC1Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
         {
-            std::lock_guard<std::mutex> g(g_lock);
             check(cvttmi_encode_etc1(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeETC1");
         }
         void EncodeETC2Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
         {
-            std::lock_guard<std::mutex> g(g_lock);
             check(cvttmi_encode_etc2(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeETC2");
         }
         void EncodeETC2RGBABatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
         {
-            std::lock_guard<std::mutex> g(g_lock);
             check(cvttmi_encode_etc2_rgba(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeETC2RGBA");
         }
         void EncodeETC2AlphaBatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
         {
-            std::lock_guard<std::mutex> g(g_lock);
             check(cvttmi_encode_etc2_alpha(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeETC2Alpha");
         }
 
         void EncodeETC2Alpha11Batch(uint8_t *pBC, const PixelBlockScalarS16 *pBlocks, size_t numBlocks, bool isSigned, const Options &options)
         {
-            std::lock_guard<std::mutex> g(g_lock);
             check(cvttmi_encode_etc2_alpha11(context(), pBC, reinterpret_cast<const int16_t *>(pBlocks), numBlocks, isSigned ? 1 : 0, opt(options)),
                   "EncodeETC2Alpha11");
         }
@@ -161,17 +161,14 @@ namespace cvtt
         }
         void DecodeBC7Batch(PixelBlockU8 *pBlocks, const uint8_t *pBC, size_t numBlocks)
         {
-            std::lock_guard<std::mutex> g(g_lock);
             check(cvttmi_decode_bc7(context(), reinterpret_cast<uint8_t *>(pBlocks), pBC, numBlocks), "DecodeBC7");
         }
         void DecodeBC6HUBatch(PixelBlockF16 *pBlocks, const uint8_t *pBC, size_t numBlocks)
         {
-            std::lock_guard<std::mutex> g(g_lock);
             check(cvttmi_decode_bc6h(context(), reinterpret_cast<uint8_t *>(pBlocks), pBC, numBlocks, 0), "DecodeBC6HU");
         }
         void DecodeBC6HSBatch(PixelBlockF16 *pBlocks, const uint8_t *pBC, size_t numBlocks)
         {
-            std::lock_guard<std::mutex> g(g_lock);
             check(cvttmi_decode_bc6h(context(), reinterpret_cast<uint8_t *>(pBlocks), pBC, numBlocks, 1), "DecodeBC6HS");
         }
         void DecodeBC7(PixelBlockU8 *pBlocks, const uint8_t *pBC) { DecodeBC7Batch(pBlocks, pBC, NumParallelBlocks); }

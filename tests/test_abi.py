@@ -77,6 +77,7 @@ CXX_CLIENT = r"""
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
 static void *allocate(void *, size_t n) { return malloc(n); }
 static void release(void *, void *p, size_t) { free(p); }
 int main(int argc, char **argv)
@@ -130,6 +131,19 @@ int main(int argc, char **argv)
             printf("%02x", out[k][i]);
         printf("\n");
     }
+    // the reference's callers run one worker thread per group (etc2packer.cpp:215-281): every thread gets its own context
+    int bad = 0;
+    {
+        static uint8_t tout[4][128];
+        std::thread th[4];
+        for (int i = 0; i < 4; i++)
+            th[i] = std::thread([&, i] { for (int rep = 0; rep < 3; rep++) cvtt::Kernels::EncodeBC7(tout[i], in, options, plan); });
+        for (int i = 0; i < 4; i++)
+            th[i].join();
+        for (int i = 0; i < 4; i++)
+            bad += memcmp(tout[i], out[0], 128) != 0;
+    }
+    printf("threads %d\n", bad);
     return 0;
 }
 """
@@ -142,7 +156,7 @@ def _build_cxx_client(tmp_path):
     src.write_text(CXX_CLIENT)
     exe = tmp_path / "client"
     libdir = os.path.dirname(os.path.abspath(os.environ.get("CVTTMI_LIB", api._LIB_PATH)))
-    subprocess.check_call(["g++", "-std=c++11", "-O1", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                            "-L", libdir, "-lcvtt_mi355x", "-Wl,-rpath," + libdir])
     return exe
 
@@ -177,3 +191,4 @@ def test_cxx_api_matches_oracle(tmp_path, oracle_lib, gpu_ctx):
     for k, w in enumerate(want):
         got = bytes.fromhex(lines[k])[:w.size]
         assert got == w.tobytes(), k
+    assert lines[10:12] == ["threads", "0"]  # four caller threads, a context each, same blocks as the main thread's
