@@ -543,7 +543,7 @@ struct UnitRec
 {
     float base[4];
     float offset[4];
-    u32 packed;  // mask | numTweak << 16 | blk << 20 | slot << 24  (slot = item * 3 + subset: where the subset's result goes)
+    u32 packed;  // mask | numTweak << 16 | blk << 20 | slot << 24  (slot = item * subsets + subset: where the subset's result goes)
     float scErr; // BC7_TrySingleColor: error of the fixed candidate (FLT_MAX when not tried)
     // the refiner's m_v of the subset: sum of the pre-weighted member pixels in ascending order (EndpointRefiner.h:78-92).
     // It does not depend on the indexes, so the seed lane takes it once for all chains and rounds of the unit.
@@ -1825,14 +1825,22 @@ __global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVE
                                                         const CvttBc7Args A, const CvttDeviceTables *__restrict__ T,
                                                         const CvttBc7DevicePlan *__restrict__ dplan)
 {
-    __shared__ float s_bound[64][16]; // error lower bound of every partition of the current mode, per block
+    // error lower bound of every partition of the current mode, per block: the upper 16 bits of the binary32 value
+    // (truncated, i.e. rounded down -- a bound may always be smaller).  Half the bytes of a float table: with that and 64
+    // result slots the kernel fits 8 LDS granules = 16 workgroups per CU = 4 waves per SIMD.
+    __shared__ unsigned short s_bound[64][16];
+    auto lbLoad = [&](int partition, int b) -> float { return __builtin_bit_cast(float, (u32)s_bound[partition][b] << 16); };
+    auto lbStore = [&](int partition, int b, float v) { s_bound[partition][b] = (unsigned short)(__builtin_bit_cast(u32, v) >> 16); };
+    // the same bytes as 32-bit words, [row][block], rows 1..16: where the dual-plane search parks its per-block invariants
+    // (row 0 of the 16-bit table, the mode-6 bound, lies below them)
+    u32 *const s_raw = reinterpret_cast<u32 *>(&s_bound[0][0]);
     __shared__ u32 s_pix[16][16];     // the 16 blocks of this wave
     __shared__ u32 s_blkFlags[16];    // wantPCA4 of the block's group
     __shared__ int s_scatter[16][14]; // raw sums (sum x per channel, sum x_r x_c) of every block: the scatter matrix of the bounds and the totals of the second tier come from here
     __shared__ u32 s_item[32];        // offers of the round: block | partition << 8
     __shared__ uint8_t s_myItems[16][32]; // the items a block offered this round
     __shared__ UnitRec s_unit[64];    // PCA seeds per (item, subset)
-    __shared__ u32 s_res[96][5];      // best of every (item, subset): error, endpoints, indexes
+    __shared__ u32 s_res[64][5];      // best of every (item, subset) = unit of the round: error, endpoints, indexes
     // BC7_RespectPunchThrough: the error of every trial (chain x refine round) of every unit of the round
     // [unit][chain][round], 32 x 16 x numRefine floats (punch-through instantiation only; up to kMaxPTRefine rounds)
     __shared__ float s_trialErr[PT ? 32 * 16 * kMaxPTRefine : 1];
@@ -1986,7 +1994,7 @@ __global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVE
             const float lbMode6 = shapeErrorLowerBound<4>(m, 16.0f, A.delta4);
             // mode 6 is the first single-plane stage: its bound waits where that stage looks for it
             if (c == 0)
-                s_bound[0][lane >> 2] = lbMode6;
+                lbStore(0, lane >> 2, lbMode6);
         }
         // rotation r codes channel r-1 (alpha for r = 0) on its own; the other three share a line
         if (!HARD)
@@ -2087,7 +2095,7 @@ __global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVE
             }
         }
         // what every configuration of a rotation would otherwise recompute (DualInv), per original channel: sub-lane ch
-        // takes channel ch and parks the five values in rows 1..20 of s_bound, which is idle until the partition bounds
+        // takes channel ch and parks the five values in rows 1..16 of s_raw (= s_bound), which is idle until the partition bounds
         // (row 0 holds the mode-6 bound); a step then reads the rows its rotation needs instead of holding 20 registers
         if (FAST)
         {
@@ -2113,10 +2121,10 @@ __global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVE
                     sw = sw + byteF(mine[g], k) * wc;
                 }
             }
-            s_bound[1 + c][lane >> 2] = __builtin_bit_cast(float, sq);
-            s_bound[5 + c][lane >> 2] = __builtin_bit_cast(float, (u32)mn | ((u32)mx << 8));
-            s_bound[9 + c][lane >> 2] = sw;
-            s_bound[13 + c][lane >> 2] = (float)(int)su; // exact
+            s_raw[(1 + c) * 16 + (lane >> 2)] = sq;
+            s_raw[(5 + c) * 16 + (lane >> 2)] = (u32)mn | ((u32)mx << 8);
+            s_raw[(9 + c) * 16 + (lane >> 2)] = __builtin_bit_cast(u32, sw);
+            s_raw[(13 + c) * 16 + (lane >> 2)] = __builtin_bit_cast(u32, (float)(int)su); // exact
             __syncthreads();
         }
         int curRotation = 0;
@@ -2209,13 +2217,13 @@ __global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVE
                 for (int ch = 0; ch < 3; ch++)
                 {
                     const int orig = (rotation == ch + 1) ? 3 : ch;
-                    inv.sumSq[ch] = __builtin_bit_cast(u32, s_bound[1 + orig][lane >> 2]);
-                    inv.vs[ch] = s_bound[9 + orig][lane >> 2];
+                    inv.sumSq[ch] = s_raw[(1 + orig) * 16 + (lane >> 2)];
+                    inv.vs[ch] = __builtin_bit_cast(float, s_raw[(9 + orig) * 16 + (lane >> 2)]);
                 }
-                inv.sumSq[3] = __builtin_bit_cast(u32, s_bound[1 + sepCh][lane >> 2]);
-                inv.vs[3] = s_bound[13 + sepCh][lane >> 2];
+                inv.sumSq[3] = s_raw[(1 + sepCh) * 16 + (lane >> 2)];
+                inv.vs[3] = __builtin_bit_cast(float, s_raw[(13 + sepCh) * 16 + (lane >> 2)]);
                 {
-                    const u32 mm = __builtin_bit_cast(u32, s_bound[5 + sepCh][lane >> 2]);
+                    const u32 mm = s_raw[(5 + sepCh) * 16 + (lane >> 2)];
                     inv.alphaMin = (int)(mm & 0xffu);
                     inv.alphaMax = (int)(mm >> 8);
                 }
@@ -2455,7 +2463,7 @@ __global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVE
                         }
                         if (!use4)
                             lb += staticAlphaBlock;
-                        s_bound[partition][blk] = lb;
+                        lbStore(partition, blk, lb);
                         freshAlive |= (lb > work.err) ? 0u : (1u << k);
                     }
                     freshBounds = true;
@@ -2487,7 +2495,7 @@ __global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVE
             else
             {
                 for (int k = 0; k * 4 < numPartitions; k++)
-                    if (s_bound[4 * k + c][blk] > work.err)
+                    if (lbLoad(4 * k + c, blk) > work.err)
                         aliveBits &= ~(1u << k);
             }
         }
@@ -2552,8 +2560,8 @@ __global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVE
                         }
                         if (!use4)
                             lb += staticAlphaBlock;
-                        if (lb > s_bound[partition][blk])
-                            s_bound[partition][blk] = lb;
+                        if (lb > lbLoad(partition, blk))
+                            lbStore(partition, blk, lb);
                         if (lb > work.err)
                             aliveBits &= ~(1u << k);
                     }
@@ -2636,7 +2644,7 @@ __global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVE
                 {
                     if ((aliveBits >> k) & 1u)
                     {
-                        const float lb = prune ? s_bound[4 * k + c][blk] : 0.0f;
+                        const float lb = prune ? lbLoad(4 * k + c, blk) : 0.0f;
                         if (lb < pickLb)
                         {
                             pickLb = lb;
@@ -2802,7 +2810,7 @@ __global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVE
 #pragma unroll
                 for (int ch = 0; ch < 4; ch++)
                     r.vs[ch] = vsum[ch];
-                r.packed = uMask | ((u32)(seeds < 0 ? 0 : seeds) << 16) | ((u32)ublk << 20) | ((u32)(item * 3 + sub) << 24);
+                r.packed = uMask | ((u32)(seeds < 0 ? 0 : seeds) << 16) | ((u32)ublk << 20) | ((u32)(item * numSubsets + sub) << 24);
                 float scErr = FLT_MAX;
                 if ((A.flags & CVTTMI_FLAG_BC7_TRY_SINGLE_COLOR) && seeds > 0)
                 {
@@ -3007,7 +3015,7 @@ __global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVE
                     u32 pIdxLo = 0, pIdxHi = 0;
                     for (int sub = 0; sub < numSubsets; sub++)
                     {
-                        const u32 *src = &s_res[item * 3 + sub][0];
+                        const u32 *src = &s_res[item * numSubsets + sub][0];
                         totalError = totalError + __builtin_bit_cast(float, src[0]);
                         const u32 e0 = src[1], e1 = src[2];
                         if (sub == 0) { pe[0][0] = e0; pe[0][1] = e1; }
