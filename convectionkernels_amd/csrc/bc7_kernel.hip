@@ -52,9 +52,14 @@ constexpr float kBoundGrid8 = 124.0f, kBoundLimit8 = 127.0f;
 #ifndef CVTT_GRID8_RGB
 #define CVTT_GRID8_RGB true
 #endif
-// minimum waves per SIMD the register allocator must leave room for (512 VGPR+AGPR / waves)
+// Waves per SIMD the register allocator must leave room for (512 VGPRs / waves).  4 since round 2: the kernel fits 8 LDS
+// granules (16-bit bound table, 64 result slots), and the dual-plane search reads the block's channel-major pixels, the
+// rotation's seeds and the per-block invariants from LDS where it uses them, which brought the 128-register build from
+// 43 spilled registers to 33.  Measured 3 -> 4 waves: RGBA noise 630 -> 672 Mblocks/s at 4096^2, opaque noise 136 -> 150,
+// smooth / photo-like / two-colour content +13 % (chain rounds are plain f32 arithmetic, which an EVEN number of resident
+// waves overlaps: profiles/r02/valu_order.txt).
 #ifndef CVTT_BC7_WAVES
-#define CVTT_BC7_WAVES 3
+#define CVTT_BC7_WAVES 4
 #endif
 // the same for the slow-indexing instantiation (Flags::Better / Ultra), whose three probes per pixel need more registers
 #ifndef CVTT_BC7_WAVES_SLOW
@@ -1026,13 +1031,18 @@ __device__ __forceinline__ u32 nibblesOf(u32 b4)
 // Invariants of the block in rotated channel order (DualInv): sum(px^2) per channel, min / max of the separately coded
 // channel, and the refiner's sums of the pre-weighted pixels sum(x * w) -- ContributeUnweightedPW adds the same 16 values
 // in the same order whatever the indexes are (EndpointRefiner.h:78-92), so the sum is taken once per block.
+// They wait in LDS (rows of 16 words, one word per block of the wave) and are read where they are used -- the pixel loop of
+// the search is the place with the fewest registers to spare: `rowSq[ch]` / `rowVs[ch]` = word offset of channel position
+// ch's sum(px^2) / refiner sum, `minMax` = min | max << 8 of the separately coded channel.
 struct DualInv
 {
-    u32 sumSq[4];
-    int alphaMin, alphaMax;
-    float vs[4]; // [3]: the separately coded channel, weight 1
+    const u32 *words; // s_raw + block index
+    int rowSq[4], rowVs[4];
+    u32 minMax;
 };
-__device__ __forceinline__ void evalDualFast(const u32 (&P)[4][4], const DualInv &inv, int mode, int indexSelector, const Unfinished &uRGB,
+// `sP`: the block's pixels in LDS, channel-major and already in rotated channel order: four words (channel positions 0..3)
+// per group g of four pixels, read again in every round (one 128-bit load per group) instead of living in 16 registers.
+__device__ __forceinline__ void evalDualFast(const u32 *sP, const DualInv &inv, int mode, int indexSelector, const Unfinished &uRGB,
                                              int numTweak, const float (&rw)[4], const float (&rwSq)[4],
                                              const float (&rrcpW)[4], u32 flags, const CvttDeviceTables *__restrict__ T,
                                              int numRefine, int lane, ShapeBest &bestRGB, ShapeBest &bestA)
@@ -1055,7 +1065,7 @@ __device__ __forceinline__ void evalDualFast(const u32 (&P)[4][4], const DualInv
     bestRGB.ep0 = bestRGB.ep1 = bestRGB.idxLo = bestRGB.idxHi = 0;
     bestA.ep0 = bestA.ep1 = bestA.idxLo = bestA.idxHi = 0;
 
-    const int alphaMin = inv.alphaMin, alphaMax = inv.alphaMax;
+    const int alphaMin = (int)(inv.minMax & 0xffu), alphaMax = (int)(inv.minMax >> 8);
 
     const int tweak = c;
     if (tweak < numTweak)
@@ -1132,12 +1142,16 @@ __device__ __forceinline__ void evalDualFast(const u32 (&P)[4][4], const DualInv
             v2f tt2 = {0.0f, 0.0f}, ts2 = {0.0f, 0.0f}; // {RGB plane, alpha plane}
             u32 rgbLo = 0, rgbHi = 0, aLo = 0, aHi = 0; // 4 bits per pixel
 
+            // an address the optimiser cannot see through: the loads stay inside the round (hoisted, they would hold 16
+            // registers again, and the 64 conversions with them)
+            const u32 *sPr = sP;
+            asm volatile("" : "+v"(sPr));
 #pragma unroll
             for (int g = 0; g < 4; g++)
             {
                 u32 iR4 = 0, iA4 = 0;
-                // fresh values for the optimiser (see fetchPixel): no hoisting of the 64 conversions out of the rounds
-                const u32 Pg[4] = {fetchPixel(P[0][g]), fetchPixel(P[1][g]), fetchPixel(P[2][g]), fetchPixel(P[3][g])};
+                const uint4 L = *reinterpret_cast<const uint4 *>(sPr + 4 * g);
+                const u32 Pg[4] = {L.x, L.y, L.z, L.w};
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                 {
@@ -1186,7 +1200,7 @@ __device__ __forceinline__ void evalDualFast(const u32 (&P)[4][4], const DualInv
             u32 err[4];
 #pragma unroll
             for (int ch = 0; ch < 4; ch++)
-                err[ch] = s2[ch] + inv.sumSq[ch] - 2u * s1[ch];
+                err[ch] = s2[ch] + inv.words[inv.rowSq[ch]] - 2u * s1[ch];
             float errorRGB, errorA;
             if (uniformErr)
             {
@@ -1221,7 +1235,9 @@ __device__ __forceinline__ void evalDualFast(const u32 (&P)[4][4], const DualInv
             if (!last)
             {
                 // EndpointRefiner<3> / <1>::GetRefinedEndpointsLDR, 16 contributions each
-                const float tv[4] = {tv01.x, tv01.y, tv23.x, tv23.y}, vs[4] = {inv.vs[0], inv.vs[1], inv.vs[2], inv.vs[3]};
+                const float tv[4] = {tv01.x, tv01.y, tv23.x, tv23.y};
+                const float vs[4] = {__builtin_bit_cast(float, inv.words[inv.rowVs[0]]), __builtin_bit_cast(float, inv.words[inv.rowVs[1]]),
+                                     __builtin_bit_cast(float, inv.words[inv.rowVs[2]]), __builtin_bit_cast(float, inv.words[inv.rowVs[3]])};
                 {
                     const float ttRGB = tt2.x, tsRGB = ts2.x;
                     float adenom = (ttRGB * 16.0f - tsRGB * tsRGB) * wRcp16;
@@ -1802,18 +1818,6 @@ __device__ __forceinline__ u32 everyFourth(u64 m, int c)
     return (u32)x;
 }
 
-// Broadcast the seeds computed by sub-lane `srcSub` of every quad to the whole quad.
-__device__ __forceinline__ void quadBroadcast(Unfinished &dst, const Unfinished &src, int lane, int srcSub)
-{
-    const int from = (lane & ~3) | srcSub;
-#pragma unroll
-    for (int ch = 0; ch < 4; ch++)
-    {
-        dst.base[ch] = __shfl(src.base[ch], from);
-        dst.offset[ch] = __shfl(src.offset[ch], from);
-    }
-}
-
 // HARD = false: the encoder.  A block whose mode-7 stage starts with at least A.hardMin partitions alive hands them to
 // the second launch (A.hardCap slots; none left: it searches them itself) and records its best without them.
 // HARD = true: the second launch.  kHardWaves (16) wavefronts per recorded block; each reloads the block's original wave
@@ -1821,7 +1825,8 @@ __device__ __forceinline__ void quadBroadcast(Unfinished &dst, const Unfinished 
 // best and leaves its best candidate, packed, in A.hardCand; cvttmi_bc7_hard_commit_kernel picks the winner.
 // Every candidate is compared by (error, position in the reference's order), so the split cannot change the result.
 template <bool FAST, bool PT, bool HARD>
-__global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVES_SLOW) void cvttmi_bc7_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+// (the punch-through instantiation holds 22 KB of LDS: two waves per SIMD is all that fits, so it may use their registers)
+__global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVES_SLOW) void cvttmi_bc7_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
                                                         const CvttBc7Args A, const CvttDeviceTables *__restrict__ T,
                                                         const CvttBc7DevicePlan *__restrict__ dplan)
 {
@@ -1840,7 +1845,9 @@ __global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVE
     __shared__ u32 s_item[32];        // offers of the round: block | partition << 8
     __shared__ uint8_t s_myItems[16][32]; // the items a block offered this round
     __shared__ UnitRec s_unit[64];    // PCA seeds per (item, subset)
-    __shared__ u32 s_res[64][5];      // best of every (item, subset) = unit of the round: error, endpoints, indexes
+    // best of every (item, subset) = unit of the round: error, endpoints, indexes.  (During the dual-plane search the same
+    // bytes hold the channel-major copy of the blocks, read with 128-bit loads.)
+    __shared__ __attribute__((aligned(16))) u32 s_res[64][5];
     // BC7_RespectPunchThrough: the error of every trial (chain x refine round) of every unit of the round
     // [unit][chain][round], 32 x 16 x numRefine floats (punch-through instantiation only; up to kMaxPTRefine rounds)
     __shared__ float s_trialErr[PT ? 32 * 16 * kMaxPTRefine : 1];
@@ -2073,36 +2080,49 @@ __global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVE
                 }
             pcaEndpoints<3>(rpix, 0xffffu, lw, -1, uRot);
         }
+        // the seeds of rotation r wait in s_unit[quad | r] (idle until the single-plane stages): a step reads the ones of its
+        // rotation from there instead of every lane keeping its own through all twelve steps
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++)
+        {
+            s_unit[lane].base[ch] = uRot.base[ch];
+            s_unit[lane].offset[ch] = uRot.offset[ch];
+        }
         PROF_MARK(0)
 
-        // fast indexing: channel-major copy of the block, P[ch][g] = channel ch of pixels 4g..4g+3; a rotation then is an
-        // exchange of four registers with four others instead of a byte shuffle of all sixteen pixels
-        u32 P[4][4];
-        if (FAST)
-        {
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-            {
-                const u32 a = pix[4 * g], b = pix[4 * g + 1], cc = pix[4 * g + 2], d = pix[4 * g + 3];
-                const u32 ab02 = __builtin_amdgcn_perm(b, a, 0x06020400u); // a0 b0 a2 b2
-                const u32 ab13 = __builtin_amdgcn_perm(b, a, 0x07030501u); // a1 b1 a3 b3
-                const u32 cd02 = __builtin_amdgcn_perm(d, cc, 0x06020400u);
-                const u32 cd13 = __builtin_amdgcn_perm(d, cc, 0x07030501u);
-                P[0][g] = __builtin_amdgcn_perm(cd02, ab02, 0x05040100u); // a0 b0 c0 d0
-                P[2][g] = __builtin_amdgcn_perm(cd02, ab02, 0x07060302u); // a2 b2 c2 d2
-                P[1][g] = __builtin_amdgcn_perm(cd13, ab13, 0x05040100u);
-                P[3][g] = __builtin_amdgcn_perm(cd13, ab13, 0x07060302u);
-            }
-        }
+        // fast indexing: the search reads a channel-major copy of the block -- per group g of four pixels one word per channel
+        // position, in the channel order of the rotation being searched -- from s_P (= s_res, idle until the single-plane
+        // stages; 20 words per block so that the 128-bit loads of a wave spread over the banks).  Sub-lane g builds group g
+        // from the pixel-major copy whenever the rotation changes (at most four times per wave).
+        u32 *const s_P = &s_res[0][0] + (lane >> 2) * 20;
+        auto writeRotated = [&](int rotation) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(&s_pix[lane >> 2][4 * c]);
+            const u32 ab02 = __builtin_amdgcn_perm(q.y, q.x, 0x06020400u); // a0 b0 a2 b2
+            const u32 ab13 = __builtin_amdgcn_perm(q.y, q.x, 0x07030501u); // a1 b1 a3 b3
+            const u32 cd02 = __builtin_amdgcn_perm(q.w, q.z, 0x06020400u);
+            const u32 cd13 = __builtin_amdgcn_perm(q.w, q.z, 0x07030501u);
+            u32 w0 = __builtin_amdgcn_perm(cd02, ab02, 0x05040100u); // a0 b0 c0 d0
+            u32 w2 = __builtin_amdgcn_perm(cd02, ab02, 0x07060302u); // a2 b2 c2 d2
+            u32 w1 = __builtin_amdgcn_perm(cd13, ab13, 0x05040100u);
+            u32 w3 = __builtin_amdgcn_perm(cd13, ab13, 0x07060302u);
+            // rotation r > 0 exchanges channel r - 1 with alpha (reference BC67.cpp:1695-1698)
+            if (rotation == 1) { const u32 t = w0; w0 = w3; w3 = t; }
+            if (rotation == 2) { const u32 t = w1; w1 = w3; w3 = t; }
+            if (rotation == 3) { const u32 t = w2; w2 = w3; w3 = t; }
+            *reinterpret_cast<uint4 *>(s_P + 4 * c) = make_uint4(w0, w1, w2, w3);
+        };
         // what every configuration of a rotation would otherwise recompute (DualInv), per original channel: sub-lane ch
         // takes channel ch and parks the five values in rows 1..16 of s_raw (= s_bound), which is idle until the partition bounds
-        // (row 0 holds the mode-6 bound); a step then reads the rows its rotation needs instead of holding 20 registers
+        // (row 0 of the 16-bit table holds the mode-6 bound); a step reads the rows its rotation needs
         if (FAST)
         {
+            __syncthreads(); // s_pix is complete
+            writeRotated(0);
+            __syncthreads();
             u32 mine[4];
 #pragma unroll
             for (int g = 0; g < 4; g++)
-                mine[g] = (c == 0) ? P[0][g] : (c == 1) ? P[1][g] : (c == 2) ? P[2][g] : P[3][g];
+                mine[g] = s_P[4 * g + c];
             const float wc = (c == 0) ? A.w[0] : (c == 1) ? A.w[1] : (c == 2) ? A.w[2] : A.w[3];
             u32 sq = 0, su = 0;
             int mn = 255, mx = 0;
@@ -2125,8 +2145,8 @@ __global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVE
             s_raw[(5 + c) * 16 + (lane >> 2)] = (u32)mn | ((u32)mx << 8);
             s_raw[(9 + c) * 16 + (lane >> 2)] = __builtin_bit_cast(u32, sw);
             s_raw[(13 + c) * 16 + (lane >> 2)] = __builtin_bit_cast(u32, (float)(int)su); // exact
-            __syncthreads();
         }
+        __syncthreads();
         int curRotation = 0;
 #ifdef CVTT_BC7_PROFILE
         float simKey[12], simErr[12];
@@ -2157,24 +2177,9 @@ __global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVE
             {
                 if (FAST)
                 {
-                    // undo the previous exchange, then exchange channel rotation-1 with channel 3
-#pragma unroll
-                    for (int pass = 0; pass < 2; pass++)
-                    {
-                        const int r = pass == 0 ? curRotation : rotation;
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++)
-                            if (r == ch + 1)
-                            {
-#pragma unroll
-                                for (int g = 0; g < 4; g++)
-                                {
-                                    const u32 t = P[ch][g];
-                                    P[ch][g] = P[3][g];
-                                    P[3][g] = t;
-                                }
-                            }
-                    }
+                    __syncthreads(); // everybody is done with the previous rotation's copy
+                    writeRotated(rotation);
+                    __syncthreads();
                 }
                 else
                 {
@@ -2207,27 +2212,32 @@ __global__ __launch_bounds__(64, (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVE
             PROF_COUNT(0, 16)
             PROF_COUNT(1, __popcll(__ballot(valid && c == 0 && !(((rotation == 0) ? lbRot[0] : (rotation == 1) ? lbRot[1] : (rotation == 2) ? lbRot[2] : lbRot[3]) > work.err))))
             Unfinished u;
-            quadBroadcast(u, uRot, lane, rotation);
+            {
+                const UnitRec &ur = s_unit[(lane & ~3) | rotation];
+#pragma unroll
+                for (int ch = 0; ch < 4; ch++)
+                {
+                    u.base[ch] = ur.base[ch];
+                    u.offset[ch] = ur.offset[ch];
+                }
+            }
             ShapeBest b, bA;
             if (FAST)
             {
                 DualInv inv;
                 const int sepCh = (rotation == 0) ? 3 : rotation - 1; // the original channel that is coded on its own
+                inv.words = s_raw + (lane >> 2);
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++)
                 {
                     const int orig = (rotation == ch + 1) ? 3 : ch;
-                    inv.sumSq[ch] = s_raw[(1 + orig) * 16 + (lane >> 2)];
-                    inv.vs[ch] = __builtin_bit_cast(float, s_raw[(9 + orig) * 16 + (lane >> 2)]);
+                    inv.rowSq[ch] = (1 + orig) * 16;
+                    inv.rowVs[ch] = (9 + orig) * 16;
                 }
-                inv.sumSq[3] = s_raw[(1 + sepCh) * 16 + (lane >> 2)];
-                inv.vs[3] = __builtin_bit_cast(float, s_raw[(13 + sepCh) * 16 + (lane >> 2)]);
-                {
-                    const u32 mm = s_raw[(5 + sepCh) * 16 + (lane >> 2)];
-                    inv.alphaMin = (int)(mm & 0xffu);
-                    inv.alphaMax = (int)(mm >> 8);
-                }
-                evalDualFast(P, inv, mode, indexSelector, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
+                inv.rowSq[3] = (1 + sepCh) * 16;
+                inv.rowVs[3] = (13 + sepCh) * 16;
+                inv.minMax = s_raw[(5 + sepCh) * 16 + (lane >> 2)];
+                evalDualFast(s_P, inv, mode, indexSelector, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
             }
             else
                 evalDual<FAST>(pix, mode, indexSelector, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
