@@ -2322,20 +2322,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             for (int px = 0; px < 16; px++)
                 pix[px] = rotatePixel(pix[px], curRotation);
         }
-        if (FAST)
-        {
-            // the pixel-major copy was dead during the search (registers); take it back from LDS
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-            {
-                const uint4 v = *reinterpret_cast<const uint4 *>(&s_pix[lane >> 2][4 * i]);
-                pix[4 * i + 0] = v.x;
-                pix[4 * i + 1] = v.y;
-                pix[4 * i + 2] = v.z;
-                pix[4 * i + 3] = v.w;
-            }
-        }
+        __syncthreads();
         PROF_MARK(1)
     }
 
@@ -2346,6 +2333,19 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     // of item c (per-lane shape mask), then the items are searched one after the other with the
     // shape wave-uniform.
     const int blk = lane >> 2;
+    // From here on the pixel-major block is read from LDS where it is needed (the bounds): 16 registers that the chain
+    // rounds, which have the fewest to spare, do not have to carry.
+    auto pixFromLds = [&](u32 (&px)[16]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&s_pix[blk][4 * i]);
+            px[4 * i + 0] = v.x;
+            px[4 * i + 1] = v.y;
+            px[4 * i + 2] = v.z;
+            px[4 * i + 3] = v.w;
+        }
+    };
     int boundsFor = -1; // which bound set s_bound holds: 0 = two subsets RGBA, 1 = two subsets RGB, 2 = three subsets RGB, 3 = mode 6
     int tier2For = -1;  // ... and for which set the second-tier bounds below have been merged into it,
     u32 tier2Done = 0;  // for which of this lane's partitions (bit k = partition 4k + c)
@@ -2355,10 +2355,12 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     if (prune)
     {
         u32 acc = 0;
+        u32 lpix[16];
+        pixFromLds(lpix);
 #pragma unroll
         for (int px = 0; px < 16; px++)
         {
-            const int d = 255 - byteI(pix[px], 3);
+            const int d = 255 - byteI(lpix[px], 3);
             acc = (u32)mad24(d, d, (int)acc);
         }
         staticAlphaBlock = ((A.flags & CVTTMI_FLAG_UNIFORM) ? (float)(int)acc : (float)(int)acc * A.wSq[3]) * 0.9999f;
@@ -2438,7 +2440,9 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                                 rs[i] = s_scatter[blk][10 + i];
                             scatterFromRaw(rs, rp, A, bsL);
                         }
-                        makeProjection(pix, bsL, A, use4, scale, P);
+                        u32 lpix[16];
+                        pixFromLds(lpix);
+                        makeProjection(lpix, bsL, A, use4, scale, P);
                     }
                     PROF_MARK(7)
                     for (int k = 0; k < 16; k++)
@@ -2539,7 +2543,11 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                         d.p[i] = s_scatter[blk][i] - a.p[i];
                 };
                 u32 CM[4][4];
-                channelMajor(pix, CM);
+                {
+                    u32 lpix[16];
+                    pixFromLds(lpix);
+                    channelMajor(lpix, CM);
+                }
                 // every lane walks its own list: as many rounds as the longest list, not as many as there are slots in use
                 u32 rem = todo;
                 while (__ballot(rem != 0) != 0)
