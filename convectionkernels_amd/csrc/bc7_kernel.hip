@@ -671,7 +671,9 @@ __device__ __forceinline__ u32 rotatePixel(u32 pk, int rotation)
 // (reference BC67.cpp:1725-1940): sub-lane c runs seed point c.  `pix` is already rotated so
 // that byte 3 is the separately coded channel; w/wSq/rcpW are rotated the same way.
 template <bool FAST>
-__device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int indexSelector, const Unfinished &uRGB,
+// `sP`: the block's 16 pixels in LDS, already rotated (byte 3 = the separately coded channel), read four at a time in every
+// round instead of living in 16 registers; `minMax` = min | max << 8 of the separately coded channel.
+__device__ __forceinline__ void evalDual(const u32 *sP, u32 minMax, int mode, int indexSelector, const Unfinished &uRGB,
                                          int numTweak, const float (&rw)[4], const float (&rwSq)[4],
                                          const float (&rrcpW)[4], u32 flags, const CvttDeviceTables *__restrict__ T,
                                          int numRefine, int lane, ShapeBest &bestRGB, ShapeBest &bestA)
@@ -697,14 +699,7 @@ __device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int ind
     bestRGB.ep0 = bestRGB.ep1 = bestRGB.idxLo = bestRGB.idxHi = 0;
     bestA.ep0 = bestA.ep1 = bestA.idxLo = bestA.idxHi = 0;
 
-    int alphaMin = byteI(pix[0], 3), alphaMax = alphaMin;
-#pragma unroll
-    for (int px = 1; px < 16; px++)
-    {
-        const int a = byteI(pix[px], 3);
-        alphaMin = a < alphaMin ? a : alphaMin;
-        alphaMax = a > alphaMax ? a : alphaMax;
-    }
+    const int alphaMin = (int)(minMax & 0xffu), alphaMax = (int)(minMax >> 8);
 
     const int tweak = c;
     if (tweak < numTweak)
@@ -785,10 +780,16 @@ __device__ __forceinline__ void evalDual(const u32 (&pix)[16], int mode, int ind
             v2f tt2 = {0.0f, 0.0f}, ts2 = {0.0f, 0.0f}; // {RGB plane, alpha plane}
             u32 rgbLo = 0, rgbHi = 0, aLo = 0, aHi = 0;
 
+            const u32 *sPr = sP; // opaque to the optimiser: the loads stay inside the round (see evalDualFast)
+            asm volatile("" : "+v"(sPr));
 #pragma unroll
             for (int px = 0; px < 16; px++)
             {
-                const u32 pk = fetchPixel(pix[px]);
+                u32 pk;
+                {
+                    const uint4 L = *reinterpret_cast<const uint4 *>(sPr + (px & ~3));
+                    pk = (px & 3) == 0 ? L.x : (px & 3) == 1 ? L.y : (px & 3) == 2 ? L.z : L.w;
+                }
                 const v2f x01 = {byteF(pk, 0), byteF(pk, 1)}, x23 = {byteF(pk, 2), byteF(pk, 3)};
                 const v2f p01 = (x01 - org01) * ax01, p23 = (x23 - org23) * ax23;
                 float dist = p01.x + p01.y;
@@ -2114,7 +2115,6 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         // what every configuration of a rotation would otherwise recompute (DualInv), per original channel: sub-lane ch
         // takes channel ch and parks the five values in rows 1..16 of s_raw (= s_bound), which is idle until the partition bounds
         // (row 0 of the 16-bit table holds the mode-6 bound); a step reads the rows its rotation needs
-        if (FAST)
         {
             __syncthreads(); // s_pix is complete
             writeRotated(0);
@@ -2147,7 +2147,13 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             s_raw[(13 + c) * 16 + (lane >> 2)] = __builtin_bit_cast(u32, (float)(int)su); // exact
         }
         __syncthreads();
-        int curRotation = 0;
+        // slow indexing reads the pixels pixel-major, rotated, from the same LDS bytes (written before its first step)
+        auto writeRotatedPixels = [&](int rotation) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(&s_pix[lane >> 2][4 * c]);
+            *reinterpret_cast<uint4 *>(s_P + 4 * c) = make_uint4(rotatePixel(q.x, rotation), rotatePixel(q.y, rotation),
+                                                                 rotatePixel(q.z, rotation), rotatePixel(q.w, rotation));
+        };
+        int curRotation = FAST ? 0 : -1;
 #ifdef CVTT_BC7_PROFILE
         float simKey[12], simErr[12];
         int simN = 0;
@@ -2183,9 +2189,9 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 }
                 else
                 {
-#pragma unroll
-                    for (int px = 0; px < 16; px++)
-                        pix[px] = rotatePixel(rotatePixel(pix[px], curRotation), rotation);
+                    __syncthreads();
+                    writeRotatedPixels(rotation);
+                    __syncthreads();
                 }
                 curRotation = rotation;
             }
@@ -2240,7 +2246,8 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 evalDualFast(s_P, inv, mode, indexSelector, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
             }
             else
-                evalDual<FAST>(pix, mode, indexSelector, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
+                evalDual<FAST>(s_P, s_raw[(5 + ((rotation == 0) ? 3 : rotation - 1)) * 16 + (lane >> 2)], mode, indexSelector, u, numTweak, rw, rwSq, rrcpW,
+                               A.flags, T, numRefine, lane, b, bA);
 
 #ifdef CVTT_BC7_DEBUG
             if (blockIdx.x * 16u + (u32)(lane >> 2) == g_bc7DbgBlock && c == 0)
@@ -2316,12 +2323,6 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             PROF_COUNT(7, evald)
         }
 #endif
-        if (!FAST && curRotation != 0)
-        {
-#pragma unroll
-            for (int px = 0; px < 16; px++)
-                pix[px] = rotatePixel(pix[px], curRotation);
-        }
         __syncthreads();
         PROF_MARK(1)
     }
