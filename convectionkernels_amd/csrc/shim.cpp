@@ -334,27 +334,29 @@ namespace
     }
 
     // The host-pointer entry points: `numBlocks` blocks of `inBpb` bytes in host memory -> `outBpb` bytes each in host
-    // memory through `launch(dOut, dIn, n, stream)`, in chunks of 2^16 blocks (4 MiB of PixelBlockU8) dealt to four pipeline slots with their own
-    // stream, so the PCIe transfers of neighbouring chunks run beside the kernels of the current one and the kernels of
-    // neighbouring chunks -- one wave per SIMD each -- fill the device together (launches that use the context's work
-    // buffers stay ordered through them).  Measured on 4096^2 BC7, page-locked / pageable caller memory, Mblocks/s:
-    // 2 slots x 2^17: 431 / 295; 3 x 2^16: 463 / 350; 4 x 2^16: 517 / 355; 4 x 2^17: 360 / 360 (CVTTMI_HOST_SLOTS,
-    // CVTTMI_HOST_CHUNK_LOG2 select other settings for experiments).  Page-locked caller memory (cvttmi_host_alloc /
+    // memory through `launch(dOut, dIn, n, stream)`, in chunks of 2^17 blocks (8 MiB of PixelBlockU8) dealt to pipeline slots with their own
+    // stream, so the PCIe transfers of neighbouring chunks run beside the kernels of the current one (launches that use the
+    // context's work buffers stay ordered through them).  Page-locked caller memory (cvttmi_host_alloc /
     // cvttmi_host_register) is transferred in place; pageable memory goes through the slots' pinned staging, the CPU copy
-    // of the next chunk overlapping the device work of the current one.
+    // of the next chunk overlapping the device work of the current one.  Measured on 4096^2 BC7 with the 4-wave kernel,
+    // median of 25 calls, page-locked / pageable, Mblocks/s: 2 slots x 2^17: 440 / 278; 4 x 2^17: 385 / 346; 4 x 2^16:
+    // 323 / 326 (best 471, unstable); 4 x 2^18: 359 / 317.  CVTTMI_HOST_SLOTS / CVTTMI_HOST_CHUNK_LOG2 select other settings.
     template <class Launch>
     int hostPipeline(cvttmi_context *ctx, uint8_t *out, const uint8_t *in, size_t numBlocks, size_t inBpb, size_t outBpb, Launch launch)
     {
-        static const int chunkLog2 = getenv("CVTTMI_HOST_CHUNK_LOG2") ? atoi(getenv("CVTTMI_HOST_CHUNK_LOG2")) : 16;
+        static const int chunkLog2 = getenv("CVTTMI_HOST_CHUNK_LOG2") ? atoi(getenv("CVTTMI_HOST_CHUNK_LOG2")) : 17;
         const size_t kChunk = (size_t)1 << (chunkLog2 < 10 ? 10 : chunkLog2 > 24 ? 24 : chunkLog2);
-        static const int slotsEnv = getenv("CVTTMI_HOST_SLOTS") ? atoi(getenv("CVTTMI_HOST_SLOTS")) : cvttmi_context::kPipeSlots;
-        const size_t kSlots = (size_t)(slotsEnv < 1 ? 1 : slotsEnv > cvttmi_context::kPipeSlots ? cvttmi_context::kPipeSlots : slotsEnv);
+        static const int slotsEnv = getenv("CVTTMI_HOST_SLOTS") ? atoi(getenv("CVTTMI_HOST_SLOTS")) : 0;
+        const bool inPinned = isPinnedHost(in) && isPinnedHost(in + numBlocks * inBpb - 1);
+        const bool outPinned = isPinnedHost(out) && isPinnedHost(out + numBlocks * outBpb - 1);
+        // page-locked caller memory: two slots keep the link and the device busy; pageable memory: four, so that the CPU
+        // copies into and out of the staging buffers overlap as well
+        const int slotsWanted = slotsEnv > 0 ? slotsEnv : (inPinned && outPinned ? 2 : cvttmi_context::kPipeSlots);
+        const size_t kSlots = (size_t)(slotsWanted > cvttmi_context::kPipeSlots ? cvttmi_context::kPipeSlots : slotsWanted);
         const size_t chunk = numBlocks < kChunk ? numBlocks : kChunk;
         int rc = ensurePipe(ctx, chunk * inBpb, chunk * outBpb);
         if (rc != CVTTMI_OK)
             return rc;
-        const bool inPinned = isPinnedHost(in) && isPinnedHost(in + numBlocks * inBpb - 1);
-        const bool outPinned = isPinnedHost(out) && isPinnedHost(out + numBlocks * outBpb - 1);
         const size_t numChunks = (numBlocks + chunk - 1) / chunk;
         hipError_t e;
         auto finish = [&](size_t c) -> int {
