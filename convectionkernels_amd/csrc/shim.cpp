@@ -1170,9 +1170,12 @@ extern "C"
         args.flags = options->flags;
         args.refineRounds = options->refineRoundsBC6H;
         args.seedPoints = options->seedPoints;
-        // the endpoint-history scratch is sized for one launch; large batches go in chunks of
-        // 2^18 blocks (75 MB of scratch) on the same stream
-        const size_t kChunk = 1u << 18;
+        // the endpoint-history scratch is sized for one launch (21.5 KB per wave of 64 blocks); large batches go in chunks of
+        // 2^20 blocks (352 MB of scratch, allocated on first use) on the same stream.  A chunk should be many waves per SIMD:
+        // launches are stream-ordered, so every chunk ends with a tail in which the SIMDs run empty -- 2^18-block chunks
+        // (4 096 waves = one generation at 4 waves per SIMD) measured 4.31 Mblocks/s on 4096^2, 2^20-block chunks 4.95.
+        static const int bc6hChunkLog2 = getenv("CVTTMI_BC6H_CHUNK_LOG2") ? atoi(getenv("CVTTMI_BC6H_CHUNK_LOG2")) : 20;
+        const size_t kChunk = (size_t)1 << (bc6hChunkLog2 < 12 ? 12 : bc6hChunkLog2 > 24 ? 24 : bc6hChunkLog2);
         const size_t need = cvttmi_bc6h_scratch_bytes(static_cast<uint32_t>(numBlocks < kChunk ? numBlocks : kChunk));
         if (ctx->dScratchBytes < need)
         {
