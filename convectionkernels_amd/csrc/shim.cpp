@@ -1380,6 +1380,23 @@ extern "C"
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
         std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+        // Page-locked caller memory on both sides: the search reads the PixelBlocks straight from host memory and writes
+        // the packed blocks straight back (one launch over the whole batch, each wave one contiguous 1 KiB read and one
+        // 256-byte write over PCIe) -- no staging, no chunking.
+        static const bool zeroCopy = !(getenv("CVTTMI_HOST_ZEROCOPY") && atoi(getenv("CVTTMI_HOST_ZEROCOPY")) == 0);
+        if (zeroCopy && isPinnedHost(blocks) && isPinnedHost(blocks + numBlocks * 64 - 1) && isPinnedHost(out) && isPinnedHost(out + numBlocks * 16 - 1))
+        {
+            void *dIn = NULL, *dOut = NULL;
+            if (hipHostGetDevicePointer(&dIn, const_cast<uint8_t *>(blocks), 0) == hipSuccess && hipHostGetDevicePointer(&dOut, out, 0) == hipSuccess)
+            {
+                const int rc = cvttmi_encode_bc7_device(ctx, dOut, dIn, numBlocks, options, plan, ctx->stream);
+                if (rc != CVTTMI_OK)
+                    return rc;
+                e = hipStreamSynchronize(ctx->stream);
+                return e == hipSuccess ? CVTTMI_OK : fail(ctx, CVTTMI_E_HIP, "kernel execution", e);
+            }
+            (void)hipGetLastError();
+        }
         return hostPipeline(ctx, reinterpret_cast<uint8_t *>(out), reinterpret_cast<const uint8_t *>(blocks), numBlocks, 64, 16,
                             [&](void *dOut, const void *dIn, size_t n, hipStream_t st) { return cvttmi_encode_bc7_device(ctx, dOut, dIn, n, options, plan, st); });
     }
