@@ -2382,6 +2382,11 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         }
         if (HARD && stageIter != 1)
             continue; // the second launch searches mode-7 partitions only
+        // A wave without a single translucent pixel: the RGBA bounds of mode 7 would equal the RGB bounds of modes 1 / 3
+        // (no variance in alpha; the colour part of a trial's error is bounded by the three-channel bound whatever alpha
+        // does), so mode 7 takes the RGB set and the next stage finds its bounds already there.
+        if (stageIter == 1 && ballotA == 0)
+            boundSet = 1;
         const int mode = md.mode;
         const bool isRGB = mode < 4;
         // does this mode run for my group?  (wave-uniform skip when it runs for nobody -- before the plan is read: a
