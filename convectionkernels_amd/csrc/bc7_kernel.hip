@@ -1888,8 +1888,16 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     }
     const u32 blockIndex = (HARD ? (hardBlock & ~15u) : blockIdx.x * 16u) + (u32)(lane >> 2);
     const bool inRange = blockIndex < A.numBlocks;
+    // The per-lane predicates of the search live as bits of one register (`lf`) rather than as one lane mask each: the
+    // scalar registers a mask takes (two each, for the whole kernel) are what the register allocator runs out of first.
+    enum : u32 { LF_VALID = 1u, LF_ANY_ALPHA = 2u, LF_ALLOW_RGB = 4u, LF_ALLOW_M7 = 8u, LF_NONMAX_ALPHA = 16u };
     // HARD: the neighbours are loaded for the group-wide booleans only
-    const bool valid = inRange && (!HARD || blockIndex == hardBlock);
+    u32 lf = (inRange && (!HARD || blockIndex == hardBlock)) ? LF_VALID : 0u;
+#define valid ((lf & LF_VALID) != 0)
+#define anyBlockHasAlpha ((lf & LF_ANY_ALPHA) != 0)
+#define allowRGBModes ((lf & LF_ALLOW_RGB) != 0)
+#define allowMode7 ((lf & LF_ALLOW_M7) != 0)
+#define blockHasNonMaxAlpha ((lf & LF_NONMAX_ALPHA) != 0)
 
     PROF_DECL
     u32 pix[16];
@@ -1920,15 +1928,15 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         const int a = byteI(pix[px], 3);
         minAlpha = a < minAlpha ? a : minAlpha;
     }
-    const bool blockHasNonMaxAlpha = minAlpha < 255;
-    const u64 ballotA = __ballot(blockHasNonMaxAlpha);
+    lf |= (minAlpha < 255) ? LF_NONMAX_ALPHA : 0u;
+    const u64 ballotA = __ballot(minAlpha < 255);
     const u64 ballotR = __ballot(250 < minAlpha);
     const u32 groupA = (lane < 32) ? (u32)ballotA : (u32)(ballotA >> 32);
     const u32 groupR = (lane < 32) ? (u32)ballotR : (u32)(ballotR >> 32);
-    const bool anyBlockHasAlpha = groupA != 0;
-    const bool allowRGBModes = groupR != 0;
+    lf |= (groupA != 0) ? LF_ANY_ALPHA : 0u;
+    lf |= (groupR != 0) ? LF_ALLOW_RGB : 0u;
     const u64 mode7RGB = plan->mode7RGBPartitionEnabled;
-    const bool allowMode7 = anyBlockHasAlpha || (mode7RGB != 0);
+    lf |= (groupA != 0 || mode7RGB != 0) ? LF_ALLOW_M7 : 0u;
     // RGBA seeds: PCA over 4 channels when the group has alpha or no RGB modes, otherwise the
     // RGB seeds extended with alpha = 255 (reference BC67.cpp:1113-1144)
     const bool wantPCA4 = anyBlockHasAlpha || !allowRGBModes;
@@ -1961,21 +1969,20 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     // commits on a strict '<', i.e. it keeps the FIRST candidate that reaches the minimum.
     // We evaluate in a different order, so every candidate carries its position `seq` in the
     // reference's order and the commit compares (error, seq) lexicographically.
-    WorkState work;
+    // What is carried through the search is small: the error, `seq` -- which also names the mode, the partition or index
+    // selector and the rotation (decoded when the block is packed) -- and the payload of the best candidate (three endpoint
+    // pairs, 64 index bits), of which every lane of the quad keeps a quarter: sub-lane s < 3 the endpoints of subset s,
+    // sub-lane 3 the indexes.  All four lanes take the same commit decisions, so the quarters always belong together.
+    struct { float err; } work;
     work.err = HARD ? hardErr : FLT_MAX;
     int workSeq = HARD ? hardSeq : -1; // nothing committed yet: a candidate must beat FLT_MAX strictly
-    work.mode = 0;
-    work.partOrIS = 0;
-    work.rotation = 0;
-#pragma unroll
-    for (int s = 0; s < 3; s++)
-        work.ep[s][0] = work.ep[s][1] = 0;
-    work.idxLo = work.idxHi = work.idx2Lo = work.idx2Hi = 0;
+    u32 workPay0 = 0, workPay1 = 0;
 
     // ------------- whole-block scatter matrix: bounds for mode 6 and the four rotations -------------
     const bool prune = !HARD && A.prune != 0; // HARD: the bounds have been applied by the first launch
     BlockScatter bs;
-    float lbRot[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float lbRotMine = 0.0f; // sub-lane r: the bound of rotation r
+    auto lbRotOf = [&](int rotation) -> float { return __shfl(lbRotMine, (lane & ~3) | rotation); };
     int rotOrder[4] = {0, 1, 2, 3};
     if (prune)
     {
@@ -2023,10 +2030,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             m.cov[4] = pick(tri(2, 1), tri(3, 2), tri(3, 2), tri(3, 1)); // (c', b)
             m.cov[5] = pick(tri(2, 2), tri(3, 3), tri(3, 3), tri(3, 3)); // (c', c')
 #undef pick
-            const float mine = shapeErrorLowerBound<3>(m, 16.0f, c == 0 ? d0 : c == 1 ? d1 : c == 2 ? d2 : d3);
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                lbRot[r] = __shfl(mine, (lane & ~3) | r);
+            lbRotMine = shapeErrorLowerBound<3>(m, 16.0f, c == 0 ? d0 : c == 1 ? d1 : c == 2 ? d2 : d3);
         }
         // search the rotations in the order of their bounds summed over the wave: the likely
         // winner first, so that the others meet a tight best error
@@ -2034,7 +2038,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #pragma unroll
         for (int r = 0; r < 4 && !HARD; r++)
         {
-            float t = valid ? lbRot[r] : 0.0f;
+            float t = valid ? lbRotOf(r) : 0.0f;
 #pragma unroll
             for (int step = 1; step < 64; step <<= 1)
                 t += __shfl_xor(t, step);
@@ -2174,7 +2178,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             if (prune)
             {
                 // the second plane costs >= 0, the first at least the bound of its three channels
-                const float lb = (rotation == 0) ? lbRot[0] : (rotation == 1) ? lbRot[1] : (rotation == 2) ? lbRot[2] : lbRot[3];
+                const float lb = lbRotOf(rotation);
                 if (__ballot(valid && !(lb > work.err)) == 0)
                     continue;
             }
@@ -2216,7 +2220,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 }
 
             PROF_COUNT(0, 16)
-            PROF_COUNT(1, __popcll(__ballot(valid && c == 0 && !(((rotation == 0) ? lbRot[0] : (rotation == 1) ? lbRot[1] : (rotation == 2) ? lbRot[2] : lbRot[3]) > work.err))))
+            PROF_COUNT(1, __popcll(__ballot(valid && c == 0 && !(lbRotOf(rotation) > work.err))))
             Unfinished u;
             {
                 const UnitRec &ur = s_unit[(lane & ~3) | rotation];
@@ -2261,7 +2265,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             const int seq = 384 + cfg;
 #ifdef CVTT_BC7_PROFILE
             {
-                const float lbp = (rotation == 0) ? lbRot[0] : (rotation == 1) ? lbRot[1] : (rotation == 2) ? lbRot[2] : lbRot[3];
+                const float lbp = lbRotOf(rotation);
                 const bool needed = valid && c == 0 && !(lbp > work.err);
                 PROF_COUNT(6, (needed && (bA.err + lbp > work.err)) ? 1 : 0)
                 if (needed && simN < 12)
@@ -2276,26 +2280,12 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             {
                 work.err = combined;
                 workSeq = seq;
-                work.mode = mode;
-                work.rotation = rotation;
-                work.partOrIS = indexSelector;
-                work.ep[0][0] = b.ep0 | bA.ep0;
-                work.ep[0][1] = b.ep1 | bA.ep1;
-                if (indexSelector)
-                {
-                    // index selector 1: the 2-bit set is the alpha plane (BC67.cpp:1953-1957)
-                    work.idxLo = bA.idxLo;
-                    work.idxHi = bA.idxHi;
-                    s_unit[lane >> 2].parkedIdx2[0] = b.idxLo;
-                    s_unit[lane >> 2].parkedIdx2[1] = b.idxHi;
-                }
-                else
-                {
-                    work.idxLo = b.idxLo;
-                    work.idxHi = b.idxHi;
-                    s_unit[lane >> 2].parkedIdx2[0] = bA.idxLo;
-                    s_unit[lane >> 2].parkedIdx2[1] = bA.idxHi;
-                }
+                // index selector 1: the 2-bit set is the alpha plane (BC67.cpp:1953-1957)
+                const u32 iLo = indexSelector ? bA.idxLo : b.idxLo, iHi = indexSelector ? bA.idxHi : b.idxHi;
+                workPay0 = (c == 0) ? (b.ep0 | bA.ep0) : (c == 3) ? iLo : 0u;
+                workPay1 = (c == 0) ? (b.ep1 | bA.ep1) : (c == 3) ? iHi : 0u;
+                s_unit[lane >> 2].parkedIdx2[0] = indexSelector ? b.idxLo : bA.idxLo;
+                s_unit[lane >> 2].parkedIdx2[1] = indexSelector ? b.idxHi : bA.idxHi;
             }
         }
 #ifdef CVTT_BC7_PROFILE
@@ -3056,16 +3046,8 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     {
                         work.err = totalError;
                         workSeq = seq;
-                        work.mode = mode;
-                        work.partOrIS = partition;
-#pragma unroll
-                        for (int sub = 0; sub < 3; sub++)
-                        {
-                            work.ep[sub][0] = pe[sub][0];
-                            work.ep[sub][1] = pe[sub][1];
-                        }
-                        work.idxLo = pIdxLo;
-                        work.idxHi = pIdxHi;
+                        workPay0 = (c == 0) ? pe[0][0] : (c == 1) ? pe[1][0] : (c == 2) ? pe[2][0] : pIdxLo;
+                        workPay1 = (c == 0) ? pe[0][1] : (c == 1) ? pe[1][1] : (c == 2) ? pe[2][1] : pIdxHi;
                     }
                 }
             }
@@ -3078,17 +3060,38 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #endif
     // ===================== fix-ups + bit packing (reference BC67.cpp:2003-2203) ==========
     {
-        const int mode = work.mode;
+        // the winner: seq = stage * 64 + partition for the single-plane modes (stages 0..5 = modes 0, 1, 2, 3, 6, 7),
+        // 384 + rotation * 2 + index selector for mode 4, 392 + rotation for mode 5; nothing committed: mode 0, all zero
+        WorkState packed;
+        {
+            const int sq = workSeq < 0 ? 0 : workSeq;
+            const int cfg = sq - 384;
+            const int stage = sq >> 6;
+            packed.mode = (sq >= 392) ? 5 : (sq >= 384) ? 4 : (stage >= 4) ? stage + 2 : stage;
+            packed.partOrIS = (sq >= 392) ? 0 : (sq >= 384) ? (cfg & 1) : (sq & 63);
+            packed.rotation = (sq >= 392) ? cfg - 8 : (sq >= 384) ? (cfg >> 1) : 0;
+            const int q = lane & ~3;
+            packed.ep[0][0] = __shfl(workPay0, q);
+            packed.ep[0][1] = __shfl(workPay1, q);
+            packed.ep[1][0] = __shfl(workPay0, q | 1);
+            packed.ep[1][1] = __shfl(workPay1, q | 1);
+            packed.ep[2][0] = __shfl(workPay0, q | 2);
+            packed.ep[2][1] = __shfl(workPay1, q | 2);
+            packed.idxLo = __shfl(workPay0, q | 3);
+            packed.idxHi = __shfl(workPay1, q | 3);
+            packed.idx2Lo = packed.idx2Hi = 0;
+        }
+        const int mode = packed.mode;
         u32 w0, w1, w2, w3;
         if (mode == 4 || mode == 5)
         {
-            work.idx2Lo = s_unit[lane >> 2].parkedIdx2[0];
-            work.idx2Hi = s_unit[lane >> 2].parkedIdx2[1];
+            packed.idx2Lo = s_unit[lane >> 2].parkedIdx2[0];
+            packed.idx2Hi = s_unit[lane >> 2].parkedIdx2[1];
         }
         if (mode == 4)
-            packDualPlane<4>(work, w0, w1, w2, w3);
+            packDualPlane<4>(packed, w0, w1, w2, w3);
         else if (mode == 5)
-            packDualPlane<5>(work, w0, w1, w2, w3);
+            packDualPlane<5>(packed, w0, w1, w2, w3);
         else
         {
         // mode description bit-fields (BC7 format)
@@ -3114,17 +3117,17 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             }
         constexpr bool separateAlpha = false; // modes 4 and 5 have gone to packDualPlane; their branches below fold away
         const bool combinedAlpha = (mode == 6 || mode == 7);
-        const int partition = work.partOrIS;
-        const int indexSelector = work.partOrIS;
+        const int partition = packed.partOrIS;
+        const int indexSelector = packed.partOrIS;
 
-        u64 idx = ((u64)work.idxHi << 32) | work.idxLo;
-        u64 idx2 = ((u64)work.idx2Hi << 32) | work.idx2Lo;
+        u64 idx = ((u64)packed.idxHi << 32) | packed.idxLo;
+        u64 idx2 = ((u64)packed.idx2Hi << 32) | packed.idx2Lo;
         u32 ep[3][2];
 #pragma unroll
         for (int s = 0; s < 3; s++)
         {
-            ep[s][0] = work.ep[s][0];
-            ep[s][1] = work.ep[s][1];
+            ep[s][0] = packed.ep[s][0];
+            ep[s][1] = packed.ep[s][1];
         }
         const u64 ones = 0x1111111111111111ull;
         int fix1 = 0, fix2 = 0;
@@ -3229,7 +3232,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         {
             if (c == 1)
             {
-                put((u32)work.rotation, epBase, 2);
+                put((u32)packed.rotation, epBase, 2);
                 if (mode == 4)
                     put((u32)indexSelector, epBase + 2, 1);
             }
@@ -3345,6 +3348,11 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     }
     PROF_MARK(5)
     PROF_FLUSH
+#undef valid
+#undef anyBlockHasAlpha
+#undef allowRGBModes
+#undef allowMode7
+#undef blockHasNonMaxAlpha
 }
 
 // Third launch: the winner among the recorded best of a handed-over block and the candidates of its partition slices.
