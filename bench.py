@@ -36,11 +36,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # algorithmic (compulsory) bytes per block, SURVEY.md 8(d): PixelBlock in + packed block out
 ALGO_BYTES = {"bc7": 80, "bc1": 72, "bc6hu": 144, "etc2rgba": 80}
-# VALU issue (profiles/r02/valu_peak.json, tools/valu_peak.hip): one SIMD issues one wave64 VALU instruction per 4
-# cycles from its main pipe; a second instruction of ANOTHER wave overlaps it when one of the two is a plain f32
-# add/sub/mul/fma or a move (or both are integer add/sub/logic/right-shift/select) -- never with packed, 24-bit multiply,
-# dot, SDWA, DPP or lane-access instructions.  So 1 per 4 cycles is what any mix reaches, 2 per 4 cycles the ceiling.
-VALU_CYCLES_PER_INST = 4.0
+# VALU issue peak: MI355X_MICROARCH.md ("Wave scheduling"): a wave64 VALU instruction occupies its SIMD for 2 cycles, i.e.
+# 256 CUs x 4 SIMDs x clock / 2 wave-instructions per second.  (tools/valu_peak.hip, profiles/r02/valu_peak.json, measures
+# how close real instruction mixes come: 2.3 cycles for pairs of waves whose instructions can overlap -- plain f32
+# add/sub/mul/fma, moves, integer add/logic -- and 4.2-4.4 for everything else: packed, 24-bit multiply, dot, SDWA, DPP.)
+VALU_CYCLES_PER_INST = 2.0
 SHADER_CLOCK_HZ = 2.4e9
 
 
@@ -177,10 +177,41 @@ def run_sharded(args):
     def exchange(i, buf):
         return sharding.gather_to_root(outs[buf], ranges, full[buf], root=0, async_op=True)
 
+    # Every timed step's gathered image is checked, not only the last one: once the gather of step i has landed, rank 0
+    # takes one wrap-around 64-bit sum per shard slice of the gathered buffer (a misplaced, missing or stale shard changes
+    # its slice's sum) into row i of `sums`; after the run every row must equal the last step's, whose whole 256 MiB are
+    # SHA-256-checked against the reference's.  On the GPU the sums run on a side stream next to the following step's search.
+    sums = torch.zeros((max(1, args.steps), n_ranks), dtype=torch.int64, device=dev) if rank == 0 else None
+    side = None if (args.dry_run or rank != 0) else torch.cuda.Stream(device=dev)
+    side_done = [None, None]
+
+    def check_step(i, buf):
+        if rank != 0:
+            return
+        def take():
+            for r, (a, b) in enumerate(ranges):
+                if b > a:
+                    sums[i, r] = full[buf][a:b].reshape(-1).view(torch.int64).sum()
+        if side is None:
+            take()
+            return
+        side.wait_stream(torch.cuda.current_stream())  # the gather's completion was queued on the current stream
+        with torch.cuda.stream(side):
+            take()
+            ev = torch.cuda.Event()
+            ev.record(side)
+        side_done[buf] = ev
+
+    def before_reuse(buf):
+        if side_done[buf] is not None:
+            torch.cuda.current_stream().wait_event(side_done[buf])
+            side_done[buf] = None
+
     sharding.pipelined_steps(args.warmup, lambda i, buf: encode(outs[buf]), exchange)
     evs = None if args.dry_run else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def encode_step(i, buf):
+        before_reuse(buf)
         if evs:
             evs[i][0].record()
         encode(outs[buf])
@@ -189,7 +220,9 @@ def run_sharded(args):
 
     sync()
     t0 = time.perf_counter()
-    sharding.pipelined_steps(args.steps, encode_step, exchange)
+    sharding.pipelined_steps(args.steps, encode_step, exchange, after_exchange=check_step)
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
     sync()
     elapsed = time.perf_counter() - t0
     if n_ranks > 1:
@@ -203,6 +236,13 @@ def run_sharded(args):
         got = last.cpu().numpy()
         digest = sha256(got)
         check = {"sha256": digest}
+        if args.steps > 0:
+            sm = sums.cpu().numpy()
+            same = int((sm == sm[args.steps - 1]).all(axis=1).sum())
+            check["steps_checked"] = int(args.steps)
+            check["steps_equal_to_last"] = same
+            check["every_step_identical"] = same == args.steps
+            check["per_step_check"] = "64-bit sum per shard slice of every step's gathered image, compared with the last step's (which is hashed whole)"
         if args.dry_run:
             whole = torch.from_numpy(synth.tile_blocks(synth.image_rgba8(seed, size, size, opaque=args.opaque)))
             check["matches_single_process"] = bool((stand_in_encoder(whole).numpy() == got).all())
@@ -241,7 +281,15 @@ def run_sharded(args):
             achieved = ALGO_BYTES["bc7"] * nloc / (k_ms * 1e-3) / 1e9
             result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                   "traffic": None, "kernel": "cvttmi_bc7_kernel", "kernel_ms": k_ms,
-                                  "note": "rank 0's shard (%d blocks) per launch; VALU-bound search, see the N=1 line for the issue-rate figures" % nloc}
+                                  "note": "rank 0's shard (%d blocks) per launch; VALU-bound search, see the N=1 line for the issue-rate figures and the PMC traffic" % nloc}
+            result["rank0_search_mblocks_s"] = nloc / k_ms / 1e3
+            if not args.no_cpu:
+                # the CPU path on a bounded sample of rank 0's shard (the golden RCPPS table is in use on every rank)
+                opt_b = np.frombuffer(api.Options().tobytes(), np.uint8).copy()
+                plan_b = np.frombuffer(api.BC7EncodingPlan().tobytes(), np.uint8).copy()
+                result["cpu_baseline"] = cpu_baseline("bc7", shard, got[lo:hi], opt_b, plan_b, golden_rcp(h), budget_one=2.0, budget_all=6.0)
+                result["cpu_baseline"]["host"] = host_info()
+                result["bit_exact_vs_cpu"] = result["cpu_baseline"]["gpu_mismatching_blocks"] == 0
         print(json.dumps(result), flush=True)
     if n_ranks > 1:
         dist.barrier()
@@ -353,10 +401,12 @@ def profiled_counters(lib_sha):
         d = json.load(open(files[-1]))
         if d.get("kernel_object_sha256") != lib_sha:
             return {"stale": True, "source": os.path.relpath(files[-1], ROOT)}
-        sq = d["pmc_sq"][0]
+        sq = d["pmc_sq"][0]  # the dominant kernel (tools/summarize_pmc.py sorts by total duration)
         return {"source": os.path.relpath(files[-1], ROOT),
+                "kernel": sq["kernel"],
                 "hbm_bytes_per_launch": d["hbm_traffic_bytes_per_launch"]["bytes_corrected"],
                 "valu_insts_per_wave": sq["derived"]["valu_insts_per_wave"],
+                "avg_waves_per_simd": sq["derived"].get("avg_waves_per_simd(WAVE_CYCLES*4/simd_cycles)"),
                 "blocks": int(sq["grid"]) // 4}
     except Exception:  # noqa
         return None
@@ -441,14 +491,16 @@ def run_single(args):
         result["profile_note"] = "%s was taken with a different kernel object: traffic / valu_issue omitted" % pmc["source"]
     elif pmc and pmc["blocks"] == nblk and not args.exhaustive and not args.opaque:
         result["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9
+        result["roofline"]["traffic_bytes_per_launch"] = pmc["hbm_bytes_per_launch"]
+        result["roofline"]["traffic_over_algorithmic"] = pmc["hbm_bytes_per_launch"] / float(ALGO_BYTES["bc7"] * nblk)
         result["roofline"]["traffic_source"] = pmc["source"]
         waves = (nblk + 15) // 16
         rate = waves * pmc["valu_insts_per_wave"] / (k_ms * 1e-3)
-        peak1 = 256 * 4 * SHADER_CLOCK_HZ / VALU_CYCLES_PER_INST
+        peak = 256 * 4 * SHADER_CLOCK_HZ / VALU_CYCLES_PER_INST
         result["valu_issue"] = {"insts_per_wave": pmc["valu_insts_per_wave"], "achieved": rate, "unit": "wave-instructions/s",
-                                "peak": peak1, "frac": rate / peak1, "peak_with_cross_wave_overlap": 2 * peak1, "frac_of_overlap_peak": rate / (2 * peak1),
-                                "source": pmc["source"], "peak_source": "profiles/r02/valu_peak.json (measured: 4.2-4.4 cycles per wave64 instruction per SIMD for "
-                                "most kinds, ~2.3 for pairs of overlappable kinds from two waves)"}
+                                "peak": peak, "frac": rate / peak, "avg_waves_per_simd": pmc.get("avg_waves_per_simd"),
+                                "source": pmc["source"],
+                                "peak_source": "MI355X_MICROARCH.md: one wave64 VALU instruction per SIMD per 2 cycles at %.1f GHz" % (SHADER_CLOCK_HZ / 1e9)}
 
     if not args.no_extra and not args.exhaustive:
         # ---- sustained rate: >= 3 s of back-to-back encodes, shader clock sampled while they run
@@ -498,7 +550,17 @@ def run_single(args):
         if hp:
             result["host_path"] = hp
         result["configs"] = per_config_legs(torch, api, synth, ctx, dev, h, rcp, rcp_gold, same_lut, args)
-        result["content_families"] = family_legs(torch, api, synth, ctx, dev)
+        result["content_families"] = family_legs(torch, api, synth, ctx, dev, rcp, args.no_cpu)
+        # the one-GPU rate on the workload the N > 1 runs shard (one 16384^2 image): the base of a strong-scaling curve
+        base = result["configs"].get("5a_bc7_16384")
+        if base:
+            result["scale_base"] = {"mblocks_s": base["mblocks_s"], "kernel_ms": base["kernel_ms"], "n_gpus": 1,
+                                    "workload": "config 5a: the 16384x16384 image of the N > 1 runs on one GPU (same job as `bench.py --gpus N`, N = 1)",
+                                    "sha256_matches_reference": base.get("sha256_matches_reference")}
+            result["scale_base_mblocks_s"] = base["mblocks_s"]
+        db = dropin_8block_leg()
+        if db:
+            result["dropin_8block"] = db
     print(json.dumps(result), flush=True)
     return result
 
@@ -548,15 +610,73 @@ def per_config_legs(torch, api, synth, ctx, dev, h, rcp, rcp_gold, same_lut, arg
     return legs
 
 
-def family_legs(torch, api, synth, ctx, dev, n=1 << 20):
-    """EncodeBC7 (default plan) on eight kinds of content: the pruning, and with it the rate, depends on the content."""
+def family_legs(torch, api, synth, ctx, dev, rcp, no_cpu, n=1 << 20, check=1 << 15):
+    """EncodeBC7 (default plan) on eight kinds of content: the pruning, and with it the rate, depends on the content.
+    Every family's output is compared with the CPU path on its first `check` blocks (`mismatches_vs_cpu`)."""
     res = {}
+    opt, plan = api.Options(), api.BC7EncodingPlan()
+    ob = np.frombuffer(opt.tobytes(), np.uint8).copy()
+    pb = np.frombuffer(plan.tobytes(), np.uint8).copy()
+    cpu = None
+    if not no_cpu:
+        from oracle import pyref
+        if pyref.RefLib.available(fast=True) and (pyref.RefLib(fast=True).probe_rcp() == rcp).all():
+            ref = pyref.RefLib(fast=True)
+            cpu = ("reference", lambda b: ref.encode_mt("bc7", b, ob, pb, threads=usable_cores(), budget_s=60.0, chunk_blocks=64)[0])
+        else:
+            orc = pyref.OracleLib()
+            cpu = ("port", lambda b: orc.encode_bc7(b, ob, pb, rcp, usable_cores()))
     for name, b in synth.content_families(n).items():
         t = torch.from_numpy(b).to(dev)
-        out = ctx.encode_bc7(t)
-        ms, _ = timed_encode(torch, lambda: ctx.encode_bc7(t, out=out), 2)
+        out = ctx.encode_bc7(t, opt, plan)
+        ms, _ = timed_encode(torch, lambda: ctx.encode_bc7(t, opt, plan, out=out), 2)
         res[name] = {"mblocks_s": n / ms / 1e3, "kernel_ms": ms}
+        if cpu:
+            got = out[:check].cpu().numpy()
+            exp = cpu[1](np.ascontiguousarray(b[:check]))
+            res[name]["mismatches_vs_cpu"] = int((got != exp[:check]).any(axis=1).sum())
+            res[name]["blocks_checked"] = int(check)
+            res[name]["cpu_kind"] = cpu[0]
         del t, out
+    return res
+
+
+def dropin_8block_leg():
+    """The UNMODIFIED caller's convention: one cvtt::Kernels::Encode* call per 8 blocks (reference API.cpp:41-54, caller loop
+    etc2packer.cpp:215-281), through include/cvtt/ConvectionKernels.h -- a PCIe round trip and a one-wave launch per call.
+    Timed by tools/dropin_bench (built by __graft_entry__.build()), 1 and 16 caller threads; the CPU reference's time per
+    call on one thread stands beside it."""
+    exe = os.path.join(ROOT, "convectionkernels_amd", "lib", "dropin_bench")
+    if not os.path.exists(exe):
+        return None
+    try:
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "convectionkernels_amd", "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+        out = subprocess.run([exe, "0.5"], capture_output=True, text=True, timeout=120, env=env).stdout
+        res = json.loads(out[out.index("{"):])
+    except Exception as e:  # noqa
+        return {"error": repr(e)}
+    try:
+        from oracle import pyref
+        if pyref.RefLib.available(fast=True):
+            ref = pyref.RefLib(fast=True)
+            rng = np.random.default_rng(7)
+            blocks = rng.integers(0, 256, (4096, 16, 4), dtype=np.uint8)
+            ob = np.frombuffer(ref.default_options(), np.uint8).copy()
+            pb = np.frombuffer(ref.default_plan(), np.uint8).copy()
+            cpu = {}
+            for fmt, n in (("bc7", 1024), ("bc1", 4096)):
+                t0 = time.perf_counter()
+                ref.encode_mt(fmt, blocks[:n], ob, pb if fmt == "bc7" else None, threads=1, budget_s=30.0, chunk_blocks=64)
+                cpu[fmt] = (time.perf_counter() - t0) / (n / 8) * 1e6
+            res["cpu_reference_us_per_call_one_thread"] = cpu
+            for fmt in cpu:
+                if fmt in res and "us_per_call_1_thread" in res[fmt]:
+                    res[fmt]["slower_than_cpu_reference_per_call"] = res[fmt]["us_per_call_1_thread"] > cpu[fmt]
+    except Exception as e:  # noqa
+        res["cpu_error"] = repr(e)
+    res["note"] = ("8 blocks per call cannot fill a GPU (one wave of 65 536 resident): use the *Batch entry points; "
+                   "the 8-block calls exist so that an unmodified caller links and gets identical bytes")
     return res
 
 

@@ -93,15 +93,17 @@ def gather_to_root(local, ranges, full, root=0, group=None, async_op=False):
         if full is not None and hi > lo and local.data_ptr() != full[lo:hi].data_ptr():
             full[lo:hi].copy_(local)
         return []
+    # P2POp takes GLOBAL ranks as peers; `ranges` and `root` are indexed by the rank inside `group`
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     ops = []
     if rank == root:
         for r, (a, b) in enumerate(ranges):
             if r != root and b > a:
-                ops.append(dist.P2POp(dist.irecv, full[a:b], r, group))
+                ops.append(dist.P2POp(dist.irecv, full[a:b], peer(r), group))
         if hi > lo and local.data_ptr() != full[lo:hi].data_ptr():
             full[lo:hi].copy_(local)
     elif hi > lo:
-        ops.append(dist.P2POp(dist.isend, local, root, group))
+        ops.append(dist.P2POp(dist.isend, local, peer(root), group))
     works = dist.batch_isend_irecv(ops) if ops else []
     if async_op:
         return works
@@ -110,19 +112,25 @@ def gather_to_root(local, ranges, full, root=0, group=None, async_op=False):
     return []
 
 
-def pipelined_steps(num_steps, encode_step, exchange):
+def pipelined_steps(num_steps, encode_step, exchange, after_exchange=None):
     """`num_steps` steps of encode + exchange with two buffer sets: `encode_step(i, buf)` fills buffer set `buf` = i & 1
     on the current stream, `exchange(i, buf)` starts the exchange that reads it and returns its pending works; a buffer
     set is reused only after the exchange that read it has completed, so the exchange of step i overlaps the search of
-    step i + 1.  All works are waited for before returning."""
+    step i + 1.  `after_exchange(i, buf)` (optional) is called once step i's exchange has been waited for -- before the
+    buffer set is handed to step i + 2 -- e.g. to check what arrived.  All works are waited for before returning."""
     pending = []
     for i in range(num_steps):
         buf = i & 1
         if len(pending) >= 2:
-            for w in pending.pop(0):
+            j, works = pending.pop(0)
+            for w in works:
                 w.wait()
+            if after_exchange is not None:
+                after_exchange(j, j & 1)
         encode_step(i, buf)
-        pending.append(exchange(i, buf))
-    for works in pending:
+        pending.append((i, exchange(i, buf)))
+    for j, works in pending:
         for w in works:
             w.wait()
+        if after_exchange is not None:
+            after_exchange(j, j & 1)

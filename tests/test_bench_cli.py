@@ -60,6 +60,7 @@ def test_self_spawn_two_ranks_dry_run():
     assert "gather" in r["config"]["exchange"] and "rank 0" in r["config"]["exchange"]
     assert "BASELINE configs[4]" in r["config"]["workload"]
     assert r["output_check"]["matches_single_process"] is True
+    assert r["output_check"]["steps_checked"] == 3 and r["output_check"]["every_step_identical"] is True
 
 
 def test_three_ranks_ragged_shards_dry_run():

@@ -80,3 +80,41 @@ def test_two_rank_gloo_matches_single_process(tmp_path, oracle_lib):
         assert got.shape[0] == rows * per_row
         assert (got[:n] == exp).all()
     assert open(tmp_path / "pipeline_ok").read() == "overlapped=True"
+
+
+SUBGROUP_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from convectionkernels_amd import sharding
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+g = dist.new_group([1, 2])  # group rank 0 = global rank 1: P2POp peers are GLOBAL ranks
+if rank in (1, 2):
+    gr = dist.get_rank(g)
+    ranges = [(0, 8), (8, 24)]
+    lo, hi = ranges[gr]
+    local = torch.full((hi - lo, 16), 10 + gr, dtype=torch.uint8)
+    full = torch.zeros((24, 16), dtype=torch.uint8) if gr == 0 else None
+    log = []
+    sharding.pipelined_steps(3, lambda i, buf: None,
+                             lambda i, buf: sharding.gather_to_root(local, ranges, full, root=0, group=g, async_op=True),
+                             after_exchange=lambda i, buf: log.append((i, buf)))
+    assert log == [(0, 0), (1, 1), (2, 0)], log
+    if gr == 0:
+        assert full[:8].eq(10).all() and full[8:].eq(11).all(), full[:, 0]
+        open(os.path.join(os.environ["OUT_DIR"], "subgroup_ok"), "w").write("ok")
+dist.barrier()
+dist.destroy_process_group()
+''' % (ROOT,)
+
+
+def test_gather_to_root_inside_a_subgroup(tmp_path):
+    """gather_to_root with group != None: peers are translated to global ranks (three gloo ranks, group = ranks 1 and 2),
+    and pipelined_steps reports every finished exchange to `after_exchange` in order"""
+    env = dict(os.environ, OUT_DIR=str(tmp_path), MASTER_ADDR="127.0.0.1")
+    script = tmp_path / "sub.py"
+    script.write_text(SUBGROUP_WORKER)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+                           "--master-addr", "127.0.0.1", "--master-port", "29733", str(script)], env=env, timeout=600)
+    assert open(tmp_path / "subgroup_ok").read() == "ok"

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 CSVs written by tools/profile_round.sh into one small JSON/markdown
-summary (the raw counter_collection CSVs have one row per counter per dispatch)."""
+"""Condense the rocprofv3 CSVs written by tools/profile_round.sh into one small JSON summary (the raw
+counter_collection CSVs have one row per counter per dispatch).
+
+Per PMC pass and kernel: the LAST dispatch (the run does 5 warm-ups and 20 timed steps, so that one is warm) with its
+counters, and `mean_last20` = the counters averaged over the last 20 dispatches.  `headline` = the entry of the dominant
+kernel (largest total duration); its derived figures and the corrected HBM traffic are what bench.py quotes."""
 import csv
 import glob
 import json
@@ -16,52 +20,70 @@ def load(path):
     return [r for r in rows if "cvttmi" in r["Kernel_Name"]]
 
 
+def per_kernel(rows):
+    by_disp = {}
+    for r in rows:
+        d = by_disp.setdefault(int(r["Dispatch_Id"]), {"kernel": r["Kernel_Name"].split("(")[0], "vgpr": r["VGPR_Count"], "sgpr": r["SGPR_Count"],
+                                                      "scratch": r["Scratch_Size"], "lds": r.get("LDS_Block_Size", ""), "grid": r["Grid_Size"], "wg": r["Workgroup_Size"],
+                                                      "dur_us": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, "counters": {}})
+        c = d["counters"]
+        c[r["Counter_Name"]] = c.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    by_kernel = {}
+    for k in sorted(by_disp):
+        by_kernel.setdefault(by_disp[k]["kernel"], []).append(by_disp[k])
+    out = []
+    for name, ds in by_kernel.items():
+        e = dict(ds[-1])
+        tail = ds[-20:]
+        e["dispatches"] = len(ds)
+        e["mean_last20"] = {"n": len(tail), "dur_us": sum(d["dur_us"] for d in tail) / len(tail),
+                            "counters": {k: sum(d["counters"].get(k, 0.0) for d in tail) / len(tail) for k in e["counters"]}}
+        e["total_dur_us"] = sum(d["dur_us"] for d in ds)
+        out.append(e)
+    out.sort(key=lambda e: -e["total_dur_us"])
+    return out
+
+
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
     f = glob.glob(os.path.join(out_dir, sub, "*counter_collection.csv"))
     if not f:
         continue
     rows = load(f[0])
-    if not rows:
-        continue
-    # first (and normally only un-warmed) dispatch of the encode kernel; with the exhaustive
-    # comparison launch in bench.py there can be several -- keep dispatches apart
-    by_disp = {}
-    for r in rows:
-        by_disp.setdefault(r["Dispatch_Id"], {"kernel": r["Kernel_Name"].split("(")[0], "vgpr": r["VGPR_Count"],
-                                              "sgpr": r["SGPR_Count"], "scratch": r["Scratch_Size"],
-                                              "grid": r["Grid_Size"], "wg": r["Workgroup_Size"],
-                                              "dur_us": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
-                                              "counters": {}})
-        c = by_disp[r["Dispatch_Id"]]["counters"]
-        c[r["Counter_Name"]] = c.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-    summary[sub] = list(by_disp.values())
+    if rows:
+        summary[sub] = per_kernel(rows)
 
 stats = glob.glob(os.path.join(out_dir, "trace", "*kernel_stats.csv"))
 if stats:
     summary["kernel_stats"] = [r for r in csv.DictReader(open(stats[0]))]
 
-# derived numbers for the first dispatch
+# derived numbers for the dominant kernel, from the mean over its last 20 dispatches
 try:
     d = summary["pmc_sq"][0]
-    c = d["counters"]
+    c = d["mean_last20"]["counters"]
     xcd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0           # summed over the 8 XCDs
     simd_cycles = xcd_cycles * 1024                    # 256 CUs x 4 SIMDs
     d["derived"] = {
-        "clock_ghz": xcd_cycles / (d["dur_us"] * 1e3),
+        "clock_ghz": xcd_cycles / (d["mean_last20"]["dur_us"] * 1e3),
         "valu_insts_per_wave": c["SQ_INSTS_VALU"] / (int(d["grid"]) / 64),
         "valu_busy_frac(ACTIVE_INST_VALU*4/simd_cycles)": c["SQ_ACTIVE_INST_VALU"] * 4 / simd_cycles,
         "avg_waves_per_simd(WAVE_CYCLES*4/simd_cycles)": c["SQ_WAVE_CYCLES"] * 4 / simd_cycles,
         "cycles_per_valu_inst": c["SQ_ACTIVE_INST_VALU"] * 4 / c["SQ_INSTS_VALU"],
+        # MI355X_MICROARCH.md: a wave64 VALU instruction occupies a SIMD for 2 cycles -> issue peak = simd_cycles / 2
+        "valu_issue_frac_of_2cycle_peak": c["SQ_INSTS_VALU"] * 2 / simd_cycles,
     }
+    summary["headline_kernel"] = d["kernel"]
 except Exception as e:  # noqa
     summary["derived_error"] = str(e)
 try:
-    fetch = summary["pmc_fetch"][0]["counters"]["FETCH_SIZE"]
-    write = summary["pmc_write"][0]["counters"]["WRITE_SIZE"]
+    name = summary["pmc_sq"][0]["kernel"] if "pmc_sq" in summary else summary["pmc_fetch"][0]["kernel"]
+    fe = [e for e in summary["pmc_fetch"] if e["kernel"] == name][0]
+    we = [e for e in summary["pmc_write"] if e["kernel"] == name][0]
+    fetch = fe["mean_last20"]["counters"]["FETCH_SIZE"]
+    write = we["mean_last20"]["counters"]["WRITE_SIZE"]
     # MI355X_MICROARCH.md: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the
     # bytes of a wide coalesced stream -> doubled
-    summary["hbm_traffic_bytes_per_launch"] = {"fetch_kib_raw": fetch, "write_kib_raw": write,
-                                               "bytes_corrected": (2 * fetch + write) * 1024}
+    summary["hbm_traffic_bytes_per_launch"] = {"kernel": name, "fetch_kib_raw": fetch, "write_kib_raw": write,
+                                               "bytes_corrected": (2 * fetch + write) * 1024, "dispatches_averaged": fe["mean_last20"]["n"]}
 except Exception as e:  # noqa
     summary["traffic_error"] = str(e)
 # which kernel objects these counters belong to: bench.py quotes them only while the loaded library still holds the same ones
