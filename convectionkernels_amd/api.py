@@ -189,6 +189,7 @@ _EXPORTS = (
     "cvttmi_decode_bc7_device", "cvttmi_decode_bc7", "cvttmi_decode_bc6h_device", "cvttmi_decode_bc6h",
     "cvttmi_encode_etc1_device", "cvttmi_encode_etc1",
     "cvttmi_encode_etc2_punchthrough_alpha_device", "cvttmi_encode_etc2_punchthrough_alpha",
+    "cvttmi_encode_etc2_with_data_device", "cvttmi_encode_etc2_with_data",
     "cvttmi_default_bc7_fine_tuning", "cvttmi_bc7_plan_from_quality", "cvttmi_bc7_plan_from_fine_tuning",
     "cvttmi_host_alloc", "cvttmi_host_free", "cvttmi_host_register", "cvttmi_host_unregister",
 )
@@ -231,6 +232,9 @@ def load_library():
         getattr(lib, n).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         getattr(lib, n + "_device").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                                  ctypes.c_void_p, ctypes.c_void_p]
+    lib.cvttmi_encode_etc2_with_data.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    lib.cvttmi_encode_etc2_with_data_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+                                                        ctypes.c_int, ctypes.c_void_p]
     lib.cvttmi_tiled_block_count.restype = ctypes.c_size_t
     lib.cvttmi_tiled_block_count.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
     lib.cvttmi_tile_image_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
@@ -295,11 +299,12 @@ def exported_symbols():
 class Context:
     """One encoder context on one HIP device (tables in HBM, staging and work buffers, rcp table).
 
-    Concurrency: a context owns ONE set of device work buffers (the BC7 hand-over list, the BC6H scratch, the host-path
-    staging ring).  Calls on different streams are ordered by the library itself (every call makes its stream wait for the
-    context's previous launch, cvtt_mi355x.h "Streams"), and the host-pointer calls of one context are serialised by a lock
-    here, so sharing a context between threads or streams is safe but not concurrent -- use one Context per worker thread
-    (they are cheap: ~10 KB of tables + the work buffers) to overlap independent jobs."""
+    Concurrency: a context owns ONE set of device work buffers (the BC7 hand-over list and punch-through table, the BC6H
+    scratch, the host-path staging ring).  The calls that use them are ordered by the library itself when they arrive on
+    different streams (cvtt_mi355x.h "Streams"; calls that use no shared work space are simply queued on their stream), the
+    host side of every call on a context is serialised by a mutex in the library, and the host-pointer calls additionally by
+    a lock here, so sharing a context between threads or streams is safe but not concurrent -- use one Context per worker
+    thread (they are cheap: ~10 KB of tables + the work buffers) to overlap independent jobs."""
 
     def __init__(self, device=0):
         import threading
@@ -383,12 +388,13 @@ class Context:
         nbytes = int(np.prod(shape)) * dtype.itemsize
         p = ctypes.c_void_p()
         self._check(self._lib.cvttmi_host_alloc(self._h, ctypes.byref(p), nbytes), "host_alloc")
-        lib, h, addr = self._lib, self._h, p.value
+        lib, addr = self._lib, p.value
 
         class _Owner:
             def __del__(self_inner):
+                # without the context: the array may outlive it (cvttmi_host_free accepts NULL)
                 try:
-                    lib.cvttmi_host_free(h, ctypes.c_void_p(addr))
+                    lib.cvttmi_host_free(None, ctypes.c_void_p(addr))
                 except Exception:  # noqa
                     pass
         buf = (ctypes.c_uint8 * max(1, nbytes)).from_address(addr)
@@ -523,21 +529,30 @@ class Context:
         return self._encode_simple(self._lib.cvttmi_encode_etc1, self._lib.cvttmi_encode_etc1_device, "encode_etc1",
                                    blocks, options, out, stream, 64, 8)
 
-    def encode_etc2(self, blocks, options=None, out=None, stream=None):
-        """Batched cvtt::Kernels::EncodeETC2 (RGB): (N,16,4) uint8 -> (N,8) uint8."""
-        return self._encode_simple(self._lib.cvttmi_encode_etc2, self._lib.cvttmi_encode_etc2_device, "encode_etc2",
-                                   blocks, options, out, stream, 64, 8)
+    def _encode_etc2_kind(self, kind, what, blocks, options, out, stream, out_bytes, compression_data):
+        """The three calls that take the reference's ETC2CompressionData: the chroma axes of the sector split belong to the
+        Options AllocETC2Data was called with (reference ConvectionKernels_ETC.cpp:3117-3145), the rest to `options`."""
+        ao = None
+        if compression_data is not None:
+            ao = compression_data.alloc_options if isinstance(compression_data, ETC2CompressionData) else compression_data
+        aop = ctypes.byref(ao) if ao is not None else None
+        host = lambda h, o, b, n, opt: self._lib.cvttmi_encode_etc2_with_data(h, o, b, n, opt, aop, kind)
+        dev = lambda h, o, b, n, opt, st: self._lib.cvttmi_encode_etc2_with_data_device(h, o, b, n, opt, aop, kind, st)
+        return self._encode_simple(host, dev, what, blocks, options, out, stream, 64, out_bytes)
 
-    def encode_etc2_punchthrough_alpha(self, blocks, options=None, out=None, stream=None):
+    def encode_etc2(self, blocks, options=None, out=None, stream=None, compression_data=None):
+        """Batched cvtt::Kernels::EncodeETC2 (RGB): (N,16,4) uint8 -> (N,8) uint8.  compression_data: what AllocETC2Data
+        returned (or the Options it was given); None = allocated with `options`."""
+        return self._encode_etc2_kind(0, "encode_etc2", blocks, options, out, stream, 8, compression_data)
+
+    def encode_etc2_punchthrough_alpha(self, blocks, options=None, out=None, stream=None, compression_data=None):
         """Batched cvtt::Kernels::EncodeETC2PunchthroughAlpha: (N,16,4) uint8 -> (N,8) uint8 (RGB8A1 blocks; a pixel is
         transparent when its alpha is below floor(clamp(options.threshold, 0, 1) * 255 + 1))."""
-        return self._encode_simple(self._lib.cvttmi_encode_etc2_punchthrough_alpha, self._lib.cvttmi_encode_etc2_punchthrough_alpha_device,
-                                   "encode_etc2_punchthrough_alpha", blocks, options, out, stream, 64, 8)
+        return self._encode_etc2_kind(4, "encode_etc2_punchthrough_alpha", blocks, options, out, stream, 8, compression_data)
 
-    def encode_etc2_rgba(self, blocks, options=None, out=None, stream=None):
+    def encode_etc2_rgba(self, blocks, options=None, out=None, stream=None, compression_data=None):
         """Batched cvtt::Kernels::EncodeETC2RGBA: (N,16,4) uint8 -> (N,16) uint8 = [EAC alpha | colour]."""
-        return self._encode_simple(self._lib.cvttmi_encode_etc2_rgba, self._lib.cvttmi_encode_etc2_rgba_device,
-                                   "encode_etc2_rgba", blocks, options, out, stream, 64, 16)
+        return self._encode_etc2_kind(1, "encode_etc2_rgba", blocks, options, out, stream, 16, compression_data)
 
     def encode_etc2_alpha(self, blocks, options=None, out=None, stream=None):
         """Batched cvtt::Kernels::EncodeETC2Alpha (EAC 8-bit): (N,16,4) uint8 -> (N,8) uint8."""
@@ -759,20 +774,39 @@ def EncodeETC1(pBlocks, options=None, compressionData=None, device=0):
     return default_context(device).encode_etc1(pBlocks, options)
 
 
+class ETC2CompressionData:
+    """What cvtt::Kernels::AllocETC2Data returns (reference ConvectionKernels_ETC.cpp:3100-3145).  The 136 KB of scratch have
+    no counterpart (the kernels' scratch is LDS); what the reference fixes at allocation time and the encoder needs later are
+    the two chroma axes, derived from the colour weights of the Options given here."""
+
+    def __init__(self, options=None):
+        self.alloc_options = Options.frombytes(bytes(options if options is not None else Options()))
+
+
+def AllocETC2Data(options=None):
+    """cvtt::Kernels::AllocETC2Data (no allocator callbacks: nothing is allocated in caller memory)."""
+    return ETC2CompressionData(options)
+
+
+def ReleaseETC2Data(compressionData):
+    """cvtt::Kernels::ReleaseETC2Data: nothing to free."""
+    return None
+
+
 def EncodeETC2(pBlocks, options=None, compressionData=None, device=0):
-    """cvtt::Kernels::EncodeETC2 (reference ConvectionKernels_API.cpp:216-229); the reference's
-    ETC2CompressionData scratch argument is accepted and ignored (scratch lives in LDS)."""
-    return default_context(device).encode_etc2(pBlocks, options)
+    """cvtt::Kernels::EncodeETC2 (reference ConvectionKernels_API.cpp:216-229).  compressionData: from AllocETC2Data; its
+    Options fix the chroma axes, as in the reference (scratch itself lives in LDS)."""
+    return default_context(device).encode_etc2(pBlocks, options, compression_data=compressionData)
 
 
 def EncodeETC2PunchthroughAlpha(pBlocks, options=None, compressionData=None, device=0):
     """cvtt::Kernels::EncodeETC2PunchthroughAlpha (reference ConvectionKernels_API.cpp:231-244)."""
-    return default_context(device).encode_etc2_punchthrough_alpha(pBlocks, options)
+    return default_context(device).encode_etc2_punchthrough_alpha(pBlocks, options, compression_data=compressionData)
 
 
 def EncodeETC2RGBA(pBlocks, options=None, compressionData=None, device=0):
     """cvtt::Kernels::EncodeETC2RGBA (reference ConvectionKernels_API.cpp:270-286)."""
-    return default_context(device).encode_etc2_rgba(pBlocks, options)
+    return default_context(device).encode_etc2_rgba(pBlocks, options, compression_data=compressionData)
 
 
 def EncodeETC2Alpha(pBlocks, options=None, device=0):

@@ -63,7 +63,9 @@ constexpr int kScrEpq0 = 0, kScrIdx = 36, kScratchDwords = 84;
 #define CVTT_BC6H_WAVES 4
 #endif
 
-// ceil(n / 31) for 0 <= n < 2^23: one v_mul_hi_u32 (2216757579 = ceil(2^36 / 31); exact while n * 8213 < 2^36)
+// ceil(n / 31) for 0 <= n < 2^23: one v_mul_hi_u32.  2216757579 = (2^36 + 8213) / 31 (NOT ceil(2^36 / 31) = 2216757315):
+// x * 2216757579 / 2^36 = x / 31 + x * 8213 / (31 * 2^36), and x / 31 lies at least 1 / 31 below the next integer, so the
+// floor is that of x / 31 while x * 8213 < 2^36, i.e. for x < 8.3 million (tools/check_bc6h_quantize.py compares every value)
 __device__ __forceinline__ int ceilDiv31(int n)
 {
     return (int)(__umulhi((u32)(n + 30), 2216757579u) >> 4);

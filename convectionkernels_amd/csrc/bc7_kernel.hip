@@ -228,7 +228,7 @@ template <int NRC, bool FAST, bool TRACE>
 __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount, const ModeDesc md, const Unfinished &u,
                                           int pIter, int tweak, bool active, const CvttBc7Args &A,
                                           const CvttDeviceTables *__restrict__ T, int numRefine, ShapeBest &best,
-                                          const float (&vs)[4], float *trialErr = nullptr, int captureRound = -1)
+                                          const float (&vs)[4], float *trialErr = nullptr, int captureRound = -1, float *trialErrHbm = nullptr)
 {
     const bool isRGB = (NRC == 3);
     const int range = 1 << md.indexBits;
@@ -454,8 +454,14 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
         if (isRGB)
             shapeError = shapeError + staticAlphaError;
 
-        if (TRACE && trialErr && active)
-            trialErr[refine] = shapeError;
+        if (TRACE && active)
+        {
+            // (two pointers, not one: the LDS stores stay ds_write instead of turning into flat stores)
+            if (trialErrHbm)
+                trialErrHbm[refine] = shapeError;
+            else if (trialErr)
+                trialErr[refine] = shapeError;
+        }
         const bool take = (TRACE && captureRound >= 0) ? (refine == captureRound) : (shapeError < best.err);
         if (active && take)
         {
@@ -1852,6 +1858,9 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     // BC7_RespectPunchThrough: the error of every trial (chain x refine round) of every unit of the round
     // [unit][chain][round], 32 x 16 x numRefine floats (punch-through instantiation only; up to kMaxPTRefine rounds)
     __shared__ float s_trialErr[PT ? 32 * 16 * kMaxPTRefine : 1];
+    // ... and with more rounds than that (the reference only clamps refineRoundsBC7 from below, BC67.cpp:1044-1045) the
+    // table of this wave lives in HBM; it is written and read inside the wave, between barriers
+    float *const trialHbm = (PT && A.ptTrial) ? A.ptTrial + (size_t)blockIdx.x * (size_t)(32 * 16) * (size_t)(A.refineRounds < 1 ? 1 : A.refineRounds) : nullptr;
     const cvttmi_bc7_plan *__restrict__ plan = &dplan->plan;
     const int lane = threadIdx.x;
     const int c = lane & 3;
@@ -2899,7 +2908,8 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     // record every trial; the lock-step commit rule is applied below
                     if (PT)
                         evalChain<4, FAST, true>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b, uvs,
-                                                 &s_trialErr[((inRange ? unit : 0) * 16 + chain) * numRefine], -1);
+                                                 trialHbm ? nullptr : &s_trialErr[((inRange ? unit : 0) * 16 + chain) * numRefine], -1,
+                                                 trialHbm ? trialHbm + ((inRange ? unit : 0) * 16 + chain) * numRefine : nullptr);
                     continue;
                 }
                 if (isRGB)
@@ -2954,7 +2964,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                         {
                             const int t = (pI * 4 + tw) * numRefine + rf;
                             const bool run = scanActive && !allInvalid && tw < r.numTweak();
-                            const float e = run ? s_trialErr[unit * 16 * numRefine + t] : FLT_MAX;
+                            const float e = run ? (trialHbm ? trialHbm[unit * 16 * numRefine + t] : s_trialErr[unit * 16 * numRefine + t]) : FLT_MAX;
                             const bool better = run && e < held;
                             const bool anyBetter = ((u32)(__ballot(better) >> slice) & 0xffu) != 0;
                             bool commit = better;

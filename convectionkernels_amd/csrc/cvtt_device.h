@@ -93,6 +93,9 @@ struct CvttBc7Args
     uint32_t *hardCount;
     CvttBc7HardRec *hardRec;
     CvttBc7HardCand *hardCand; // [hardCap][kHardWaves]
+    // BC7_RespectPunchThrough with more refine rounds than the LDS trial table holds (bc7_kernel.hip, kMaxPTRefine): the
+    // table of every wave of the launch in HBM, [wave][unit 32][chain 16][round]; NULL: the LDS table is used
+    float *ptTrial;
 };
 
 // BC1 per-launch parameters.

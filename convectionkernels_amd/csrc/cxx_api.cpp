@@ -58,10 +58,15 @@ namespace
 
     const cvttmi_options *opt(const cvtt::Options &o) { return reinterpret_cast<const cvttmi_options *>(&o); }
 
+    // What survives of the reference's 136 KB ETC2 scratch: the allocator context (for ReleaseETC2Data) and the Options of
+    // the allocation -- the reference derives the chroma axes of the sector split from THOSE (ETC.cpp:3117-3145), and from
+    // the Options of the Encode call everything else.
     struct Etc2Marker : public cvtt::ETC2CompressionData
     {
         void *context;
+        cvttmi_options allocOptions;
     };
+    const cvttmi_options *allocOpt(cvtt::ETC2CompressionData *data) { return data ? &static_cast<Etc2Marker *>(data)->allocOptions : NULL; }
     struct Etc1Marker : public cvtt::ETC1CompressionData
     {
         void *context;
@@ -129,21 +134,22 @@ namespace cvtt
         {
             check(cvttmi_encode_bc6h(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), 1), "EncodeBC6HS");
         }
-        void EncodeETC2PunchthroughAlphaBatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
+        void EncodeETC2PunchthroughAlphaBatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options, ETC2CompressionData *data)
         {
-            check(cvttmi_encode_etc2_punchthrough_alpha(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeETC2PunchthroughAlpha");
+            check(cvttmi_encode_etc2_with_data(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), allocOpt(data), CVTTMI_ETC2_PUNCHTHROUGH),
+                  "EncodeETC2PunchthroughAlpha");
         }
         void EncodeETC1Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
         {
             check(cvttmi_encode_etc1(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeETC1");
         }
-        void EncodeETC2Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
+        void EncodeETC2Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options, ETC2CompressionData *data)
         {
-            check(cvttmi_encode_etc2(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeETC2");
+            check(cvttmi_encode_etc2_with_data(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), allocOpt(data), CVTTMI_ETC2_RGB), "EncodeETC2");
         }
-        void EncodeETC2RGBABatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
+        void EncodeETC2RGBABatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options, ETC2CompressionData *data)
         {
-            check(cvttmi_encode_etc2_rgba(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeETC2RGBA");
+            check(cvttmi_encode_etc2_with_data(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), allocOpt(data), CVTTMI_ETC2_RGBA), "EncodeETC2RGBA");
         }
         void EncodeETC2AlphaBatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
         {
@@ -179,21 +185,22 @@ namespace cvtt
         void EncodeBC1(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options) { EncodeBC1Batch(pBC, pBlocks, NumParallelBlocks, options); }
         void EncodeBC6HU(uint8_t *pBC, const PixelBlockF16 *pBlocks, const Options &options) { EncodeBC6HUBatch(pBC, pBlocks, NumParallelBlocks, options); }
         void EncodeBC6HS(uint8_t *pBC, const PixelBlockF16 *pBlocks, const Options &options) { EncodeBC6HSBatch(pBC, pBlocks, NumParallelBlocks, options); }
-        void EncodeETC2PunchthroughAlpha(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC2CompressionData *) { EncodeETC2PunchthroughAlphaBatch(pBC, pBlocks, NumParallelBlocks, options); }
+        void EncodeETC2PunchthroughAlpha(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC2CompressionData *data) { EncodeETC2PunchthroughAlphaBatch(pBC, pBlocks, NumParallelBlocks, options, data); }
         void EncodeETC1(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC1CompressionData *) { EncodeETC1Batch(pBC, pBlocks, NumParallelBlocks, options); }
-        void EncodeETC2(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC2CompressionData *) { EncodeETC2Batch(pBC, pBlocks, NumParallelBlocks, options); }
-        void EncodeETC2RGBA(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC2CompressionData *) { EncodeETC2RGBABatch(pBC, pBlocks, NumParallelBlocks, options); }
+        void EncodeETC2(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC2CompressionData *data) { EncodeETC2Batch(pBC, pBlocks, NumParallelBlocks, options, data); }
+        void EncodeETC2RGBA(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options, ETC2CompressionData *data) { EncodeETC2RGBABatch(pBC, pBlocks, NumParallelBlocks, options, data); }
         void EncodeETC2Alpha(uint8_t *pBC, const PixelBlockU8 *pBlocks, const Options &options) { EncodeETC2AlphaBatch(pBC, pBlocks, NumParallelBlocks, options); }
 
-        // The reference places 136 KB of scratch in caller memory (ETC.cpp:3100-3115); here only the
-        // allocator context survives so that ReleaseETC2Data can hand the block back.
-        ETC2CompressionData *AllocETC2Data(allocFunc_t allocFunc, void *ctx, const Options &)
+        // The reference places 136 KB of scratch in caller memory (ETC.cpp:3100-3115); here the allocator context survives
+        // so that ReleaseETC2Data can hand the block back, and the Options, whose colour weights fix the chroma axes.
+        ETC2CompressionData *AllocETC2Data(allocFunc_t allocFunc, void *ctx, const Options &options)
         {
             void *buffer = allocFunc(ctx, sizeof(Etc2Marker));
             if (!buffer)
                 return NULL;
             Etc2Marker *m = new (buffer) Etc2Marker();
             m->context = ctx;
+            memcpy(&m->allocOptions, &options, sizeof(m->allocOptions));
             return m;
         }
         void ReleaseETC2Data(ETC2CompressionData *data, freeFunc_t freeFunc)

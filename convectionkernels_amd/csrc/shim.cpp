@@ -67,8 +67,15 @@ struct cvttmi_context
     CvttBc7DevicePlan *pinnedPlans; // the staged plans in pinned memory: sources of the asynchronous uploads
     cvttmi_bc7_plan lastPlan[kPlanSlots];
     bool planValid[kPlanSlots];
-    hipEvent_t evPlan[kPlanSlots];  // recorded after the last launch that reads the slot
-    bool planEventValid[kPlanSlots];
+    // launches that read a slot since it was last written: one event per stream that launched one (a slot is rewritten
+    // only when every one of them has finished; more than kPlanUsers distinct streams: the oldest entry is waited for)
+    static const int kPlanUsers = 4;
+    struct PlanUse
+    {
+        hipStream_t stream;
+        hipEvent_t ev; // created on first use
+        bool valid;
+    } planUse[kPlanSlots][kPlanUsers];
     hipEvent_t evPlanUp[kPlanSlots]; // recorded after the slot's upload, on the stream that did it
     hipStream_t planUpStream[kPlanSlots];
     int nextPlanSlot;
@@ -92,6 +99,8 @@ struct cvttmi_context
     bool lastValid;
     void *dScratch;       // kernel work space (BC6H endpoint history), grown on demand
     size_t dScratchBytes;
+    float *dPtTrial;      // BC7_RespectPunchThrough with more than 6 refine rounds: the trial-error table of a launch's waves
+    size_t dPtTrialBytes;
     bool exhaustive; // search every candidate even when it provably cannot win
     // BC7: blocks with many live mode-7 partitions are finished by a second launch (bc7_kernel.hip, HARD).
     // One set of buffers per context, like dScratch: launches of one context are expected on one stream at a time.
@@ -117,6 +126,7 @@ namespace
     {
         if (ctx)
         {
+            std::lock_guard<std::recursive_mutex> lock(ctx->mu); // callers on several threads may fail at the same time
             ctx->lastError = what;
             if (e != hipSuccess)
             {
@@ -247,10 +257,15 @@ namespace
         const int slot = ctx->nextPlanSlot;
         ctx->nextPlanSlot = (slot + 1) % cvttmi_context::kPlanSlots;
         hipError_t e;
-        if (ctx->planEventValid[slot] && (e = hipEventSynchronize(ctx->evPlan[slot])) != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "hipEventSynchronize(plan slot)", e);
-        memcpy(&ctx->lastPlan[slot], plan, sizeof(*plan));
-        ctx->planValid[slot] = true;
+        // every launch that read the slot, on whatever stream, must have finished (normally long past)
+        for (int u = 0; u < cvttmi_context::kPlanUsers; u++)
+        {
+            cvttmi_context::PlanUse &use = ctx->planUse[slot][u];
+            if (use.valid && (e = hipEventSynchronize(use.ev)) != hipSuccess)
+                return fail(ctx, CVTTMI_E_HIP, "hipEventSynchronize(plan slot)", e);
+            use.valid = false;
+        }
+        ctx->planValid[slot] = false; // until the upload below has been queued
         CvttBc7DevicePlan &staged = ctx->pinnedPlans[slot];
         memset(&staged, 0, sizeof(staged));
         staged.plan = *plan;
@@ -277,9 +292,40 @@ namespace
         if ((e = hipEventRecord(ctx->evPlanUp[slot], stream)) != hipSuccess)
             return fail(ctx, CVTTMI_E_HIP, "hipEventRecord(plan upload)", e);
         ctx->planUpStream[slot] = stream;
+        memcpy(&ctx->lastPlan[slot], plan, sizeof(*plan));
+        ctx->planValid[slot] = true;
         *dPlanOut = ctx->dPlans + slot;
         *slotOut = slot;
         return CVTTMI_OK;
+    }
+
+    // A launch on `stream` that reads plan slot `slot` has just been queued.
+    void markPlanUse(cvttmi_context *ctx, int slot, hipStream_t stream)
+    {
+        cvttmi_context::PlanUse *use = NULL;
+        for (int u = 0; u < cvttmi_context::kPlanUsers && !use; u++)
+            if (ctx->planUse[slot][u].valid && ctx->planUse[slot][u].stream == stream)
+                use = &ctx->planUse[slot][u];
+        for (int u = 0; u < cvttmi_context::kPlanUsers && !use; u++)
+            if (!ctx->planUse[slot][u].valid)
+                use = &ctx->planUse[slot][u];
+        if (!use)
+        {
+            // more distinct streams than entries: the first entry's launch is waited for and the entry taken over
+            use = &ctx->planUse[slot][0];
+            (void)hipEventSynchronize(use->ev);
+        }
+        if (!use->ev && hipEventCreateWithFlags(&use->ev, hipEventDisableTiming) != hipSuccess)
+        {
+            use->ev = NULL;
+            (void)hipStreamSynchronize(stream); // no event to remember the launch by: wait for it now
+            use->valid = false;
+            return;
+        }
+        use->stream = stream;
+        use->valid = hipEventRecord(use->ev, stream) == hipSuccess;
+        if (!use->valid)
+            (void)hipStreamSynchronize(stream);
     }
 
     void freePipe(cvttmi_context *ctx)
@@ -332,6 +378,32 @@ namespace
         }
         return attr.type == hipMemoryTypeHost;
     }
+    // ... the WHOLE range [p, p + bytes): one allocation that covers it (hipMemGetAddressRange), else -- registered memory
+    // the runtime gives no range for -- both ends and a probe every 64 KiB in between (a buffer registered in parts with
+    // pageable holes smaller than that is not something a caller gets by accident)
+    bool isPinnedHostRange(const void *p, size_t bytes)
+    {
+        if (bytes == 0 || !isPinnedHost(p))
+            return false;
+        const uint8_t *b = static_cast<const uint8_t *>(p);
+        hipDeviceptr_t base = NULL;
+        size_t size = 0;
+        void *dev = NULL;
+        if (hipHostGetDevicePointer(&dev, const_cast<void *>(p), 0) == hipSuccess && hipMemGetAddressRange(&base, &size, dev) == hipSuccess)
+        {
+            const uint8_t *lo = static_cast<const uint8_t *>(static_cast<void *>(base));
+            const uint8_t *d = static_cast<const uint8_t *>(dev);
+            if (d >= lo && d + bytes <= lo + size)
+                return true;
+        }
+        (void)hipGetLastError();
+        if (!isPinnedHost(b + bytes - 1))
+            return false;
+        for (size_t off = 65536; off < bytes; off += 65536)
+            if (!isPinnedHost(b + off))
+                return false;
+        return true;
+    }
 
     // The host-pointer entry points: `numBlocks` blocks of `inBpb` bytes in host memory -> `outBpb` bytes each in host
     // memory through `launch(dOut, dIn, n, stream)`, in chunks of 2^17 blocks (8 MiB of PixelBlockU8) dealt to pipeline slots with their own
@@ -341,14 +413,16 @@ namespace
     // of the next chunk overlapping the device work of the current one.  Measured on 4096^2 BC7 with the 4-wave kernel,
     // median of 25 calls, page-locked / pageable, Mblocks/s: 2 slots x 2^17: 440 / 278; 4 x 2^17: 385 / 346; 4 x 2^16:
     // 323 / 326 (best 471, unstable); 4 x 2^18: 359 / 317.  CVTTMI_HOST_SLOTS / CVTTMI_HOST_CHUNK_LOG2 select other settings.
+    // zeroCopyOk: the kernel reads every input byte once (BC7, where the in-place path was measured); kernels that read a
+    // block several times (ETC2: every wave loads its whole group) would re-read it over PCIe and keep the staged copies.
     template <class Launch>
-    int hostPipeline(cvttmi_context *ctx, uint8_t *out, const uint8_t *in, size_t numBlocks, size_t inBpb, size_t outBpb, Launch launch)
+    int hostPipeline(cvttmi_context *ctx, uint8_t *out, const uint8_t *in, size_t numBlocks, size_t inBpb, size_t outBpb, Launch launch, bool zeroCopyOk = false)
     {
         static const int chunkLog2 = getenv("CVTTMI_HOST_CHUNK_LOG2") ? atoi(getenv("CVTTMI_HOST_CHUNK_LOG2")) : 17;
         const size_t kChunk = (size_t)1 << (chunkLog2 < 10 ? 10 : chunkLog2 > 24 ? 24 : chunkLog2);
         static const int slotsEnv = getenv("CVTTMI_HOST_SLOTS") ? atoi(getenv("CVTTMI_HOST_SLOTS")) : 0;
-        const bool inPinned = isPinnedHost(in) && isPinnedHost(in + numBlocks * inBpb - 1);
-        const bool outPinned = isPinnedHost(out) && isPinnedHost(out + numBlocks * outBpb - 1);
+        const bool inPinned = isPinnedHostRange(in, numBlocks * inBpb);
+        const bool outPinned = isPinnedHostRange(out, numBlocks * outBpb);
         // page-locked caller memory: two slots keep the link and the device busy; pageable memory: four, so that the CPU
         // copies into and out of the staging buffers overlap as well
         const int slotsWanted = slotsEnv > 0 ? slotsEnv : (inPinned && outPinned ? 2 : cvttmi_context::kPipeSlots);
@@ -357,7 +431,7 @@ namespace
         // straight back over PCIe -- no staging, no chunking, one launch over the whole batch (BC7: a wave reads 1 KiB
         // contiguous and writes 256 B; 4096^2 host to host 642 Mblocks/s against 440 with pipelined copies).
         static const bool zeroCopy = !(getenv("CVTTMI_HOST_ZEROCOPY") && atoi(getenv("CVTTMI_HOST_ZEROCOPY")) == 0);
-        if (zeroCopy && inPinned && outPinned)
+        if (zeroCopy && zeroCopyOk && inPinned && outPinned)
         {
             void *dIn = NULL, *dOut = NULL;
             if (hipHostGetDevicePointer(&dIn, const_cast<uint8_t *>(in), 0) == hipSuccess && hipHostGetDevicePointer(&dOut, out, 0) == hipSuccess)
@@ -376,6 +450,13 @@ namespace
             return rc;
         const size_t numChunks = (numBlocks + chunk - 1) / chunk;
         hipError_t e;
+        // an error leaves copies of earlier chunks in flight that still write into `out` / read `in`: nothing returns
+        // before every pipeline stream has drained, so the caller may free its buffers as soon as it has the error code
+        auto drained = [&](int code) -> int {
+            for (size_t sl = 0; sl < kSlots; sl++)
+                (void)hipStreamSynchronize(ctx->pipe[sl].stream);
+            return code;
+        };
         auto finish = [&](size_t c) -> int {
             cvttmi_context::PipeSlot &S = ctx->pipe[c % kSlots];
             hipError_t fe = hipEventSynchronize(S.done);
@@ -392,7 +473,7 @@ namespace
         {
             cvttmi_context::PipeSlot &S = ctx->pipe[c % kSlots];
             if (c >= kSlots && (rc = finish(c - kSlots)) != CVTTMI_OK)
-                return rc;
+                return drained(rc);
             const size_t first = c * chunk;
             const size_t n = (numBlocks - first) < chunk ? (numBlocks - first) : chunk;
             const void *src = in + first * inBpb;
@@ -402,29 +483,18 @@ namespace
                 src = S.pinnedIn;
             }
             if ((e = hipMemcpyAsync(S.dIn, src, n * inBpb, hipMemcpyHostToDevice, S.stream)) != hipSuccess)
-                return fail(ctx, CVTTMI_E_HIP, "H2D", e);
+                return drained(fail(ctx, CVTTMI_E_HIP, "H2D", e));
             if ((rc = launch(S.dOut, S.dIn, n, S.stream)) != CVTTMI_OK)
-                return rc;
+                return drained(rc);
             void *dst = outPinned ? static_cast<void *>(out + first * outBpb) : S.pinnedOut;
             if ((e = hipMemcpyAsync(dst, S.dOut, n * outBpb, hipMemcpyDeviceToHost, S.stream)) != hipSuccess)
-                return fail(ctx, CVTTMI_E_HIP, "D2H", e);
+                return drained(fail(ctx, CVTTMI_E_HIP, "D2H", e));
             if ((e = hipEventRecord(S.done, S.stream)) != hipSuccess)
-                return fail(ctx, CVTTMI_E_HIP, "hipEventRecord", e);
+                return drained(fail(ctx, CVTTMI_E_HIP, "hipEventRecord", e));
         }
         for (size_t c = numChunks >= kSlots ? numChunks - kSlots : 0; c < numChunks; c++)
             if ((rc = finish(c)) != CVTTMI_OK)
-                return rc;
-        return CVTTMI_OK;
-    }
-
-    // common front of the host-pointer entry points
-    int hostPrologue(cvttmi_context *ctx, const void *out, const void *in, const void *options, size_t numBlocks)
-    {
-        if (!out || !in || !options || (numBlocks % 8) != 0 || numBlocks > 0xfffffff0u)
-            return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
-        hipError_t e = hipSetDevice(ctx->device);
-        if (e != hipSuccess)
-            return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+                return drained(rc);
         return CVTTMI_OK;
     }
 
@@ -620,10 +690,11 @@ extern "C"
         ctx->nextPlanSlot = 0;
         for (int i = 0; i < cvttmi_context::kPlanSlots; i++)
         {
-            ctx->planValid[i] = ctx->planEventValid[i] = false;
-            ctx->evPlan[i] = ctx->evPlanUp[i] = NULL;
+            ctx->planValid[i] = false;
+            ctx->evPlanUp[i] = NULL;
             ctx->planUpStream[i] = NULL;
         }
+        memset(ctx->planUse, 0, sizeof(ctx->planUse));
         memset(ctx->pipe, 0, sizeof(ctx->pipe));
         ctx->pipeInBytes = ctx->pipeOutBytes = 0;
         ctx->stream = NULL;
@@ -632,6 +703,8 @@ extern "C"
         ctx->lastValid = false;
         ctx->dScratch = NULL;
         ctx->dScratchBytes = 0;
+        ctx->dPtTrial = NULL;
+        ctx->dPtTrialBytes = 0;
         ctx->timing = false;
         ctx->exhaustive = getenv("CVTTMI_EXHAUSTIVE") != NULL && atoi(getenv("CVTTMI_EXHAUSTIVE")) != 0;
         ctx->totalMs = 0.0;
@@ -661,8 +734,7 @@ extern "C"
             ok = (e = hipStreamCreate(&ctx->pipe[i].stream)) == hipSuccess &&
                  (e = hipEventCreateWithFlags(&ctx->pipe[i].done, hipEventDisableTiming)) == hipSuccess;
         for (int i = 0; ok && i < cvttmi_context::kPlanSlots; i++)
-            ok = (e = hipEventCreateWithFlags(&ctx->evPlan[i], hipEventDisableTiming)) == hipSuccess &&
-                 (e = hipEventCreateWithFlags(&ctx->evPlanUp[i], hipEventDisableTiming)) == hipSuccess;
+            ok = (e = hipEventCreateWithFlags(&ctx->evPlanUp[i], hipEventDisableTiming)) == hipSuccess;
         ctx->stream = ctx->pipe[0].stream;
         if (!ok || uploadTables(ctx) != CVTTMI_OK)
         {
@@ -684,6 +756,7 @@ extern "C"
         if (ctx->pinnedPlans) (void)hipHostFree(ctx->pinnedPlans);
         freePipe(ctx);
         if (ctx->dScratch) (void)hipFree(ctx->dScratch);
+        if (ctx->dPtTrial) (void)hipFree(ctx->dPtTrial);
         if (ctx->dHardCount) (void)hipFree(ctx->dHardCount);
         if (ctx->dHardRec) (void)hipFree(ctx->dHardRec);
         if (ctx->dHardCand) (void)hipFree(ctx->dHardCand);
@@ -694,7 +767,8 @@ extern "C"
         }
         for (int i = 0; i < cvttmi_context::kPlanSlots; i++)
         {
-            if (ctx->evPlan[i]) (void)hipEventDestroy(ctx->evPlan[i]);
+            for (int u = 0; u < cvttmi_context::kPlanUsers; u++)
+                if (ctx->planUse[i][u].ev) (void)hipEventDestroy(ctx->planUse[i][u].ev);
             if (ctx->evPlanUp[i]) (void)hipEventDestroy(ctx->evPlanUp[i]);
         }
         if (ctx->evLast) (void)hipEventDestroy(ctx->evLast);
@@ -713,10 +787,9 @@ extern "C"
             e = hipHostMalloc(ptr, bytes ? bytes : 1);
         return e == hipSuccess ? CVTTMI_OK : fail(ctx, CVTTMI_E_HIP, "hipHostMalloc", e);
     }
+    // ctx may be NULL (the memory may outlive the context that allocated it; no error text is kept then)
     int cvttmi_host_free(cvttmi_context *ctx, void *ptr)
     {
-        if (!ctx)
-            return CVTTMI_E_INVALID;
         hipError_t e = ptr ? hipHostFree(ptr) : hipSuccess;
         return e == hipSuccess ? CVTTMI_OK : fail(ctx, CVTTMI_E_HIP, "hipHostFree", e);
     }
@@ -781,6 +854,7 @@ extern "C"
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu); // lastError, timing state and work buffers are per context
         e = cvttmi_launch_tile(d_image, d_blocks, width, height, rowPitchBytes, bpp, static_cast<hipStream_t>(hipStream));
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_HIP, "tile kernel launch", e);
@@ -797,6 +871,7 @@ extern "C"
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu); // lastError, timing state and work buffers are per context
         e = cvttmi_launch_compact_rows(d_packed, d_out, width, height, bytesPerBlock, static_cast<hipStream_t>(hipStream));
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_HIP, "compact kernel launch", e);
@@ -815,6 +890,7 @@ extern "C"
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu); // lastError, timing state and work buffers are per context
         e = cvttmi_launch_decode(d_bc, d_blocks, static_cast<uint32_t>(numBlocks), format, ctx->dTables, static_cast<hipStream_t>(hipStream));
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_HIP, "decode kernel launch", e);
@@ -959,8 +1035,6 @@ extern "C"
             return CVTTMI_E_INVALID;
         if (!d_out || !d_blocks || !options || !plan || (numBlocks % 8) != 0 || numBlocks > 0xfffffff0u)
             return fail(ctx, CVTTMI_E_INVALID, "invalid argument");
-        if ((options->flags & CVTTMI_FLAG_BC7_RESPECT_PUNCHTHROUGH) && options->refineRoundsBC7 > 6)
-            return fail(ctx, CVTTMI_E_UNSUPPORTED, "BC7_RespectPunchThrough supports refineRoundsBC7 <= 6 on the GPU path (2 KB of LDS per round)");
         if (numBlocks == 0)
             return CVTTMI_OK;
         hipError_t e = hipSetDevice(ctx->device);
@@ -1005,19 +1079,53 @@ extern "C"
             args.delta4 = static_cast<float>(0.5 * sqrt(s4) * 1.000001);
         }
 
-        // the hand-over list exists once per context: launches that use it are ordered after the previous one that did
-        // (the plan ring is protected by its own per-slot events)
-        if (args.hardCap)
+        // BC7_RespectPunchThrough records the error of every trial of a round of units; up to 6 refine rounds that table is
+        // 2 KB of LDS per round, beyond (the reference clamps refineRoundsBC7 only from below, BC67.cpp:1044-1045) it lives
+        // in HBM: 2 KB per round and wave, so such a call goes in launches of as many waves as 256 MB of table hold
+        args.ptTrial = NULL;
+        size_t blocksPerLaunch = numBlocks;
+        if ((options->flags & CVTTMI_FLAG_BC7_RESPECT_PUNCHTHROUGH) && options->refineRoundsBC7 > 6)
+        {
+            const size_t perWave = (size_t)32 * 16 * sizeof(float) * (size_t)options->refineRoundsBC7;
+            size_t wavesPerLaunch = ((size_t)256 << 20) / perWave;
+            wavesPerLaunch = wavesPerLaunch < 1 ? 1 : wavesPerLaunch;
+            const size_t wavesNeeded = (numBlocks + 15) / 16;
+            wavesPerLaunch = wavesPerLaunch > wavesNeeded ? wavesNeeded : wavesPerLaunch;
+            const size_t need = wavesPerLaunch * perWave;
+            if (ctx->dPtTrialBytes < need)
+            {
+                if (ctx->dPtTrial)
+                {
+                    hipDeviceSynchronize();
+                    hipFree(ctx->dPtTrial);
+                    ctx->dPtTrial = NULL;
+                    ctx->dPtTrialBytes = 0;
+                }
+                if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->dPtTrial), need)) != hipSuccess)
+                    return fail(ctx, CVTTMI_E_HIP, "hipMalloc(punch-through trial table)", e);
+                ctx->dPtTrialBytes = need;
+            }
+            args.ptTrial = ctx->dPtTrial;
+            blocksPerLaunch = wavesPerLaunch * 16;
+        }
+
+        // the hand-over list and the punch-through table exist once per context: launches that use them are ordered after
+        // the previous one that did (the plan ring is protected by its own per-slot events)
+        if (args.hardCap || args.ptTrial)
             orderAfterPrevious(ctx, stream);
         if (ctx->timing)
             hipEventRecord(ctx->evStart, stream);
-        e = cvttmi_launch_bc7(d_blocks, d_out, &args, ctx->dTables, dPlan, stream);
-        if (e != hipSuccess)
-            return fail(ctx, CVTTMI_E_HIP, "bc7 kernel launch", e);
-        if (args.hardCap)
+        for (size_t first = 0; first < numBlocks; first += blocksPerLaunch)
+        {
+            const size_t n = (numBlocks - first) < blocksPerLaunch ? (numBlocks - first) : blocksPerLaunch;
+            args.numBlocks = static_cast<uint32_t>(n);
+            e = cvttmi_launch_bc7(static_cast<const uint8_t *>(d_blocks) + first * 64, static_cast<uint8_t *>(d_out) + first * 16, &args, ctx->dTables, dPlan, stream);
+            if (e != hipSuccess)
+                return fail(ctx, CVTTMI_E_HIP, "bc7 kernel launch", e);
+        }
+        if (args.hardCap || args.ptTrial)
             markLaunch(ctx, stream);
-        if (hipEventRecord(ctx->evPlan[planSlot], stream) == hipSuccess)
-            ctx->planEventValid[planSlot] = true;
+        markPlanUse(ctx, planSlot, stream);
         if (ctx->timing)
         {
             hipEventRecord(ctx->evStop, stream);
@@ -1032,7 +1140,7 @@ extern "C"
 
     // mode 0: EncodeETC2, 1: EncodeETC2RGBA, 2: EncodeETC2Alpha
     static int etc2Device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
-                          const cvttmi_options *options, int mode, void *hipStream)
+                          const cvttmi_options *options, int mode, void *hipStream, const cvttmi_options *allocOptions = NULL)
     {
         if (!ctx)
             return CVTTMI_E_INVALID;
@@ -1043,6 +1151,7 @@ extern "C"
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu); // lastError, timing state and work buffers are per context
         hipStream_t stream = static_cast<hipStream_t>(hipStream);
         CvttEtcArgs args;
         memset(&args, 0, sizeof(args));
@@ -1050,8 +1159,10 @@ extern "C"
         args.gw = options->greenWeight;
         args.bw = options->blueWeight;
         {
-            // ETC2CompressionDataInternal constructor, reference ETC.cpp:3117-3145 (scalar binary32)
-            volatile float cd[3] = {options->redWeight, options->greenWeight, options->blueWeight};
+            // ETC2CompressionDataInternal constructor, reference ETC.cpp:3117-3145 (scalar binary32): the axes belong to
+            // the Options of AllocETC2Data, not to those of the Encode call
+            const cvttmi_options *ao = allocOptions ? allocOptions : options;
+            volatile float cd[3] = {ao->redWeight, ao->greenWeight, ao->blueWeight};
             volatile float rotCD[3] = {cd[1], cd[2], cd[0]};
             volatile float offs = -(rotCD[0] * cd[0] + rotCD[1] * cd[1] + rotCD[2] * cd[2]) / (cd[0] * cd[0] + cd[1] * cd[1] + cd[2] * cd[2]);
             volatile float a0[3] = {rotCD[0] + cd[0] * offs, rotCD[1] + cd[1] * offs, rotCD[2] + cd[2] * offs};
@@ -1093,7 +1204,7 @@ extern "C"
     }
 
     static int etc2Host(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
-                        const cvttmi_options *options, int mode)
+                        const cvttmi_options *options, int mode, const cvttmi_options *allocOptions = NULL)
     {
         if (!ctx)
             return CVTTMI_E_INVALID;
@@ -1106,7 +1217,22 @@ extern "C"
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
         std::lock_guard<std::recursive_mutex> lock(ctx->mu);
         return hostPipeline(ctx, reinterpret_cast<uint8_t *>(out), reinterpret_cast<const uint8_t *>(blocks), numBlocks, 64, (mode == 1 ? 16 : 8),
-                            [&](void *dOut, const void *dIn, size_t n, hipStream_t st) { return etc2Device(ctx, dOut, dIn, n, options, mode, st); });
+                            [&](void *dOut, const void *dIn, size_t n, hipStream_t st) { return etc2Device(ctx, dOut, dIn, n, options, mode, st, allocOptions); });
+    }
+
+    int cvttmi_encode_etc2_with_data_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options,
+                                            const cvttmi_options *allocOptions, int kind, void *hipStream)
+    {
+        if (kind != CVTTMI_ETC2_RGB && kind != CVTTMI_ETC2_RGBA && kind != CVTTMI_ETC2_PUNCHTHROUGH)
+            return ctx ? fail(ctx, CVTTMI_E_INVALID, "invalid argument") : CVTTMI_E_INVALID;
+        return etc2Device(ctx, d_out, d_blocks, numBlocks, options, kind, hipStream, allocOptions);
+    }
+    int cvttmi_encode_etc2_with_data(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks, const cvttmi_options *options,
+                                     const cvttmi_options *allocOptions, int kind)
+    {
+        if (kind != CVTTMI_ETC2_RGB && kind != CVTTMI_ETC2_RGBA && kind != CVTTMI_ETC2_PUNCHTHROUGH)
+            return ctx ? fail(ctx, CVTTMI_E_INVALID, "invalid argument") : CVTTMI_E_INVALID;
+        return etc2Host(ctx, out, blocks, numBlocks, options, kind, allocOptions);
     }
 
     int cvttmi_encode_etc2_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks, const cvttmi_options *options, void *hipStream)
@@ -1144,6 +1270,7 @@ extern "C"
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu); // lastError, timing state and work buffers are per context
         e = cvttmi_launch_eac11(d_blocksS16, d_out, static_cast<uint32_t>(numBlocks), isSigned, ctx->dTables, static_cast<hipStream_t>(hipStream));
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_HIP, "eac11 kernel launch", e);
@@ -1260,6 +1387,7 @@ extern "C"
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu); // lastError, timing state and work buffers are per context
         hipStream_t stream = static_cast<hipStream_t>(hipStream);
         CvttBc1Args args;
         fillWeightArgs(options, args.w, args.wSq, args.rcpW);
@@ -1303,6 +1431,7 @@ extern "C"
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess)
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu); // lastError, timing state and work buffers are per context
         hipStream_t stream = static_cast<hipStream_t>(hipStream);
         const uint32_t n = static_cast<uint32_t>(numBlocks);
         if (format == 2 || format == 3)
@@ -1398,6 +1527,7 @@ extern "C"
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
         std::lock_guard<std::recursive_mutex> lock(ctx->mu);
         return hostPipeline(ctx, reinterpret_cast<uint8_t *>(out), reinterpret_cast<const uint8_t *>(blocks), numBlocks, 64, 16,
-                            [&](void *dOut, const void *dIn, size_t n, hipStream_t st) { return cvttmi_encode_bc7_device(ctx, dOut, dIn, n, options, plan, st); });
+                            [&](void *dOut, const void *dIn, size_t n, hipStream_t st) { return cvttmi_encode_bc7_device(ctx, dOut, dIn, n, options, plan, st); },
+                            true /* reads every PixelBlock once: page-locked caller memory is used in place */);
     }
 }

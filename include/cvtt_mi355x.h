@@ -140,11 +140,14 @@ int cvttmi_host_unregister(cvttmi_context *ctx, void *ptr);
 
 /* ---- device-resident entry points: d_blocks / d_out are HBM pointers on the context's
  * device; the launch is asynchronous on `hipStream` (a hipStream_t, NULL = default).
- * Streams: a context owns ONE set of device work space (BC7 hand-over list and plan ring, BC6H endpoint
- * history).  The library orders the launches itself -- a call on another stream than the context's previous call
- * first makes its stream wait (hipStreamWaitEvent) for that call's launches -- and a mutex serialises the host side
- * of concurrent calls, so any stream / thread mix is SAFE on one context; it is not concurrent: use one context per
- * stream (or per worker thread, the reference's caller model, etc2packer.cpp:215-281) to overlap independent jobs. ---- */
+ * Streams: a context owns ONE set of device work space (BC7 hand-over list, punch-through trial table and plan ring,
+ * BC6H endpoint history).  The calls that use it (EncodeBC7 from half a million blocks or with BC7_RespectPunchThrough and
+ * more than 6 refine rounds, EncodeBC6H) are ordered by the library itself: such a call on another stream than the
+ * previous one first makes its stream wait (hipStreamWaitEvent) for that call's launches; a plan slot is rewritten only
+ * after every launch that read it, on whatever stream, has finished.  Calls that use no shared work space (BC1-BC5, ETC,
+ * EAC, decode, tiling) are simply queued on the stream given.  A mutex serialises the host side of EVERY call on a
+ * context, so any stream / thread mix is safe on one context; it is not concurrent: use one context per stream (or per
+ * worker thread, the reference's caller model, etc2packer.cpp:215-281) to overlap independent jobs. ---- */
 
 /* replaces cvtt::Kernels::EncodeBC7 (ConvectionKernels_API.cpp:41-54): numBlocks * 64 B
  * of PixelBlockU8 in, numBlocks * 16 B out. */
@@ -173,7 +176,9 @@ int cvttmi_encode_bc6h_device(cvttmi_context *ctx, void *d_out, const void *d_bl
  * 1889-2085).  numBlocks * 64 B of PixelBlockU8 in; 8 B (RGB, alpha) or 16 B (RGBA: EAC alpha
  * block then colour block) per block out.  The reference's ETC2CompressionData scratch
  * (AllocETC2Data / ReleaseETC2Data) has no counterpart: the kernels keep their scratch in
- * LDS and derive the two chroma axes from options->{red,green,blue}Weight on every call.
+ * LDS.  These calls derive the two chroma axes of the sector split from options->{red,green,blue}Weight,
+ * i.e. they behave like a caller who allocates with the options it encodes with; a caller whose two
+ * Options differ uses cvttmi_encode_etc2_with_data[_device] below.
  * Uses the colour weights and the Uniform / ETC_UseFakeBT709 / ETC_FakeBT709Accurate flags. */
 int cvttmi_encode_etc2_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
                               const cvttmi_options *options, void *hipStream);
@@ -201,6 +206,19 @@ int cvttmi_encode_etc2_punchthrough_alpha_device(cvttmi_context *ctx, void *d_ou
                                                  const cvttmi_options *options, void *hipStream);
 int cvttmi_encode_etc2_punchthrough_alpha(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
                                           const cvttmi_options *options);
+
+/* The reference fixes the two chroma axes when the scratch is ALLOCATED -- ETC2CompressionDataInternal's constructor
+ * computes them from the Options given to AllocETC2Data (ConvectionKernels_ETC.cpp:3117-3145) -- while the error weights
+ * come from the Options of each Encode call.  `allocOptions` = the Options the caller passed to AllocETC2Data (only its
+ * red / green / blue weights are read; NULL = `options`).  kind: CVTTMI_ETC2_RGB = EncodeETC2, CVTTMI_ETC2_RGBA =
+ * EncodeETC2RGBA, CVTTMI_ETC2_PUNCHTHROUGH = EncodeETC2PunchthroughAlpha (the three calls that take the scratch). */
+#define CVTTMI_ETC2_RGB 0
+#define CVTTMI_ETC2_RGBA 1
+#define CVTTMI_ETC2_PUNCHTHROUGH 4
+int cvttmi_encode_etc2_with_data_device(cvttmi_context *ctx, void *d_out, const void *d_blocks, size_t numBlocks,
+                                        const cvttmi_options *options, const cvttmi_options *allocOptions, int kind, void *hipStream);
+int cvttmi_encode_etc2_with_data(cvttmi_context *ctx, uint8_t *out, const uint8_t *blocks, size_t numBlocks,
+                                 const cvttmi_options *options, const cvttmi_options *allocOptions, int kind);
 
 /* ---- host-buffer convenience entry points: stage through pinned memory, launch, copy
  * back, synchronise.  Same semantics as the *_device calls. ---- */

@@ -81,6 +81,9 @@ int orc_encode_bc6h(uint8_t *out, const uint8_t *blocksF16, size_t numBlocks,
 /* mode 0: ETC2 RGB (8 B/block), 1: ETC2 RGBA = [EAC alpha | colour] (16 B/block), 2: EAC alpha (8 B/block) */
 int orc_encode_etc2(uint8_t *out, const uint8_t *blocks, size_t numBlocks,
                     const orc_options *options, int mode, int threads);
+/* the same with the Options of AllocETC2Data given apart (their colour weights fix the chroma axes, ETC.cpp:3117-3145) */
+int orc_encode_etc2_alloc(uint8_t *out, const uint8_t *blocks, size_t numBlocks, const orc_options *options,
+                          const orc_options *allocOptions, int mode, int threads);
 
 /* BC2 / BC3 / BC4U / BC4S / BC5U / BC5S (format 2..7; signed formats take PixelBlockS8): 8 B (BC4) or 16 B per block */
 int orc_encode_s3tc(uint8_t *out, const uint8_t *blocks, size_t numBlocks, const orc_options *options, int format,

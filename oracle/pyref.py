@@ -108,15 +108,18 @@ class RefLib:
                                  ctypes.c_size_t(n), options.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(int(signed)))
         return out.reshape(n, 16)
 
-    def encode_etc2(self, blocks, options, mode):
-        """mode 0: ETC2 RGB (8 B), 1: ETC2 RGBA (16 B), 2: EAC alpha (8 B), 3: ETC1 (8 B), 4: ETC2 punch-through alpha (8 B)."""
+    def encode_etc2(self, blocks, options, mode, alloc_options=None):
+        """mode 0: ETC2 RGB (8 B), 1: ETC2 RGBA (16 B), 2: EAC alpha (8 B), 3: ETC1 (8 B), 4: ETC2 punch-through alpha (8 B).
+        alloc_options: the Options handed to AllocETC2Data (default: the encode options)."""
         blocks, pb = _u8(blocks)
         n = blocks.size // 64
         assert n % 8 == 0
         per = 16 if mode == 1 else 8
         out = np.zeros(n * per, np.uint8)
-        rc = self.lib.ref_encode_etc2(out.ctypes.data_as(ctypes.c_void_p), pb, ctypes.c_size_t(n),
-                                      options.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(mode))
+        ao = options if alloc_options is None else alloc_options
+        self.lib.ref_encode_etc2_alloc.restype = ctypes.c_int
+        rc = self.lib.ref_encode_etc2_alloc(out.ctypes.data_as(ctypes.c_void_p), pb, ctypes.c_size_t(n),
+                                            options.ctypes.data_as(ctypes.c_void_p), ao.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(mode))
         assert rc == 0
         return out.reshape(n, per)
 
@@ -249,15 +252,18 @@ class OracleLib:
             raise RuntimeError("orc_encode_bc6h rc=%d" % rc)
         return out.reshape(n, 16)
 
-    def encode_etc2(self, blocks, options, mode, threads=1):
-        """mode 0: ETC2 RGB (8 B), 1: ETC2 RGBA (16 B), 2: EAC alpha (8 B), 3: ETC1 (8 B), 4: ETC2 punch-through alpha (8 B)."""
+    def encode_etc2(self, blocks, options, mode, threads=1, alloc_options=None):
+        """mode 0: ETC2 RGB (8 B), 1: ETC2 RGBA (16 B), 2: EAC alpha (8 B), 3: ETC1 (8 B), 4: ETC2 punch-through alpha (8 B).
+        alloc_options: the Options handed to AllocETC2Data (default: the encode options)."""
         blocks, pb = _u8(blocks)
         n = blocks.size // 64
         assert n % 8 == 0
         per = 16 if mode == 1 else 8
         out = np.zeros(n * per, np.uint8)
-        rc = self.lib.orc_encode_etc2(out.ctypes.data_as(ctypes.c_void_p), pb, ctypes.c_size_t(n),
-                                      options.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(mode), ctypes.c_int(threads))
+        ao = options if alloc_options is None else alloc_options
+        self.lib.orc_encode_etc2_alloc.restype = ctypes.c_int
+        rc = self.lib.orc_encode_etc2_alloc(out.ctypes.data_as(ctypes.c_void_p), pb, ctypes.c_size_t(n),
+                                            options.ctypes.data_as(ctypes.c_void_p), ao.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(mode), ctypes.c_int(threads))
         if rc != 0:
             raise RuntimeError("orc_encode_etc2 rc=%d" % rc)
         return out.reshape(n, per)

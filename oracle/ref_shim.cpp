@@ -127,10 +127,17 @@ extern "C"
     }
 
     // mode: 0 = ETC2 RGB (8 B/block), 1 = ETC2 RGBA (16 B/block), 2 = EAC alpha only (8 B/block), 3 = ETC1 (8 B/block), 4 = ETC2 punch-through alpha (8 B/block)
+    int ref_encode_etc2_alloc(uint8_t *out, const uint8_t *blocks, size_t numBlocks, const void *optionsBytes, const void *allocOptionsBytes, int mode);
     int ref_encode_etc2(uint8_t *out, const uint8_t *blocks, size_t numBlocks, const void *optionsBytes, int mode)
     {
-        cvtt::Options o;
+        return ref_encode_etc2_alloc(out, blocks, numBlocks, optionsBytes, optionsBytes, mode);
+    }
+    // allocOptionsBytes: the Options handed to AllocETC2Data (may differ from those of the Encode calls)
+    int ref_encode_etc2_alloc(uint8_t *out, const uint8_t *blocks, size_t numBlocks, const void *optionsBytes, const void *allocOptionsBytes, int mode)
+    {
+        cvtt::Options o, ao;
         memcpy(&o, optionsBytes, sizeof(o));
+        memcpy(&ao, allocOptionsBytes, sizeof(ao));
         const cvtt::PixelBlockU8 *in = reinterpret_cast<const cvtt::PixelBlockU8 *>(blocks);
         if (mode == 3)
         {
@@ -145,7 +152,7 @@ extern "C"
         cvtt::ETC2CompressionData *data = NULL;
         if (mode != 2)
         {
-            data = cvtt::Kernels::AllocETC2Data(shimAlloc, NULL, o);
+            data = cvtt::Kernels::AllocETC2Data(shimAlloc, NULL, ao);
             if (!data)
                 return -1;
         }

@@ -107,7 +107,7 @@ int main(int argc, char **argv)
                 in[b].m_pixels[p][c] = (uint8_t)v;
                 hdr[b].m_pixels[p][c] = (int16_t)(c == 3 ? 0x3C00 : (((8 + (b + p + c) % 12) << 10) | ((131 * b + 61 * p + 17 * c + 7 * p * p) & 0x3FF)));
             }
-    uint8_t out[10][128];
+    uint8_t out[11][128];
     memset(out, 0, sizeof(out));
     cvtt::Kernels::EncodeBC7(out[0], in, options, plan);
     cvtt::Kernels::EncodeBC1(out[1], in, options);
@@ -125,7 +125,13 @@ int main(int argc, char **argv)
     cvtt::Kernels::EncodeETC1(out[8], in, options, data1);
     cvtt::Kernels::ReleaseETC1Data(data1, release);
     cvtt::Kernels::EncodeBC7(out[9], in, options, qplan);
-    for (int k = 0; k < 10; k++)
+    // scratch allocated with other Options than the Encode call's: the chroma axes are the allocation's (ETC.cpp:3117-3145)
+    cvtt::Options other;
+    other.redWeight = 0.9f; other.greenWeight = 0.3f; other.blueWeight = 0.6f;
+    data = cvtt::Kernels::AllocETC2Data(allocate, NULL, other);
+    cvtt::Kernels::EncodeETC2RGBA(out[10], in, options, data);
+    cvtt::Kernels::ReleaseETC2Data(data, release);
+    for (int k = 0; k < 11; k++)
     {
         for (int i = 0; i < 128; i++)
             printf("%02x", out[k][i]);
@@ -188,7 +194,24 @@ def test_cxx_api_matches_oracle(tmp_path, oracle_lib, gpu_ctx):
     qplan = api.BC7EncodingPlan()
     api.ConfigureBC7EncodingPlanFromQuality(qplan, 20)
     want.append(oracle_lib.encode_bc7(ldr, o, np.frombuffer(bytes(qplan), np.uint8).copy(), rcp))
+    want.append(oracle_lib.encode_etc2(ldr, o, mode=1, alloc_options=pyref.make_options(weights=(0.9, 0.3, 0.6, 1.0))))
     for k, w in enumerate(want):
         got = bytes.fromhex(lines[k])[:w.size]
         assert got == w.tobytes(), k
-    assert lines[10:12] == ["threads", "0"]  # four caller threads, a context each, same blocks as the main thread's
+    assert lines[11:13] == ["threads", "0"]  # four caller threads, a context each, same blocks as the main thread's
+
+
+def test_headline_kernel_needs_no_scratch():
+    """the BC7 fast-indexing kernel (BASELINE configs[1]) is built for 4 waves per SIMD (128 VGPRs, <= 10 240 B of LDS) and
+    must not spill: 64 B of scratch per lane were 2.8x the algorithmic HBM traffic in round 2 (tools/kernel_resources.py
+    reads the code objects of the shipped library)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    if not os.path.exists(m.READELF):
+        pytest.skip("llvm-readelf not installed")
+    k = m.kernels()
+    head = [v for name, v in k.items() if name.startswith("cvttmi_bc7_kernel<true, false, false>")]
+    assert len(head) == 1, sorted(k)
+    assert head[0]["scratch_bytes_per_lane"] == 0 and head[0]["vgpr"] <= 128 and head[0]["lds_bytes"] <= 10240, head[0]

@@ -141,11 +141,28 @@ def test_device_tensor_path_and_ragged_sizes(gpu_ctx, oracle_lib):
         gpu_ctx.encode_bc7(np.zeros((4, 16, 4), np.uint8))
 
 
-def test_unsupported_flags_fail_loudly(gpu_ctx):
+def test_respect_punchthrough_many_refine_rounds(gpu_ctx, oracle_lib):
+    """BC7_RespectPunchThrough with more refine rounds than the LDS trial table holds (6): the reference clamps
+    refineRoundsBC7 only from below (BC67.cpp:1044-1045), so 7 and 9 rounds must work too -- the table moves to HBM and a
+    large call goes in several launches (the second shape: enough blocks for two launches at 9 rounds is too slow for a
+    test, so the chunking is exercised through the table size knob of the shim's arithmetic: 512 blocks = 32 waves)"""
     api = _api()
-    with pytest.raises(api.CvttError):
-        gpu_ctx.encode_bc7(np.zeros((8, 16, 4), np.uint8),
-                           api.Options(flags=api.Flags.Default | api.Flags.BC7_RespectPunchThrough, refineRoundsBC7=7))
+    rcp = oracle_lib.probe_rcp()
+    gpu_ctx.set_rcp_table(rcp)
+    blocks = np.concatenate([content.mixed_ldr_blocks(4242, 40), content.mixed_ldr_blocks(9, 24)[::-1]])
+    plan = api.BC7EncodingPlan()
+    PTF = api.Flags.BC7_RespectPunchThrough
+    for opt in (api.Options(flags=api.Flags.Default | PTF, refineRoundsBC7=7), api.Options(flags=api.Flags.Better | PTF, refineRoundsBC7=9),
+                api.Options(flags=api.Flags.Default | PTF | api.Flags.Uniform, refineRoundsBC7=12)):
+        exp = oracle_lib.encode_bc7(blocks, np.frombuffer(opt.tobytes(), np.uint8).copy(),
+                                    np.frombuffer(plan.tobytes(), np.uint8).copy(), rcp, threads=8)
+        out = gpu_ctx.encode_bc7(blocks, opt, plan)
+        bad = _diff(out, exp)
+        assert bad.size == 0, "flags %x refine %d blocks %s" % (opt.flags, opt.refineRoundsBC7, bad[:8])
+    # back to a table that fits LDS on the same context
+    opt = api.Options(flags=api.Flags.Default | PTF)
+    exp = oracle_lib.encode_bc7(blocks, np.frombuffer(opt.tobytes(), np.uint8).copy(), np.frombuffer(plan.tobytes(), np.uint8).copy(), rcp, threads=8)
+    assert _diff(gpu_ctx.encode_bc7(blocks, opt, plan), exp).size == 0
 
 
 def test_respect_punchthrough(gpu_ctx, oracle_lib):

@@ -65,6 +65,27 @@ def test_oracle_vs_reference(oracle_lib, ref_lib):
             assert (oracle_lib.encode_etc2(blocks, opt, mode, 8) == ref_lib.encode_etc2(blocks, opt, mode)).all()
 
 
+def _alloc_cases():
+    """(encode options, AllocETC2Data options): the chroma axes follow the second (reference ETC.cpp:3117-3145)"""
+    a = pyref.make_options(weights=(0.9, 0.3, 0.6, 1.0))
+    b = pyref.make_options(weights=(0.1, 1.0, 0.8, 1.0), flags=pyref.FLAGS_DEFAULT | 0x400)  # + ETC_UseFakeBT709
+    return [(pyref.make_options(), a), (a, pyref.make_options()), (pyref.make_options(flags=pyref.FLAG_UNIFORM), b)]
+
+
+def test_oracle_alloc_time_axes_vs_reference(oracle_lib, ref_lib):
+    """AllocETC2Data(options A) + EncodeETC2*(options B): the sector split uses A's axes, the error metric B's weights"""
+    blocks = np.concatenate([content.mixed_ldr_blocks(77, 24), content.config_blocks(4, 32, 32)])
+    pt = content.punchthrough_blocks(29, 1)
+    differs = 0
+    for enc, alloc in _alloc_cases():
+        for mode in (0, 1, 4):
+            b = pt if mode == 4 else blocks
+            want = ref_lib.encode_etc2(b, enc, mode, alloc_options=alloc)
+            assert (oracle_lib.encode_etc2(b, enc, mode, 8, alloc_options=alloc) == want).all(), mode
+            differs += int((want != ref_lib.encode_etc2(b, enc, mode)).any())
+    assert differs > 0  # the allocation-time options do matter on this content
+
+
 FAKE_NAMES = ["fake709", "fake709_accurate", "fake709_uniform"]
 
 
@@ -257,3 +278,22 @@ def test_gpu_eac11(gpu_ctx, oracle_lib):
     t = torch.from_numpy(b).cuda()
     for sg in (False, True):
         assert (gpu_ctx.encode_etc2_alpha11(t, signed=sg).cpu().numpy() == oracle_lib.encode_eac11(b, sg)).all()
+
+
+@pytest.mark.gpu
+def test_gpu_alloc_time_axes(gpu_ctx, oracle_lib):
+    """the drop-in keeps the reference's split of responsibilities: axes from the Options of AllocETC2Data, weights from the
+    Options of the Encode call (cvttmi_encode_etc2_with_data; ConvectionKernels_ETC.cpp:3117-3145)"""
+    from convectionkernels_amd import api
+    ref = pyref.RefLib() if pyref.RefLib.available() else None
+    blocks = np.concatenate([content.mixed_ldr_blocks(77, 24), content.config_blocks(4, 32, 32)])
+    pt = content.punchthrough_blocks(29, 1)
+    for enc, alloc in _alloc_cases():
+        data = api.AllocETC2Data(api.Options.frombytes(alloc))
+        eo = api.Options.frombytes(enc)
+        for mode, fn in ((0, gpu_ctx.encode_etc2), (1, gpu_ctx.encode_etc2_rgba), (4, gpu_ctx.encode_etc2_punchthrough_alpha)):
+            b = pt if mode == 4 else blocks
+            want = ref.encode_etc2(b, enc, mode, alloc_options=alloc) if ref else oracle_lib.encode_etc2(b, enc, mode, 8, alloc_options=alloc)
+            got = fn(b, eo, compression_data=data)
+            bad = np.nonzero((got != want).any(axis=1))[0]
+            assert bad.size == 0, (mode, bad[:8])
