@@ -87,6 +87,21 @@ constexpr float kBoundGrid8 = 124.0f, kBoundLimit8 = 127.0f;
 #ifdef CVTT_BC7_PROFILE
 __device__ unsigned long long g_bc7Prof[48];
 __device__ unsigned long long g_bc7Dup[8]; // chain rounds: total, same endpoints as a lower seed point this round, seen in an earlier round of the group
+// per single-plane stage (6, 7, 1, 3, 0, 2): chain batches, units searched, partitions alive when the stage starts (after
+// both bound tiers), offer rounds, partitions committed as the block's new best, active chain lanes, wave-stages entered
+__device__ unsigned long long g_bc7Stage[6][8];
+__device__ unsigned long long g_bc7Stage2[6][8]; // what-if counters of the subset-by-subset cut-off (see the commit loop)
+extern "C" int cvttmi_bc7_stage_read(unsigned long long *out)
+{
+    unsigned long long zero[48] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bc7Stage), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bc7Stage), zero, sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out + 48, HIP_SYMBOL(g_bc7Stage2), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bc7Stage2), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#define PROF_STAGE(stage, slot, n) { const unsigned long long v_ = (unsigned long long)(n); if (threadIdx.x == 0 && v_) atomicAdd(&g_bc7Stage[stage][slot], v_); }
+#define PROF_STAGE_LANES(stage, slot, pred) { const unsigned long long v_ = (unsigned long long)__popcll(__ballot(pred)); if (threadIdx.x == 0 && v_) atomicAdd(&g_bc7Stage[stage][slot], v_); }
 extern "C" int cvttmi_bc7_dup_read(unsigned long long *out)
 {
     unsigned long long zero[8] = {0};
@@ -114,6 +129,8 @@ extern "C" int cvttmi_bc7_prof_read(unsigned long long *out)
 #define PROF_MARK(slot)
 #define PROF_COUNT(slot, n)
 #define PROF_FLUSH
+#define PROF_STAGE(stage, slot, n)
+#define PROF_STAGE_LANES(stage, slot, pred)
 #endif
 
 // Developer-only trial trace (-DCVTT_BC7_DEBUG): per-round results of the dual-plane search of one block.
@@ -2648,6 +2665,14 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         }
         PROF_COUNT(4, __popc(aliveBits))
         PROF_COUNT(5, (c == 0 && valid) ? 1 : 0)
+#ifdef CVTT_BC7_PROFILE
+        {
+            int cntAlive = __popc(aliveBits);
+            for (int st = 1; st < 64; st <<= 1) cntAlive += __shfl_xor(cntAlive, st);
+            PROF_STAGE(stageIter, 2, cntAlive)
+            PROF_STAGE(stageIter, 6, 1)
+        }
+#endif
         const int itemCap = (numSubsets == 3) ? 21 : 32; // items * subsets <= 64 lanes of the seed pass
         // BC7_RespectPunchThrough couples the 8 blocks of a group in modes 6 and 7 (BC67.cpp:1283-1428): a
         // partition one block wants is searched by its whole group, trial by trial in lock-step
@@ -2729,6 +2754,8 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             if (numItems == 0)
                 break;
             const int numUnits = numItems * numSubsets;
+            PROF_STAGE(stageIter, 1, numUnits)
+            PROF_STAGE(stageIter, 3, 1)
             __syncthreads();
 
             // ---- PCA seed search: lane l takes unit l = (item, subset) ----
@@ -2902,6 +2929,8 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 const float uvs[4] = {r.vs[0], r.vs[1], r.vs[2], r.vs[3]};
                 PROF_COUNT(2, 64)
                 PROF_COUNT(3, __popcll(__ballot(active)))
+                PROF_STAGE(stageIter, 0, 1)
+                PROF_STAGE_LANES(stageIter, 5, active)
                 ShapeBest b;
                 if (ptStage)
                 {
@@ -3034,6 +3063,50 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 {
                     const int item = s_myItems[blk][j];
                     const int partition = (int)(s_item[item] >> 8);
+#ifdef CVTT_BC7_PROFILE
+                    if (prune && numSubsets >= 2 && !ptStage)
+                    {
+                        // how often would the exact error of ONE subset plus the full-dimension bound of the rest already rule the
+                        // partition out?  (slots of g_bc7Stage2: items, first = subset 0, first = subset 1, first = the larger
+                        // subset, first = the subset with the larger bound, either order, total bound alone (stale best))
+                        u32 lpix[16];
+                        pixFromLds(lpix);
+                        u32 CMp[4][4];
+                        channelMajor(lpix, CMp);
+                        float lw4[4] = {A.w[0], A.w[1], A.w[2], A.w[3]};
+                        float lbS[3] = {0, 0, 0}, eS[3] = {0, 0, 0};
+                        int nS[3] = {0, 0, 0};
+                        const bool use4p = (boundSet == 0);
+                        for (int sub = 0; sub < numSubsets; sub++)
+                        {
+                            const int shape = numSubsets == 2 ? T->shapes2[partition][sub] : T->shapes3[partition][sub];
+                            RawSums rs;
+                            maskedRawSumsCM(CMp, T->shapeMask[shape], rs);
+                            const float v = use4p ? subsetBoundFull<4>(rs, lw4, A.delta4) : subsetBoundFull<3>(rs, lw4, A.delta3);
+                            const float e = __builtin_bit_cast(float, s_res[item * numSubsets + sub][0]);
+                            if (sub == 0) { lbS[0] = v; eS[0] = e; nS[0] = rs.n; } else if (sub == 1) { lbS[1] = v; eS[1] = e; nS[1] = rs.n; } else { lbS[2] = v; eS[2] = e; nS[2] = rs.n; }
+                        }
+                        const float extra = use4p ? 0.0f : staticAlphaBlock;
+                        const float lbAll = lbS[0] + lbS[1] + lbS[2] + extra;
+                        const bool cut0 = eS[0] + (lbAll - lbS[0]) > work.err;
+                        const bool cut1 = eS[1] + (lbAll - lbS[1]) > work.err;
+                        const int big = (nS[1] > nS[0]) ? 1 : 0, hiLb = (lbS[1] > lbS[0]) ? 1 : 0;
+                        const bool cutBig = big ? cut1 : cut0, cutLb = hiLb ? cut1 : cut0;
+                        const bool cnt = (c == 0);
+                        const int sI = stageIter;
+                        PROF_STAGE_LANES(sI + 0, 7, false)
+                        {
+                            const unsigned long long v0 = __popcll(__ballot(cnt)), v1 = __popcll(__ballot(cnt && cut0)), v2 = __popcll(__ballot(cnt && cut1)),
+                                                     v3 = __popcll(__ballot(cnt && cutBig)), v4 = __popcll(__ballot(cnt && cutLb)), v5 = __popcll(__ballot(cnt && (cut0 || cut1))),
+                                                     v6 = __popcll(__ballot(cnt && lbAll > work.err)), v7 = __popcll(__ballot(cnt && (eS[0] + eS[1] + eS[2] + extra * 0.0f) < work.err));
+                            if (threadIdx.x == 0)
+                            {
+                                atomicAdd(&g_bc7Stage2[sI][0], v0); atomicAdd(&g_bc7Stage2[sI][1], v1); atomicAdd(&g_bc7Stage2[sI][2], v2); atomicAdd(&g_bc7Stage2[sI][3], v3);
+                                atomicAdd(&g_bc7Stage2[sI][4], v4); atomicAdd(&g_bc7Stage2[sI][5], v5); atomicAdd(&g_bc7Stage2[sI][6], v6); atomicAdd(&g_bc7Stage2[sI][7], v7);
+                            }
+                        }
+                    }
+#endif
                     float totalError = 0.0f;
                     u32 pe[3][2] = {{0, 0}, {0, 0}, {0, 0}};
                     u32 pIdxLo = 0, pIdxHi = 0;
@@ -3052,6 +3125,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     bool mayTake = laneRuns;
                     if (ptStage && mode == 7 && anyBlockHasAlpha && !blockHasNonMaxAlpha && ((mode7RGB >> partition) & 1ull) == 0)
                         mayTake = false; // searched for the group's sake only (BC67.cpp:1625-1635)
+                    PROF_STAGE_LANES(stageIter, 4, c == 0 && mayTake && (totalError < work.err || (totalError == work.err && seq < workSeq)))
                     if (mayTake && (totalError < work.err || (totalError == work.err && seq < workSeq)))
                     {
                         work.err = totalError;
