@@ -1866,8 +1866,8 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     __shared__ u32 s_pix[16][16];     // the 16 blocks of this wave
     __shared__ u32 s_blkFlags[16];    // wantPCA4 of the block's group
     __shared__ int s_scatter[16][14]; // raw sums (sum x per channel, sum x_r x_c) of every block: the scatter matrix of the bounds and the totals of the second tier come from here
-    __shared__ u32 s_item[32];        // offers of the round: block | partition << 8
-    __shared__ uint8_t s_myItems[16][32]; // the items a block offered this round
+    __shared__ u32 s_item[64];        // items of the current phase of a round: block | partition << 8 (up to 64 probes)
+    __shared__ uint8_t s_myItems[PT ? 16 : 1][32]; // punch-through stages only: the items a block offered this round (elsewhere a block's items are consecutive)
     __shared__ UnitRec s_unit[64];    // PCA seeds per (item, subset)
     // best of every (item, subset) = unit of the round: error, endpoints, indexes.  (During the dual-plane search the same
     // bytes hold the channel-major copy of the blocks, read with 128-bit loads.)
@@ -2677,12 +2677,31 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         // BC7_RespectPunchThrough couples the 8 blocks of a group in modes 6 and 7 (BC67.cpp:1283-1428): a
         // partition one block wants is searched by its whole group, trial by trial in lock-step
         const bool ptStage = PT && (mode == 6 || mode == 7);
+        // Everything else takes its partitions SUBSET BY SUBSET.  The offers of a round (a set of partitions per block, kept
+        // as a 64-bit mask) are first PROBED: one unit per partition, its largest subset, searched exactly; the subset's
+        // exact error plus the full-dimension bound of the other subset(s) is again a lower bound of the partition's total,
+        // and on smooth, photo-like and two-colour content -- where the geometric bounds say little because the errors are
+        // quantisation errors -- it rules out 76-99 % of the probed partitions (profiles/r03/bc7_stage_whatif.txt).  Only
+        // the survivors are then searched in full (all subsets, payload kept) and committed as before.  The items of a
+        // phase are numbered block by block (a block's items are consecutive), in chunks of what the 64 result slots hold.
+        const bool staged = !ptStage;
+        const bool probing = staged && prune && numSubsets >= 2 && (A.prune & 2u) == 0; // (bit 1 of A.prune: developer knob, probes off)
+        const int offerCap = probing ? 64 : itemCap;
+        // the subset of a partition that is probed: the one with the most pixels (the first of them)
+        auto probeSubOf = [&](int partition) -> int {
+            if (numSubsets == 2)
+                return __popc(T->shapeMask[T->shapes2[partition][1]]) > __popc(T->shapeMask[T->shapes2[partition][0]]) ? 1 : 0;
+            const int n0 = __popc(T->shapeMask[T->shapes3[partition][0]]), n1 = __popc(T->shapeMask[T->shapes3[partition][1]]),
+                      n2 = __popc(T->shapeMask[T->shapes3[partition][2]]);
+            return (n2 > n0 && n2 > n1) ? 2 : (n1 > n0) ? 1 : 0;
+        };
         for (;;)
         {
             // ---- offers.  Pass 0: every block offers its cheapest-bound candidate.  When few blocks
             // offer, the idle lanes take further candidates of the same blocks (they might have been
             // pruned by the first result, but waiting for it would cost a whole round). ----
             int numItems = 0, myCount = 0, maxPasses = 1;
+            u64 offerMask = 0; // staged: the partitions this block offers in this round (the same in the four lanes of the quad)
             for (int pass = 0; pass < maxPasses; pass++)
             {
                 // quad-wide argmin of the bounds still alive (ties: lowest partition)
@@ -2733,17 +2752,26 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 }
                 const u64 offers = __ballot(offer && c == 0);
                 const int numOffers = __popcll(offers);
-                if (numOffers == 0 || numItems + numOffers > itemCap)
+                if (numOffers == 0 || numItems + numOffers > offerCap)
                     break;
                 if (pass == 0 && !ptStage)
+                {
                     maxPasses = (numOffers <= 1) ? CVTT_SPEC_1 : (numOffers <= 2) ? CVTT_SPEC_2 : (numOffers <= 4) ? CVTT_SPEC_4 : (numOffers <= 8) ? CVTT_SPEC_8 : CVTT_SPEC_16;
+                    if (probing)
+                        maxPasses = maxPasses * 2 > 32 ? 32 : maxPasses * 2; // a probe is one unit per partition: twice the partitions per round
+                }
                 if (offer)
                 {
-                    const int item = numItems + __popcll(offers & ((1ull << (lane & ~3)) - 1ull));
-                    if (c == 0)
+                    if (staged)
+                        offerMask |= 1ull << pick;
+                    else
                     {
-                        s_item[item] = (u32)blk | ((u32)pick << 8);
-                        s_myItems[blk][pass] = (uint8_t)item;
+                        const int item = numItems + __popcll(offers & ((1ull << (lane & ~3)) - 1ull));
+                        if (c == 0)
+                        {
+                            s_item[item] = (u32)blk | ((u32)pick << 8);
+                            s_myItems[PT ? blk : 0][pass] = (uint8_t)item;
+                        }
                     }
                     if ((pick & 3) == c)
                         aliveBits &= ~(1u << (pick >> 2));
@@ -2753,9 +2781,48 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             }
             if (numItems == 0)
                 break;
-            const int numUnits = numItems * numSubsets;
-            PROF_STAGE(stageIter, 1, numUnits)
             PROF_STAGE(stageIter, 3, 1)
+            u64 curMask = offerMask; // staged: this block's partitions of the current phase
+            bool isProbe = probing;
+            int chunkLo = 0;
+            for (;;) // phases of the round: [probe,] then the full search of the survivors, chunk by chunk
+            {
+            PROF_MARK(4)
+            int iLo = 0, iHi = 0, phaseTotal = numItems;
+            if (staged)
+            {
+                // number the items block by block and write this chunk's part of the list
+                const int kb = __popcll(curMask);
+                int base = 0;
+                phaseTotal = 0;
+#pragma unroll
+                for (int b = 0; b < 16; b++)
+                {
+                    const int o = __shfl(kb, 4 * b);
+                    base += (b < blk) ? o : 0;
+                    phaseTotal += o;
+                }
+                phaseTotal = __builtin_amdgcn_readfirstlane(phaseTotal);
+                const int cap = isProbe ? 64 : itemCap;
+                numItems = phaseTotal - chunkLo < cap ? phaseTotal - chunkLo : cap;
+                iLo = base - chunkLo;
+                iHi = iLo + kb;
+                iLo = iLo < 0 ? 0 : (iLo > numItems ? numItems : iLo);
+                iHi = iHi < 0 ? 0 : (iHi > numItems ? numItems : iHi);
+                // sub-lane c files the partitions 16c .. 16c+15 of the block's mask
+                u32 part = (u32)(curMask >> (16 * c)) & 0xffffu;
+                int rnk = base - chunkLo + __popcll(curMask & ((1ull << (16 * c)) - 1ull));
+                while (part)
+                {
+                    const int bit = __ffs((int)part) - 1;
+                    part &= part - 1u;
+                    if (rnk >= 0 && rnk < numItems)
+                        s_item[rnk] = (u32)blk | ((u32)(16 * c + bit) << 8);
+                    rnk++;
+                }
+            }
+            const int numUnits = isProbe ? numItems : numItems * numSubsets;
+            PROF_STAGE(stageIter, isProbe ? 7 : 1, numUnits)
             __syncthreads();
 
             // ---- PCA seed search: lane l takes unit l = (item, subset) ----
@@ -2768,9 +2835,9 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 int cnt = 0;
                 if (lane < numUnits && numSubsets >= 2 && !ptStage)
                 {
-                    const int item = (numSubsets == 2) ? (lane >> 1) : (lane / 3);
-                    const int sub = lane - item * numSubsets;
+                    const int item = isProbe ? lane : (numSubsets == 2) ? (lane >> 1) : (lane / 3);
                     const int upart = (int)(s_item[item] >> 8);
+                    const int sub = isProbe ? probeSubOf(upart) : lane - item * numSubsets;
                     cnt = __popc(T->shapeMask[(numSubsets == 2) ? T->shapes2[upart][sub] : T->shapes3[upart][sub]]);
                 }
                 if (numSubsets >= 2 && !ptStage)
@@ -2789,10 +2856,10 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             }
             if (lane < numUnits)
             {
-                const int item = (numSubsets == 1) ? lane : (numSubsets == 2) ? (lane >> 1) : (lane / 3);
-                const int sub = lane - item * numSubsets;
+                const int item = (isProbe || numSubsets == 1) ? lane : (numSubsets == 2) ? (lane >> 1) : (lane / 3);
                 const u32 it = s_item[item];
                 const int ublk = (int)(it & 255u), upart = (int)(it >> 8);
+                const int sub = isProbe ? probeSubOf(upart) : lane - item * numSubsets;
                 int shape = 0;
                 if (numSubsets == 2)
                     shape = T->shapes2[upart][sub];
@@ -2860,7 +2927,8 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #pragma unroll
                 for (int ch = 0; ch < 4; ch++)
                     r.vs[ch] = vsum[ch];
-                r.packed = uMask | ((u32)(seeds < 0 ? 0 : seeds) << 16) | ((u32)ublk << 20) | ((u32)(item * numSubsets + sub) << 24);
+                // where the unit's result goes: a probe's by item, a full search's by (item, subset)
+                r.packed = uMask | ((u32)(seeds < 0 ? 0 : seeds) << 16) | ((u32)ublk << 20) | ((u32)(isProbe ? item : item * numSubsets + sub) << 24);
                 float scErr = FLT_MAX;
                 if ((A.flags & CVTTMI_FLAG_BC7_TRY_SINGLE_COLOR) && seeds > 0)
                 {
@@ -2966,6 +3034,66 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             }
             __syncthreads();
 
+            if (isProbe)
+            {
+                // ---- which of the probed partitions can still win?  Exact error of the probed subset + full-dimension
+                // bound of the other subset(s) <= the partition's total in the reference: for two subsets the total is the
+                // float sum of the same two kinds of terms (rounding is monotone); for three the association differs, which
+                // the factor below covers (the total is >= the real sum * (1 - 2u), this sum <= the real one * (1 + 2u)).
+                // Sub-lane c takes the block's items c, c + 4, ... ----
+                u64 surv = 0;
+                if (__ballot(iLo + c < iHi) != 0)
+                {
+                    u32 CMf[4][4];
+                    {
+                        u32 lpix[16];
+                        pixFromLds(lpix);
+                        channelMajor(lpix, CMf);
+                    }
+                    const bool use4 = (boundSet == 0);
+                    const float lwf[4] = {A.w[0], A.w[1], A.w[2], A.w[3]};
+                    for (int i = iLo + c; __ballot(i < iHi) != 0; i += 4)
+                    {
+                        if (i < iHi)
+                        {
+                            const int partition = (int)(s_item[i] >> 8);
+                            const float eProbed = __builtin_bit_cast(float, s_res[i][0]);
+                            const int ps = probeSubOf(partition);
+                            float lbRest = 0.0f;
+                            for (int sub = 0; sub < numSubsets; sub++)
+                            {
+                                if (sub == ps)
+                                    continue;
+                                RawSums rs;
+                                maskedRawSumsCM(CMf, T->shapeMask[(numSubsets == 2) ? T->shapes2[partition][sub] : T->shapes3[partition][sub]], rs);
+                                lbRest += use4 ? subsetBoundFull<4>(rs, lwf, A.delta4) : subsetBoundFull<3>(rs, lwf, A.delta3);
+                            }
+                            const float lbTotal = (eProbed + lbRest) * 0.9999995f;
+
+                            if (!(lbTotal > work.err))
+                                surv |= 1ull << partition;
+                        }
+                    }
+                }
+                {
+                    u32 lo = (u32)surv, hi = (u32)(surv >> 32);
+                    lo |= __shfl_xor(lo, 1);
+                    hi |= __shfl_xor(hi, 1);
+                    lo |= __shfl_xor(lo, 2);
+                    hi |= __shfl_xor(hi, 2);
+                    surv = ((u64)hi << 32) | lo;
+                }
+                PROF_STAGE_LANES(stageIter, 0, false)
+                curMask = surv;
+                isProbe = false;
+                chunkLo = 0;
+                const bool anyLeft = __ballot(surv != 0) != 0;
+                __syncthreads(); // everybody has read its items before the next list is written
+                if (!anyLeft)
+                    break;
+                continue;
+            }
+
             if (PT && ptStage)
             {
                 __syncthreads();
@@ -3055,13 +3183,14 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 }
             }
             // ---- every offering block adds up the subsets of its items and commits ----
-            for (int j = 0; j < 32; j++)
+            for (int j = 0; j < 64; j++)
             {
-                if (__ballot(j < myCount) == 0)
+                const bool mine = staged ? (iLo + j < iHi) : (j < myCount);
+                if (__ballot(mine) == 0)
                     break;
-                if (j < myCount)
+                if (mine)
                 {
-                    const int item = s_myItems[blk][j];
+                    const int item = staged ? iLo + j : (int)s_myItems[PT ? blk : 0][j];
                     const int partition = (int)(s_item[item] >> 8);
 #ifdef CVTT_BC7_PROFILE
                     if (prune && numSubsets >= 2 && !ptStage)
@@ -3085,6 +3214,12 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                             const float v = use4p ? subsetBoundFull<4>(rs, lw4, A.delta4) : subsetBoundFull<3>(rs, lw4, A.delta3);
                             const float e = __builtin_bit_cast(float, s_res[item * numSubsets + sub][0]);
                             if (sub == 0) { lbS[0] = v; eS[0] = e; nS[0] = rs.n; } else if (sub == 1) { lbS[1] = v; eS[1] = e; nS[1] = rs.n; } else { lbS[2] = v; eS[2] = e; nS[2] = rs.n; }
+                        }
+                        {
+                            // per-subset validity of the full-dimension bound (it must never exceed the subset's exact error)
+                            const unsigned long long viol = __popcll(__ballot(c == 0 && (lbS[0] > eS[0] || lbS[1] > eS[1] || (numSubsets == 3 && lbS[2] > eS[2]))));
+                            if (threadIdx.x == 0 && viol)
+                                atomicAdd(&g_bc7Dup[7], viol);
                         }
                         const float extra = use4p ? 0.0f : staticAlphaBlock;
                         const float lbAll = lbS[0] + lbS[1] + lbS[2] + extra;
@@ -3135,6 +3270,13 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     }
                 }
             }
+            if (!staged)
+                break;
+            chunkLo += itemCap;
+            if (chunkLo >= phaseTotal)
+                break;
+            __syncthreads(); // the commits have read this chunk's items and results
+            } // phases of the round
             PROF_MARK(4)
         }
     }
