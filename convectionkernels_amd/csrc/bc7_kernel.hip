@@ -82,6 +82,10 @@ constexpr float kBoundGrid8 = 124.0f, kBoundLimit8 = 127.0f;
 #ifndef CVTT_SPEC_16
 #define CVTT_SPEC_16 2
 #endif
+// probe survivors a wave collects before it searches them in full (one full-search chunk holds 32 / 21 partitions)
+#ifndef CVTT_PEND_MIN
+#define CVTT_PEND_MIN 20
+#endif
 
 // Developer-only phase profile (-DCVTT_BC7_PROFILE): wave cycles per phase, summed over waves.
 #ifdef CVTT_BC7_PROFILE
@@ -2383,8 +2387,13 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         staticAlphaBlock = ((A.flags & CVTTMI_FLAG_UNIFORM) ? (float)(int)acc : (float)(int)acc * A.wSq[3]) * 0.9999f;
     }
 
-    for (int stageIter = 0; stageIter < 6; stageIter++)
+    for (int stageOrder = 0; stageOrder < 6; stageOrder++)
     {
+        // The order of the stages is free (every commit compares (error, position in the reference's order)).  A wave without a
+        // single translucent pixel searches modes 1 and 3 before mode 7: there mode 7 -- the same partitions with coarser end
+        // points -- almost never wins, and what the other two find first prunes its partitions (smooth opaque gradients: 44
+        // -> ... partitions per block alive in mode 7); the three share one set of bounds.
+        const int stageIter = (ballotA == 0 && !HARD) ? ((stageOrder == 1) ? 2 : (stageOrder == 2) ? 3 : (stageOrder == 3) ? 1 : stageOrder) : stageOrder;
         ModeDesc md;
         int numSubsets, numPartitions, stage, boundSet;
         switch (stageIter)
@@ -2695,6 +2704,9 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                       n2 = __popc(T->shapeMask[T->shapes3[partition][2]]);
             return (n2 > n0 && n2 > n1) ? 2 : (n1 > n0) ? 1 : 0;
         };
+        // survivors of the probes wait here (per block) until the wave has enough of them for a well-filled full search
+        // (CVTT_PEND_MIN partitions) or the stage has nothing left to offer
+        u64 pend = 0;
         for (;;)
         {
             // ---- offers.  Pass 0: every block offers its cheapest-bound candidate.  When few blocks
@@ -2779,11 +2791,17 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 }
                 numItems += numOffers;
             }
-            if (numItems == 0)
+            const bool flush = (numItems == 0); // nothing left to offer: the waiting survivors are searched, then the stage ends
+            if (flush && __ballot(pend != 0) == 0)
                 break;
             PROF_STAGE(stageIter, 3, 1)
+            bool isProbe = probing && !flush;
             u64 curMask = offerMask; // staged: this block's partitions of the current phase
-            bool isProbe = probing;
+            if (!isProbe)
+            {
+                curMask |= pend;
+                pend = 0;
+            }
             int chunkLo = 0;
             for (;;) // phases of the round: [probe,] then the full search of the survivors, chunk by chunk
             {
@@ -3083,14 +3101,22 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     hi |= __shfl_xor(hi, 2);
                     surv = ((u64)hi << 32) | lo;
                 }
-                PROF_STAGE_LANES(stageIter, 0, false)
-                curMask = surv;
+                pend |= surv;
+                int pendTotal = 0;
+                {
+                    const int kb = __popcll(pend);
+#pragma unroll
+                    for (int b = 0; b < 16; b++)
+                        pendTotal += __shfl(kb, 4 * b);
+                    pendTotal = __builtin_amdgcn_readfirstlane(pendTotal);
+                }
+                __syncthreads(); // everybody has read its items before the next list is written
+                if (pendTotal < CVTT_PEND_MIN)
+                    break; // they wait for more
+                curMask = pend;
+                pend = 0;
                 isProbe = false;
                 chunkLo = 0;
-                const bool anyLeft = __ballot(surv != 0) != 0;
-                __syncthreads(); // everybody has read its items before the next list is written
-                if (!anyLeft)
-                    break;
                 continue;
             }
 
@@ -3278,6 +3304,8 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             __syncthreads(); // the commits have read this chunk's items and results
             } // phases of the round
             PROF_MARK(4)
+            if (flush)
+                break;
         }
     }
 
