@@ -94,7 +94,7 @@ __device__ unsigned long long g_bc7Dup[8]; // chain rounds: total, same endpoint
 // per single-plane stage (6, 7, 1, 3, 0, 2): chain batches, units searched, partitions alive when the stage starts (after
 // both bound tiers), offer rounds, partitions committed as the block's new best, active chain lanes, wave-stages entered
 __device__ unsigned long long g_bc7Stage[6][8];
-__device__ unsigned long long g_bc7Stage2[6][8]; // what-if counters of the subset-by-subset cut-off (see the commit loop)
+__device__ unsigned long long g_bc7Stage2[6][8]; // spare
 extern "C" int cvttmi_bc7_stage_read(unsigned long long *out)
 {
     unsigned long long zero[48] = {0};
@@ -113,9 +113,9 @@ extern "C" int cvttmi_bc7_dup_read(unsigned long long *out)
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_bc7Dup), zero, sizeof(zero)) != hipSuccess) return -1;
     return 0;
 }
-#define PROF_DECL unsigned long long profT = __builtin_readcyclecounter(); unsigned long long profAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long profCnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF_DECL unsigned long long profT = __builtin_readcyclecounter(); unsigned long long profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long profCnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define PROF_MARK(slot) { const unsigned long long now = __builtin_readcyclecounter(); profAcc[slot] += now - profT; profT = now; }
-#define PROF_FLUSH if (threadIdx.x == 0) { unsigned long long tot = 0; for (int i = 0; i < 8; i++) { atomicAdd(&g_bc7Prof[i], profAcc[i]); tot += profAcc[i]; } \
+#define PROF_FLUSH if (threadIdx.x == 0) { unsigned long long tot = 0; for (int i = 0; i < 16; i++) { atomicAdd(&g_bc7Prof[i], profAcc[i]); tot += profAcc[i]; } \
     int bucket = 63 - __builtin_clzll(tot | 1ull) - 12; bucket = bucket < 0 ? 0 : (bucket > 15 ? 15 : bucket); atomicAdd(&g_bc7Prof[16 + bucket], 1ull); \
     } { unsigned long long wsum[8]; for (int i = 0; i < 8; i++) { unsigned long long v = profCnt[i]; if (i >= 4) { for (int st = 1; st < 64; st <<= 1) v += __shfl_xor(v, st); } wsum[i] = v; } \
     if (threadIdx.x == 0) { for (int i = 0; i < 8; i++) atomicAdd(&g_bc7Prof[32 + i], wsum[i]); \
@@ -245,15 +245,19 @@ __device__ __forceinline__ void quadArgminBroadcast(ShapeBest &b, int lane)
 // upper bound on popcount(mask).
 // TRACE (BC7_RespectPunchThrough only): every round's error is also written to trialErr[round], and with
 // captureRound >= 0 the result is that round's instead of the best one.
+// `list`: the member pixels in ascending order, 4 bits each (UnitRec::listLo / listHi); best.idxLo / idxHi come back COMPACT: the
+// index of member i in bits [4i, 4i + 4) (expandIndexes puts them at their pixel positions when a block is packed).
+// wantPayload (wave-uniform) = false: only best.err is wanted (probes).
 template <int NRC, bool FAST, bool TRACE>
-__device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount, const ModeDesc md, const Unfinished &u,
+__device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, u64 list, int maxCount, const ModeDesc md, const Unfinished &u,
                                           int pIter, int tweak, bool active, const CvttBc7Args &A,
                                           const CvttDeviceTables *__restrict__ T, int numRefine, ShapeBest &best,
-                                          const float (&vs)[4], float *trialErr = nullptr, int captureRound = -1, float *trialErrHbm = nullptr)
+                                          const float (&vs)[4], bool wantPayload = true, float *trialErr = nullptr, int captureRound = -1, float *trialErrHbm = nullptr)
 {
     const bool isRGB = (NRC == 3);
     const int range = 1 << md.indexBits;
-    const float maxValue = (float)(range - 1);
+    // (literals: the clamp below then needs no canonicalising v_max_f32 per pixel)
+    const float maxValue = md.indexBits == 2 ? 3.0f : md.indexBits == 3 ? 7.0f : 15.0f;
     const float rcpMaxIndex = T->rcpMaxIndex[md.indexBits];
     const int weightRcp = (65536 + (range - 1)) / (2 * (range - 1)); // g_weightReciprocals, IndexSelector.cpp:43-62
     const int count = __popc(mask);
@@ -264,8 +268,12 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
     best.err = FLT_MAX;
     best.ep0 = best.ep1 = 0;
     best.idxLo = best.idxHi = 0;
-    if (!active)
-        mask = 0;
+    const int myCount = active ? count : 0; // member i exists for i < myCount
+    const u32 listLo = (u32)list, listHi = (u32)(list >> 32);
+    // pixel id of member i (i is wave-uniform: the halves of the list are told apart by a scalar branch)
+    auto memberOf = [&](int i) -> int {
+        return (int)(i < 8 ? __builtin_amdgcn_ubfe(listLo, (u32)(4 * i), 4u) : __builtin_amdgcn_ubfe(listHi, (u32)(4 * i - 32), 4u));
+    };
 #ifdef CVTT_BC7_PROFILE
     u32 profHist[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #endif
@@ -275,14 +283,11 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
     if (isRGB)
     {
         u32 acc = 0;
-        u32 rem = mask;
         for (int i = 0; i < maxCount; i++)
         {
-            if (rem)
+            if (i < myCount)
             {
-                const int px = __ffs((int)rem) - 1;
-                rem &= rem - 1;
-                const int d = 255 - byteI(lp[px], 3);
+                const int d = 255 - byteI(lp[memberOf(i)], 3);
                 acc = (u32)mad24(d, d, (int)acc);
             }
         }
@@ -370,16 +375,13 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
         float slowErr = 0.0f;
         v2f tv01 = {0.0f, 0.0f}, tv23 = {0.0f, 0.0f};
         float tt = 0.0f, ts = 0.0f;
-        u64 idx = 0;
-        u32 rem = mask;
+        u32 idxLo = 0, idxHi = 0; // compact: member i in bits [4i, 4i + 4)
 
         for (int i = 0; i < maxCount; i++)
         {
-            if (rem)
+            if (i < myCount)
             {
-                const int px = __ffs((int)rem) - 1;
-                rem &= rem - 1;
-                const u32 pk = lp[px];
+                const u32 pk = lp[memberOf(i)];
                 // SelectIndexLDR (reference IndexSelector.h:124-131)
                 const v2f x01 = {byteF(pk, 0), byteF(pk, 1)}, x23 = {byteF(pk, 2), byteF(pk, 3)};
                 const v2f p01 = (x01 - org01) * ax01, p23 = (x23 - org23) * ax23;
@@ -452,7 +454,13 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
                     tt = tt + t * t;
                     ts = ts + t;
                 }
-                idx |= (u64)(u32)index << (4 * px);
+                if (wantPayload)
+                {
+                    if (i < 8)
+                        idxLo |= (u32)index << (4 * i);
+                    else
+                        idxHi |= (u32)index << (4 * i - 32);
+                }
             }
         }
 
@@ -489,8 +497,8 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, int maxCount,
             best.err = shapeError;
             best.ep0 = packEP(ep[0]);
             best.ep1 = packEP(ep[1]);
-            best.idxLo = (u32)idx;
-            best.idxHi = (u32)(idx >> 32);
+            best.idxLo = idxLo;
+            best.idxHi = idxHi;
         }
 
         if (!last)
@@ -580,10 +588,9 @@ struct UnitRec
     // the refiner's m_v of the subset: sum of the pre-weighted member pixels in ascending order (EndpointRefiner.h:78-92).
     // It does not depend on the indexes, so the seed lane takes it once for all chains and rounds of the unit.
     float vs[4];
-    // Not part of the unit (the seed pass never writes it): entry b < 16 keeps the secondary index set of block b's best
-    // mode 4 / 5 candidate out of the registers until the block is packed.  It lives here because gfx950 allocates LDS in
-    // 1280-byte granules and the kernel sits exactly on 10 of them (12 workgroups per CU).
-    u32 parkedIdx2[2];
+    // the member pixels of the subset in ascending order, 4 bits each: the chain lanes read pixel i of their subset with one
+    // bit-field extract at a wave-uniform position instead of popping a per-lane bit mask
+    u32 listLo, listHi;
     __device__ __forceinline__ u32 mask() const { return packed & 0xffffu; }
     __device__ __forceinline__ int numTweak() const { return (int)((packed >> 16) & 7u); }
     __device__ __forceinline__ int blk() const { return (int)((packed >> 20) & 15u); }
@@ -1873,6 +1880,11 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     __shared__ u32 s_item[64];        // items of the current phase of a round: block | partition << 8 (up to 64 probes)
     __shared__ uint8_t s_myItems[PT ? 16 : 1][32]; // punch-through stages only: the items a block offered this round (elsewhere a block's items are consecutive)
     __shared__ UnitRec s_unit[64];    // PCA seeds per (item, subset)
+    __shared__ u32 s_parked[16][2];   // the secondary index set of every block's best mode 4 / 5 candidate, out of the registers until the block is packed
+    // the pixel bitmaps of the partitions (subset 1 of a two-subset partition; subsets 1 | 2 << 16 of a three-subset one): the
+    // search looks them up per lane many times per round, and a per-lane lookup in the HBM tables is a dependent global load
+    __shared__ unsigned short s_pm2[64];
+    __shared__ u32 s_pm3[64];
     // best of every (item, subset) = unit of the round: error, endpoints, indexes.  (During the dual-plane search the same
     // bytes hold the channel-major copy of the blocks, read with 128-bit loads.)
     __shared__ __attribute__((aligned(16))) u32 s_res[64][5];
@@ -1883,8 +1895,11 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     // table of this wave lives in HBM; it is written and read inside the wave, between barriers
     float *const trialHbm = (PT && A.ptTrial) ? A.ptTrial + (size_t)blockIdx.x * (size_t)(32 * 16) * (size_t)(A.refineRounds < 1 ? 1 : A.refineRounds) : nullptr;
     const cvttmi_bc7_plan *__restrict__ plan = &dplan->plan;
-    const int lane = threadIdx.x;
-    const int c = lane & 3;
+    // (not const: REFRESH_LANE() below hands the optimiser the same values as "new" ones at the start of every section of the
+    // single-plane search, so that the LDS addresses and masks it derives from them are computed where they are used instead
+    // of being hoisted in front of the stage loop and kept -- i.e. spilled -- across the chain rounds)
+    int lane = threadIdx.x;
+    int c = lane & 3;
     u32 hardIndex = 0, hardBlock = 0;
     u64 hardMine = 0;
     float hardErr = FLT_MAX;
@@ -1930,6 +1945,9 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #define blockHasNonMaxAlpha ((lf & LF_NONMAX_ALPHA) != 0)
 
     PROF_DECL
+    s_pm2[lane] = T->partition2[lane];
+    s_pm3[lane] = (u32)T->subsetMask3[lane][0] | ((u32)T->subsetMask3[lane][1] << 16);
+    __syncthreads();
     u32 pix[16];
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(blocks + (size_t)(inRange ? blockIndex : 0u) * 64u);
@@ -2314,8 +2332,8 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 const u32 iLo = indexSelector ? bA.idxLo : b.idxLo, iHi = indexSelector ? bA.idxHi : b.idxHi;
                 workPay0 = (c == 0) ? (b.ep0 | bA.ep0) : (c == 3) ? iLo : 0u;
                 workPay1 = (c == 0) ? (b.ep1 | bA.ep1) : (c == 3) ? iHi : 0u;
-                s_unit[lane >> 2].parkedIdx2[0] = indexSelector ? b.idxLo : bA.idxLo;
-                s_unit[lane >> 2].parkedIdx2[1] = indexSelector ? b.idxHi : bA.idxHi;
+                s_parked[lane >> 2][0] = indexSelector ? b.idxLo : bA.idxLo;
+                s_parked[lane >> 2][1] = indexSelector ? b.idxHi : bA.idxHi;
             }
         }
 #ifdef CVTT_BC7_PROFILE
@@ -2353,7 +2371,21 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     // consumed in batches of four (partition, subset) items: sub-lane c runs the PCA seed search
     // of item c (per-lane shape mask), then the items are searched one after the other with the
     // shape wave-uniform.
-    const int blk = lane >> 2;
+    int blk = lane >> 2;
+#define REFRESH_LANE() do { asm volatile("" : "+v"(lane)); c = lane & 3; blk = lane >> 2; } while (0)
+    // pixel bitmap of subset `sub` of partition `partition` of a mode with numSub subsets
+    auto subsetMaskOf = [&](int numSub, int partition, int sub) -> u32 {
+        if (numSub == 1)
+            return 0xffffu;
+        if (numSub == 2)
+        {
+            const u32 m1 = s_pm2[partition];
+            return sub ? m1 : (~m1 & 0xffffu);
+        }
+        const u32 m = s_pm3[partition];
+        const u32 m1 = m & 0xffffu, m2 = m >> 16;
+        return sub == 1 ? m1 : sub == 2 ? m2 : (~(m1 | m2) & 0xffffu);
+    };
     // From here on the pixel-major block is read from LDS where it is needed (the bounds): 16 registers that the chain
     // rounds, which have the fewest to spare, do not have to carry.
     auto pixFromLds = [&](u32 (&px)[16]) {
@@ -2393,6 +2425,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         // single translucent pixel searches modes 1 and 3 before mode 7: there mode 7 -- the same partitions with coarser end
         // points -- almost never wins, and what the other two find first prunes its partitions (smooth opaque gradients: 44
         // -> ... partitions per block alive in mode 7); the three share one set of bounds.
+        REFRESH_LANE();
         const int stageIter = (ballotA == 0 && !HARD) ? ((stageOrder == 1) ? 2 : (stageOrder == 2) ? 3 : (stageOrder == 3) ? 1 : stageOrder) : stageOrder;
         ModeDesc md;
         int numSubsets, numPartitions, stage, boundSet;
@@ -2483,7 +2516,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                         if (boundSet < 2)
                         {
                             Sums2D s1, s0;
-                            maskedSums(P, T->partition2[partition], s1);
+                            maskedSums(P, s_pm2[partition], s1);
                             s0.n = 16 - s1.n;
                             s0.u = P.tU - s1.u;
                             s0.v = P.tV - s1.v;
@@ -2495,8 +2528,8 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                         else
                         {
                             Sums2D s1, s2, s0;
-                            maskedSums(P, T->subsetMask3[partition][0], s1);
-                            maskedSums(P, T->subsetMask3[partition][1], s2);
+                            maskedSums(P, s_pm3[partition] & 0xffffu, s1);
+                            maskedSums(P, s_pm3[partition] >> 16, s2);
                             s0.n = 16 - s1.n - s2.n;
                             s0.u = P.tU - s1.u - s2.u;
                             s0.v = P.tV - s1.v - s2.v;
@@ -2592,17 +2625,17 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                         RawSums s0, s1;
                         if (numSubsets == 2)
                         {
-                            maskedRawSumsCM(CM, T->partition2[partition], s1);
+                            maskedRawSumsCM(CM, s_pm2[partition], s1);
                             rest(s0, s1);
                             lb = use4 ? subsetBoundFull<4>(s1, lw, A.delta4) : subsetBoundFull<3>(s1, lw, A.delta3);
                             lb += use4 ? subsetBoundFull<4>(s0, lw, A.delta4) : subsetBoundFull<3>(s0, lw, A.delta3);
                         }
                         else
                         {
-                            maskedRawSumsCM(CM, T->subsetMask3[partition][0], s1);
+                            maskedRawSumsCM(CM, s_pm3[partition] & 0xffffu, s1);
                             rest(s0, s1);
                             lb = subsetBoundFull<3>(s1, lw, A.delta3);
-                            maskedRawSumsCM(CM, T->subsetMask3[partition][1], s1);
+                            maskedRawSumsCM(CM, s_pm3[partition] >> 16, s1);
                             rawSumsSub(s0, s1);
                             lb += subsetBoundFull<3>(s1, lw, A.delta3);
                             lb += subsetBoundFull<3>(s0, lw, A.delta3);
@@ -2699,9 +2732,9 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         // the subset of a partition that is probed: the one with the most pixels (the first of them)
         auto probeSubOf = [&](int partition) -> int {
             if (numSubsets == 2)
-                return __popc(T->shapeMask[T->shapes2[partition][1]]) > __popc(T->shapeMask[T->shapes2[partition][0]]) ? 1 : 0;
-            const int n0 = __popc(T->shapeMask[T->shapes3[partition][0]]), n1 = __popc(T->shapeMask[T->shapes3[partition][1]]),
-                      n2 = __popc(T->shapeMask[T->shapes3[partition][2]]);
+                return __popc((u32)s_pm2[partition]) > 8 ? 1 : 0;
+            const u32 m = s_pm3[partition];
+            const int n1 = __popc(m & 0xffffu), n2 = __popc(m >> 16), n0 = 16 - n1 - n2;
             return (n2 > n0 && n2 > n1) ? 2 : (n1 > n0) ? 1 : 0;
         };
         // survivors of the probes wait here (per block) until the wave has enough of them for a well-filled full search
@@ -2712,6 +2745,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             // ---- offers.  Pass 0: every block offers its cheapest-bound candidate.  When few blocks
             // offer, the idle lanes take further candidates of the same blocks (they might have been
             // pruned by the first result, but waiting for it would cost a whole round). ----
+            REFRESH_LANE();
             int numItems = 0, myCount = 0, maxPasses = 1;
             u64 offerMask = 0; // staged: the partitions this block offers in this round (the same in the four lanes of the quad)
             for (int pass = 0; pass < maxPasses; pass++)
@@ -2791,6 +2825,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 }
                 numItems += numOffers;
             }
+            PROF_MARK(8)
             const bool flush = (numItems == 0); // nothing left to offer: the waiting survivors are searched, then the stage ends
             if (flush && __ballot(pend != 0) == 0)
                 break;
@@ -2805,7 +2840,8 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             int chunkLo = 0;
             for (;;) // phases of the round: [probe,] then the full search of the survivors, chunk by chunk
             {
-            PROF_MARK(4)
+            PROF_MARK(14)
+            REFRESH_LANE();
             int iLo = 0, iHi = 0, phaseTotal = numItems;
             if (staged)
             {
@@ -2856,7 +2892,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     const int item = isProbe ? lane : (numSubsets == 2) ? (lane >> 1) : (lane / 3);
                     const int upart = (int)(s_item[item] >> 8);
                     const int sub = isProbe ? probeSubOf(upart) : lane - item * numSubsets;
-                    cnt = __popc(T->shapeMask[(numSubsets == 2) ? T->shapes2[upart][sub] : T->shapes3[upart][sub]]);
+                    cnt = __popc(subsetMaskOf(numSubsets, upart, sub));
                 }
                 if (numSubsets >= 2 && !ptStage)
                 {
@@ -2872,6 +2908,8 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     }
                 }
             }
+            PROF_MARK(9)
+            REFRESH_LANE();
             if (lane < numUnits)
             {
                 const int item = (isProbe || numSubsets == 1) ? lane : (numSubsets == 2) ? (lane >> 1) : (lane / 3);
@@ -2883,7 +2921,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     shape = T->shapes2[upart][sub];
                 else if (numSubsets == 3)
                     shape = T->shapes3[upart][sub];
-                const u32 uMask = T->shapeMask[shape];
+                const u32 uMask = subsetMaskOf(numSubsets, upart, sub);
                 int seeds = isRGB ? plan->seedPointsForShapeRGB[shape] : plan->seedPointsForShapeRGBA[shape];
                 if (seeds > 4)
                     seeds = 4;
@@ -2982,10 +3020,27 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                         scErr = scErr + (uniformErr ? (float)(int)st : (float)(int)st * A.wSq[3]);
                 }
                 r.scErr = scErr;
+                {
+                    u32 lo = 0, hi = 0;
+                    int k = 0;
+#pragma unroll
+                    for (int px = 0; px < 16; px++)
+                        if ((uMask >> px) & 1u)
+                        {
+                            if (k < 8)
+                                lo |= (u32)px << (4 * k);
+                            else
+                                hi |= (u32)px << (4 * k - 32);
+                            k++;
+                        }
+                    r.listLo = lo;
+                    r.listHi = hi;
+                }
             }
             __syncthreads();
-            PROF_MARK(3)
+            PROF_MARK(10)
 
+            REFRESH_LANE();
             // ---- chains: lane l of a batch = (unit l / CP, p-bits (l % CP) / 4, seed point l % 4) ----
             for (int u0 = 0; u0 < numUnits; u0 += UPB)
             {
@@ -3013,6 +3068,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 }
                 const u32 *lp = &s_pix[r.blk()][0];
                 const float uvs[4] = {r.vs[0], r.vs[1], r.vs[2], r.vs[3]};
+                const u64 uList = ((u64)r.listHi << 32) | r.listLo;
                 PROF_COUNT(2, 64)
                 PROF_COUNT(3, __popcll(__ballot(active)))
                 PROF_STAGE(stageIter, 0, 1)
@@ -3022,15 +3078,15 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 {
                     // record every trial; the lock-step commit rule is applied below
                     if (PT)
-                        evalChain<4, FAST, true>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b, uvs,
+                        evalChain<4, FAST, true>(lp, uMask, uList, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b, uvs, true,
                                                  trialHbm ? nullptr : &s_trialErr[((inRange ? unit : 0) * 16 + chain) * numRefine], -1,
                                                  trialHbm ? trialHbm + ((inRange ? unit : 0) * 16 + chain) * numRefine : nullptr);
                     continue;
                 }
                 if (isRGB)
-                    evalChain<3, FAST, false>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b, uvs);
+                    evalChain<3, FAST, false>(lp, uMask, uList, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b, uvs, !isProbe);
                 else
-                    evalChain<4, FAST, false>(lp, uMask, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b, uvs);
+                    evalChain<4, FAST, false>(lp, uMask, uList, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b, uvs, !isProbe);
                 groupArgminBroadcast(b, lane, CP);
                 if (inRange && chain == 0)
                 {
@@ -3051,6 +3107,8 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 }
             }
             __syncthreads();
+            if (isProbe) { PROF_MARK(11) } else { PROF_MARK(13) }
+            REFRESH_LANE();
 
             if (isProbe)
             {
@@ -3083,7 +3141,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                                 if (sub == ps)
                                     continue;
                                 RawSums rs;
-                                maskedRawSumsCM(CMf, T->shapeMask[(numSubsets == 2) ? T->shapes2[partition][sub] : T->shapes3[partition][sub]], rs);
+                                maskedRawSumsCM(CMf, subsetMaskOf(numSubsets, partition, sub), rs);
                                 lbRest += use4 ? subsetBoundFull<4>(rs, lwf, A.delta4) : subsetBoundFull<3>(rs, lwf, A.delta3);
                             }
                             const float lbTotal = (eProbed + lbRest) * 0.9999995f;
@@ -3111,6 +3169,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     pendTotal = __builtin_amdgcn_readfirstlane(pendTotal);
                 }
                 __syncthreads(); // everybody has read its items before the next list is written
+                PROF_MARK(12)
                 if (pendTotal < CVTT_PEND_MIN)
                     break; // they wait for more
                 curMask = pend;
@@ -3185,8 +3244,8 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 }
                 ShapeBest b;
                 const float uvs[4] = {r.vs[0], r.vs[1], r.vs[2], r.vs[3]};
-                evalChain<4, FAST, true>(&s_pix[r.blk()][0], r.mask(), maxCount, md, uu, hChain >> 2, hChain & 3, have, A, T, numRefine, b, uvs,
-                                         nullptr, hRound);
+                evalChain<4, FAST, true>(&s_pix[r.blk()][0], r.mask(), ((u64)r.listHi << 32) | r.listLo, maxCount, md, uu, hChain >> 2, hChain & 3, have, A, T, numRefine, b, uvs,
+                                         true, nullptr, hRound);
                 if (scanActive)
                 {
                     if (!have)
@@ -3208,6 +3267,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     dst[4] = b.idxHi;
                 }
             }
+            REFRESH_LANE();
             // ---- every offering block adds up the subsets of its items and commits ----
             for (int j = 0; j < 64; j++)
             {
@@ -3218,59 +3278,12 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 {
                     const int item = staged ? iLo + j : (int)s_myItems[PT ? blk : 0][j];
                     const int partition = (int)(s_item[item] >> 8);
-#ifdef CVTT_BC7_PROFILE
-                    if (prune && numSubsets >= 2 && !ptStage)
-                    {
-                        // how often would the exact error of ONE subset plus the full-dimension bound of the rest already rule the
-                        // partition out?  (slots of g_bc7Stage2: items, first = subset 0, first = subset 1, first = the larger
-                        // subset, first = the subset with the larger bound, either order, total bound alone (stale best))
-                        u32 lpix[16];
-                        pixFromLds(lpix);
-                        u32 CMp[4][4];
-                        channelMajor(lpix, CMp);
-                        float lw4[4] = {A.w[0], A.w[1], A.w[2], A.w[3]};
-                        float lbS[3] = {0, 0, 0}, eS[3] = {0, 0, 0};
-                        int nS[3] = {0, 0, 0};
-                        const bool use4p = (boundSet == 0);
-                        for (int sub = 0; sub < numSubsets; sub++)
-                        {
-                            const int shape = numSubsets == 2 ? T->shapes2[partition][sub] : T->shapes3[partition][sub];
-                            RawSums rs;
-                            maskedRawSumsCM(CMp, T->shapeMask[shape], rs);
-                            const float v = use4p ? subsetBoundFull<4>(rs, lw4, A.delta4) : subsetBoundFull<3>(rs, lw4, A.delta3);
-                            const float e = __builtin_bit_cast(float, s_res[item * numSubsets + sub][0]);
-                            if (sub == 0) { lbS[0] = v; eS[0] = e; nS[0] = rs.n; } else if (sub == 1) { lbS[1] = v; eS[1] = e; nS[1] = rs.n; } else { lbS[2] = v; eS[2] = e; nS[2] = rs.n; }
-                        }
-                        {
-                            // per-subset validity of the full-dimension bound (it must never exceed the subset's exact error)
-                            const unsigned long long viol = __popcll(__ballot(c == 0 && (lbS[0] > eS[0] || lbS[1] > eS[1] || (numSubsets == 3 && lbS[2] > eS[2]))));
-                            if (threadIdx.x == 0 && viol)
-                                atomicAdd(&g_bc7Dup[7], viol);
-                        }
-                        const float extra = use4p ? 0.0f : staticAlphaBlock;
-                        const float lbAll = lbS[0] + lbS[1] + lbS[2] + extra;
-                        const bool cut0 = eS[0] + (lbAll - lbS[0]) > work.err;
-                        const bool cut1 = eS[1] + (lbAll - lbS[1]) > work.err;
-                        const int big = (nS[1] > nS[0]) ? 1 : 0, hiLb = (lbS[1] > lbS[0]) ? 1 : 0;
-                        const bool cutBig = big ? cut1 : cut0, cutLb = hiLb ? cut1 : cut0;
-                        const bool cnt = (c == 0);
-                        const int sI = stageIter;
-                        PROF_STAGE_LANES(sI + 0, 7, false)
-                        {
-                            const unsigned long long v0 = __popcll(__ballot(cnt)), v1 = __popcll(__ballot(cnt && cut0)), v2 = __popcll(__ballot(cnt && cut1)),
-                                                     v3 = __popcll(__ballot(cnt && cutBig)), v4 = __popcll(__ballot(cnt && cutLb)), v5 = __popcll(__ballot(cnt && (cut0 || cut1))),
-                                                     v6 = __popcll(__ballot(cnt && lbAll > work.err)), v7 = __popcll(__ballot(cnt && (eS[0] + eS[1] + eS[2] + extra * 0.0f) < work.err));
-                            if (threadIdx.x == 0)
-                            {
-                                atomicAdd(&g_bc7Stage2[sI][0], v0); atomicAdd(&g_bc7Stage2[sI][1], v1); atomicAdd(&g_bc7Stage2[sI][2], v2); atomicAdd(&g_bc7Stage2[sI][3], v3);
-                                atomicAdd(&g_bc7Stage2[sI][4], v4); atomicAdd(&g_bc7Stage2[sI][5], v5); atomicAdd(&g_bc7Stage2[sI][6], v6); atomicAdd(&g_bc7Stage2[sI][7], v7);
-                            }
-                        }
-                    }
-#endif
                     float totalError = 0.0f;
                     u32 pe[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-                    u32 pIdxLo = 0, pIdxHi = 0;
+                    // the index sets come compact (member i of a subset in bits [4i, 4i + 4)): subset after subset, still
+                    // compact -- expandIndexes sorts them to their pixels when the block is packed
+                    u64 pIdx = 0;
+                    int nibbles = 0;
                     for (int sub = 0; sub < numSubsets; sub++)
                     {
                         const u32 *src = &s_res[item * numSubsets + sub][0];
@@ -3279,9 +3292,11 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                         if (sub == 0) { pe[0][0] = e0; pe[0][1] = e1; }
                         else if (sub == 1) { pe[1][0] = e0; pe[1][1] = e1; }
                         else { pe[2][0] = e0; pe[2][1] = e1; }
-                        pIdxLo |= src[3];
-                        pIdxHi |= src[4];
+                        const u64 part = ((u64)src[4] << 32) | src[3];
+                        pIdx |= nibbles < 16 ? part << (4 * nibbles) : 0ull;
+                        nibbles += __popc(subsetMaskOf(numSubsets, partition, sub));
                     }
+                    const u32 pIdxLo = (u32)pIdx, pIdxHi = (u32)(pIdx >> 32);
                     const int seq = stage * 64 + partition;
                     bool mayTake = laneRuns;
                     if (ptStage && mode == 7 && anyBlockHasAlpha && !blockHasNonMaxAlpha && ((mode7RGB >> partition) & 1ull) == 0)
@@ -3303,7 +3318,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 break;
             __syncthreads(); // the commits have read this chunk's items and results
             } // phases of the round
-            PROF_MARK(4)
+            PROF_MARK(14)
             if (flush)
                 break;
         }
@@ -3313,6 +3328,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     PROF_MARK(3)
 #endif
     // ===================== fix-ups + bit packing (reference BC67.cpp:2003-2203) ==========
+    REFRESH_LANE();
     {
         // the winner: seq = stage * 64 + partition for the single-plane modes (stages 0..5 = modes 0, 1, 2, 3, 6, 7),
         // 384 + rotation * 2 + index selector for mode 4, 392 + rotation for mode 5; nothing committed: mode 0, all zero
@@ -3334,13 +3350,42 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             packed.idxLo = __shfl(workPay0, q | 3);
             packed.idxHi = __shfl(workPay1, q | 3);
             packed.idx2Lo = packed.idx2Hi = 0;
+            if (packed.mode < 4 || packed.mode == 7)
+            {
+                // single-plane results carry their indexes compact, subset after subset in member order: sort them to their
+                // pixels (sub-lane c places pixels 4c .. 4c + 3; modes 4 / 5 are positional already, mode 6 is one subset of 16)
+                const int p = packed.partOrIS;
+                const bool three = (packed.mode == 0 || packed.mode == 2);
+                const u32 m1 = three ? (s_pm3[p] & 0xffffu) : (u32)s_pm2[p];
+                const u32 m2 = three ? (s_pm3[p] >> 16) : 0u;
+                const u32 m0 = ~(m1 | m2) & 0xffffu;
+                const int n0 = __popc(m0), n1 = __popc(m1);
+                const u64 cat = ((u64)packed.idxHi << 32) | packed.idxLo;
+                u64 pos = 0;
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                {
+                    const int px = 4 * c + t;
+                    const u32 below = (1u << px) - 1u;
+                    const bool in1 = (m1 >> px) & 1u, in2 = (m2 >> px) & 1u;
+                    const int k = in2 ? n0 + n1 + __popc(m2 & below) : in1 ? n0 + __popc(m1 & below) : __popc(m0 & below);
+                    pos |= ((cat >> (4 * k)) & 0xfull) << (4 * px);
+                }
+                u32 lo = (u32)pos, hi = (u32)(pos >> 32);
+                lo |= __shfl_xor(lo, 1);
+                hi |= __shfl_xor(hi, 1);
+                lo |= __shfl_xor(lo, 2);
+                hi |= __shfl_xor(hi, 2);
+                packed.idxLo = lo;
+                packed.idxHi = hi;
+            }
         }
         const int mode = packed.mode;
         u32 w0, w1, w2, w3;
         if (mode == 4 || mode == 5)
         {
-            packed.idx2Lo = s_unit[lane >> 2].parkedIdx2[0];
-            packed.idx2Hi = s_unit[lane >> 2].parkedIdx2[1];
+            packed.idx2Lo = s_parked[lane >> 2][0];
+            packed.idx2Hi = s_parked[lane >> 2][1];
         }
         if (mode == 4)
             packDualPlane<4>(packed, w0, w1, w2, w3);
@@ -3602,6 +3647,7 @@ __global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     }
     PROF_MARK(5)
     PROF_FLUSH
+#undef REFRESH_LANE
 #undef valid
 #undef anyBlockHasAlpha
 #undef allowRGBModes

@@ -12,7 +12,8 @@ ctx = api.Context(0)
 lib = api.load_library()
 buf = (ctypes.c_ulonglong * 96)()
 prof = (ctypes.c_ulonglong * 48)()
-phase = ["dual seeds", "dual-plane search", "partition bounds", "seed PCA", "single-plane search", "pack", "load+block bounds", "projection"]
+phase = ["dual seeds", "dual-plane search", "partition bounds", "seed PCA", "single-plane search", "pack", "load+block bounds", "projection",
+         "offers", "item list + sort", "seed pass", "probe chains", "probe filter", "full chains", "commit", "-"]
 modes = [6, 7, 1, 3, 0, 2]
 for name, b in synth.content_families(N).items():
     if want and name not in want:
@@ -22,12 +23,12 @@ for name, b in synth.content_families(N).items():
     lib.cvttmi_bc7_stage_read(buf); lib.cvttmi_bc7_prof_read(prof)
     ctx.encode_bc7(t, out=out); torch.cuda.synchronize()
     lib.cvttmi_bc7_stage_read(buf); lib.cvttmi_bc7_prof_read(prof)
-    tot = float(sum(prof[:8]))
+    tot = float(sum(prof[:16]))
     o = out.cpu().numpy()
     first = o[:, 0].astype(np.uint32)
     mode = np.array([(int(v) & -int(v)).bit_length() - 1 if v else 8 for v in first])
     hist = np.bincount(mode, minlength=9)[:8]
-    print("== %-20s winners by mode %s   phases %s" % (name, hist.tolist(), {phase[i]: round(prof[i] / tot, 3) for i in range(8) if prof[i] / tot >= 0.01}))
+    print("== %-20s winners by mode %s   phases %s" % (name, hist.tolist(), {phase[i]: round(prof[i] / tot, 3) for i in range(16) if prof[i] / tot >= 0.01}))
     for si, m in enumerate(modes):
         r = [int(buf[si * 8 + k]) for k in range(8)]
         if r[6] == 0:
