@@ -38,7 +38,10 @@
 
 #include "cvtt_device.h"
 
-constexpr int kMaxPTRefine = 6; // BC7_RespectPunchThrough: refine rounds whose trial errors fit the LDS table
+// BC7_RespectPunchThrough: refine rounds whose trial errors are kept in LDS (2 KB per round; the reference's default is 2
+// rounds).  With more rounds the table of a wave lives in HBM (CvttBc7Args::ptTrial).  6 rounds of LDS held this
+// instantiation at 6 workgroups per CU; 2 rounds: 10 (2.5 waves per SIMD).
+constexpr int kMaxPTRefine = 2;
 // half-range of the integer grid the projected points are rounded to: 12-bit coordinates summed with v_dot2_i32_i16, or
 // 8-bit ones summed with v_dot4_i32_i8 (half the instructions, bounds looser by the coarser rounding)
 constexpr float kBoundGrid16 = 2000.0f, kBoundLimit16 = 2040.0f;
@@ -62,8 +65,10 @@ constexpr float kBoundGrid8 = 124.0f, kBoundLimit8 = 127.0f;
 #define CVTT_BC7_WAVES 4
 #endif
 // the same for the slow-indexing instantiation (Flags::Better / Ultra), whose three probes per pixel need more registers
+// (4 since round 3: with the pixel loop of its dual-plane search rolled into four trips the instantiation fits 128
+// registers; Flags::Better on 4096^2 RGBA noise 292 -> 306 Mblocks/s, opaque 75 -> 78)
 #ifndef CVTT_BC7_WAVES_SLOW
-#define CVTT_BC7_WAVES_SLOW 3
+#define CVTT_BC7_WAVES_SLOW 4
 #endif
 // power iterations per principal axis of the projection the first-tier bounds are taken in (tightness only, never validity)
 #ifndef CVTT_EIG_ITERS
@@ -816,14 +821,17 @@ __device__ __forceinline__ void evalDual(const u32 *sP, u32 minMax, int mode, in
 
             const u32 *sPr = sP; // opaque to the optimiser: the loads stay inside the round (see evalDualFast)
             asm volatile("" : "+v"(sPr));
-#pragma unroll
-            for (int px = 0; px < 16; px++)
+            // four pixels per trip, the trips not unrolled: unrolled sixteen times, the three probes of every pixel kept so
+            // much in flight that this instantiation could not be held in the 128 registers of four waves per SIMD
+#pragma unroll 1
+            for (int g = 0; g < 4; g++)
             {
-                u32 pk;
-                {
-                    const uint4 L = *reinterpret_cast<const uint4 *>(sPr + (px & ~3));
-                    pk = (px & 3) == 0 ? L.x : (px & 3) == 1 ? L.y : (px & 3) == 2 ? L.z : L.w;
-                }
+            const uint4 L = *reinterpret_cast<const uint4 *>(sPr + 4 * g);
+            u32 r4 = 0, a4 = 0; // the group's indexes, 4 bits per pixel
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const u32 pk = k == 0 ? L.x : k == 1 ? L.y : k == 2 ? L.z : L.w;
                 const v2f x01 = {byteF(pk, 0), byteF(pk, 1)}, x23 = {byteF(pk, 2), byteF(pk, 3)};
                 const v2f p01 = (x01 - org01) * ax01, p23 = (x23 - org23) * ax23;
                 float dist = p01.x + p01.y;
@@ -913,16 +921,19 @@ __device__ __forceinline__ void evalDual(const u32 *sP, u32 minMax, int mode, in
                     tt2 = tt2 + t2 * t2;
                     ts2 = ts2 + t2;
                 }
-                if (px < 8)
-                {
-                    rgbLo |= (u32)iRGB << (4 * px);
-                    aLo |= (u32)iA << (4 * px);
-                }
-                else
-                {
-                    rgbHi |= (u32)iRGB << (4 * (px - 8));
-                    aHi |= (u32)iA << (4 * (px - 8));
-                }
+                r4 |= (u32)iRGB << (4 * k);
+                a4 |= (u32)iA << (4 * k);
+            }
+            if (g < 2)
+            {
+                rgbLo |= r4 << (16 * g);
+                aLo |= a4 << (16 * g);
+            }
+            else
+            {
+                rgbHi |= r4 << (16 * (g - 2));
+                aHi |= a4 << (16 * (g - 2));
+            }
             }
 
             float errorRGB, errorA;
@@ -1861,7 +1872,7 @@ __device__ __forceinline__ u32 everyFourth(u64 m, int c)
 // Every candidate is compared by (error, position in the reference's order), so the split cannot change the result.
 template <bool FAST, bool PT, bool HARD>
 // (the punch-through instantiation holds 22 KB of LDS: two waves per SIMD is all that fits, so it may use their registers)
-__global__ __launch_bounds__(64, PT ? 2 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVES_SLOW) void cvttmi_bc7_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVES_SLOW) void cvttmi_bc7_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
                                                         const CvttBc7Args A, const CvttDeviceTables *__restrict__ T,
                                                         const CvttBc7DevicePlan *__restrict__ dplan)
 {

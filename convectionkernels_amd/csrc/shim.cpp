@@ -1080,12 +1080,13 @@ extern "C"
             args.delta4 = static_cast<float>(0.5 * sqrt(s4) * 1.000001);
         }
 
-        // BC7_RespectPunchThrough records the error of every trial of a round of units; up to 6 refine rounds that table is
-        // 2 KB of LDS per round, beyond (the reference clamps refineRoundsBC7 only from below, BC67.cpp:1044-1045) it lives
-        // in HBM: 2 KB per round and wave, so such a call goes in launches of as many waves as 256 MB of table hold
+        // BC7_RespectPunchThrough records the error of every trial of a round of units; up to 2 refine rounds (the reference's
+        // default) that table is 2 KB of LDS per round, beyond (the reference clamps refineRoundsBC7 only from below,
+        // BC67.cpp:1044-1045) it lives in HBM: 2 KB per round and wave, so such a call goes in launches of as many waves as
+        // 256 MB of table hold
         args.ptTrial = NULL;
         size_t blocksPerLaunch = numBlocks;
-        if ((options->flags & CVTTMI_FLAG_BC7_RESPECT_PUNCHTHROUGH) && options->refineRoundsBC7 > 6)
+        if ((options->flags & CVTTMI_FLAG_BC7_RESPECT_PUNCHTHROUGH) && options->refineRoundsBC7 > 2) // kMaxPTRefine of bc7_kernel.hip
         {
             const size_t perWave = (size_t)32 * 16 * sizeof(float) * (size_t)options->refineRoundsBC7;
             size_t wavesPerLaunch = ((size_t)256 << 20) / perWave;
