@@ -1707,7 +1707,9 @@ __device__ __forceinline__ void makeProjection(const u32 (&pix)[16], const Block
     if constexpr (G8)
     {
     // the four lanes of a quad hold the same block: sub-lane c projects pixels 4c .. 4c+3 and the quad exchanges the words
-    const int c = (int)threadIdx.x & 3;
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid)); // a value of its own: the optimiser otherwise keeps `lane & ~3` of the kernel's prologue alive (spilled) for this
+    const int c = tid & 3;
     u32 myU = 0, myV = 0;
     {
         u32 ub = 0, vb = 0;
@@ -1733,7 +1735,7 @@ __device__ __forceinline__ void makeProjection(const u32 (&pix)[16], const Block
         myU = ub;
         myV = vb;
     }
-    const int quadBase = (int)threadIdx.x & ~3;
+    const int quadBase = tid & ~3;
 #pragma unroll
     for (int k = 0; k < 4; k++)
     {
@@ -1911,6 +1913,9 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     // of being hoisted in front of the stage loop and kept -- i.e. spilled -- across the chain rounds)
     int lane = threadIdx.x;
     int c = lane & 3;
+    int blk = lane >> 2;
+// (the lane number comes from v_mbcnt -- a workgroup is one wave -- so that not even threadIdx.x has to stay alive)
+#define REFRESH_LANE() do { lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); asm volatile("" : "+v"(lane)); c = lane & 3; blk = lane >> 2; } while (0)
     u32 hardIndex = 0, hardBlock = 0;
     u64 hardMine = 0;
     float hardErr = FLT_MAX;
@@ -1979,6 +1984,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         }
     }
 
+    REFRESH_LANE();
     // ---- per-block alpha statistics and the two group-wide booleans (BC67.cpp:1054-1078) ----
     int minAlpha = 255;
 #pragma unroll
@@ -2037,6 +2043,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     int workSeq = HARD ? hardSeq : -1; // nothing committed yet: a candidate must beat FLT_MAX strictly
     u32 workPay0 = 0, workPay1 = 0;
 
+    REFRESH_LANE();
     // ------------- whole-block scatter matrix: bounds for mode 6 and the four rotations -------------
     const bool prune = !HARD && A.prune != 0; // HARD: the bounds have been applied by the first launch
     BlockScatter bs;
@@ -2073,7 +2080,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         // rotation r codes channel r-1 (alpha for r = 0) on its own; the other three share a line
         if (!HARD)
         {
-            const float s012 = A.wSq[0] + A.wSq[1] + A.wSq[2];
+            const float s012 = A.wSqSum3;
             const float d0 = A.delta3;
             const float d1 = 0.5000005f * __builtin_amdgcn_sqrtf(s012 - A.wSq[0] + A.wSq[3]) * 1.000001f;
             const float d2 = 0.5000005f * __builtin_amdgcn_sqrtf(s012 - A.wSq[1] + A.wSq[3]) * 1.000001f;
@@ -2123,6 +2130,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     // reference TryDualPlane, BC67.cpp:1678-1963.  The RGB seeds depend only on the rotation,
     // so sub-lane r computes them for rotation r once (the reference recomputes them for each
     // mode / index selector).
+    REFRESH_LANE();
     if constexpr (!HARD)
     {
         Unfinished uRot;
@@ -2223,6 +2231,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #endif
         for (int step = 0; step < 12; step++)
         {
+            REFRESH_LANE();
             const int slot = step / 3, which = step - slot * 3;
             const int rotation = (slot == 0) ? rotOrder[0] : (slot == 1) ? rotOrder[1] : (slot == 2) ? rotOrder[2] : rotOrder[3];
             // position in the reference's commit order: mode 4 (rot 0: is 0,1; rot 1: ...), then mode 5 rot 0..3
@@ -2382,8 +2391,6 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     // consumed in batches of four (partition, subset) items: sub-lane c runs the PCA seed search
     // of item c (per-lane shape mask), then the items are searched one after the other with the
     // shape wave-uniform.
-    int blk = lane >> 2;
-#define REFRESH_LANE() do { asm volatile("" : "+v"(lane)); c = lane & 3; blk = lane >> 2; } while (0)
     // pixel bitmap of subset `sub` of partition `partition` of a mode with numSub subsets
     auto subsetMaskOf = [&](int numSub, int partition, int sub) -> u32 {
         if (numSub == 1)
@@ -2495,7 +2502,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     const bool use4 = (boundSet == 0);
                     auto boundsOnGrid = [&](auto g8) {
                     constexpr bool G8 = decltype(g8)::value;
-                    const float wsum = A.wSq[0] + A.wSq[1] + A.wSq[2] + (use4 ? A.wSq[3] : 0.0f);
+                    const float wsum = A.wSqSum3 + (use4 ? A.wSq[3] : 0.0f);
                     const float scale = (G8 ? kBoundGrid8 : kBoundGrid16) / (255.0f * __builtin_amdgcn_sqrtf(wsum)); // wave-uniform
                     const float invScaleSq = 1.0f / (scale * scale);
                     // rounding the projected points moves each by at most sqrt(2)/2 grid units
@@ -2753,12 +2760,44 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         u64 pend = 0;
         for (;;)
         {
-            // ---- offers.  Pass 0: every block offers its cheapest-bound candidate.  When few blocks
-            // offer, the idle lanes take further candidates of the same blocks (they might have been
+            // ---- offers.  Pass 0: every block offers its cheapest-bound candidate.  When few
+            // blocks offer, the idle lanes take further candidates of the same blocks (they might have been
             // pruned by the first result, but waiting for it would cost a whole round). ----
             REFRESH_LANE();
             int numItems = 0, myCount = 0, maxPasses = 1;
             u64 offerMask = 0; // staged: the partitions this block offers in this round (the same in the four lanes of the quad)
+            if (probing)
+            {
+                // When the partitions the whole wave has left fit one probe phase (64) -- noise-like content, where the bounds
+                // leave few -- there is nothing to order and the offer passes are skipped: all of them are probed at once
+                // (opaque noise +13 %, near-opaque alpha +22 %).  With more than that the order matters: cheapest bound first, a
+                // few per block and round, so that what the first survivors achieve prunes the rest (probing a stage block by
+                // block instead measured -12 % on smooth content).
+                u64 m = aliveBits; // bit k of sub-lane c is partition 4k + c
+                m = (m | (m << 24)) & 0x000000ff000000ffull;
+                m = (m | (m << 12)) & 0x000f000f000f000full;
+                m = (m | (m << 6)) & 0x0303030303030303ull;
+                m = (m | (m << 3)) & 0x1111111111111111ull;
+                m <<= c;
+                u32 lo = (u32)m, hi = (u32)(m >> 32);
+                lo |= __shfl_xor(lo, 1);
+                hi |= __shfl_xor(hi, 1);
+                lo |= __shfl_xor(lo, 2);
+                hi |= __shfl_xor(hi, 2);
+                const int kb = __popc(lo) + __popc(hi);
+                int allTotal = 0;
+#pragma unroll
+                for (int b = 0; b < 16; b++)
+                    allTotal += __shfl(kb, 4 * b);
+                allTotal = __builtin_amdgcn_readfirstlane(allTotal);
+                if (allTotal <= 64)
+                {
+                    offerMask = ((u64)hi << 32) | lo;
+                    aliveBits = 0;
+                    numItems = allTotal;
+                    maxPasses = 0;
+                }
+            }
             for (int pass = 0; pass < maxPasses; pass++)
             {
                 // quad-wide argmin of the bounds still alive (ties: lowest partition)

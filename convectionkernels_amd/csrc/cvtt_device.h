@@ -86,6 +86,7 @@ struct CvttBc7Args
     uint32_t prune;
     float delta3;    // 0.5*sqrt(wSq[0]+wSq[1]+wSq[2]), rounded up
     float delta4;    // 0.5*sqrt(wSq[0..3]), rounded up
+    float wSqSum3;   // wSq[0] + wSq[1] + wSq[2] (scale of the bound grids; summed on the host so that it arrives in a scalar register)
     // hand-over of blocks with many live mode-7 partitions to a second launch; hardCap = 0: off
     uint32_t hardCap;   // record slots of this launch
     uint32_t hardMin;   // live partitions of a wave from which its blocks are handed over, at the end of the grid

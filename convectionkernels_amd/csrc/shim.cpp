@@ -1076,6 +1076,7 @@ extern "C"
         {
             const double s3 = (double)args.wSq[0] + (double)args.wSq[1] + (double)args.wSq[2];
             const double s4 = s3 + (double)args.wSq[3];
+            args.wSqSum3 = (args.wSq[0] + args.wSq[1]) + args.wSq[2];
             args.delta3 = static_cast<float>(0.5 * sqrt(s3) * 1.000001);
             args.delta4 = static_cast<float>(0.5 * sqrt(s4) * 1.000001);
         }
