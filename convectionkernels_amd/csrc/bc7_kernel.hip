@@ -2798,9 +2798,13 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     maxPasses = 0;
                 }
             }
+            // Probing stages: every LANE offers the cheapest of the sixteen partitions it looks after (a block offers up to four
+            // per pass, nearly its four cheapest), so a full wave fills a probe phase in one pass over the bounds instead of four
+            // with a quad-wide argmin each.  The order only steers the pruning, never the result.
+            const bool laneOffers = probing;
             for (int pass = 0; pass < maxPasses; pass++)
             {
-                // quad-wide argmin of the bounds still alive (ties: lowest partition)
+                // argmin of the bounds still alive (ties: lowest partition), over the quad unless every lane offers for itself
                 float pickLb = FLT_MAX;
                 int pick = 255;
                 for (int k = 0; k * 4 < numPartitions; k++)
@@ -2815,14 +2819,17 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                         }
                     }
                 }
-#pragma unroll
-                for (int step = 1; step <= 2; step <<= 1)
+                if (!laneOffers)
                 {
-                    const float oLb = __shfl_xor(pickLb, step);
-                    const int oPick = __shfl_xor(pick, step);
-                    const bool take = (oLb < pickLb) || (oLb == pickLb && oPick < pick);
-                    pickLb = take ? oLb : pickLb;
-                    pick = take ? oPick : pick;
+#pragma unroll
+                    for (int step = 1; step <= 2; step <<= 1)
+                    {
+                        const float oLb = __shfl_xor(pickLb, step);
+                        const int oPick = __shfl_xor(pick, step);
+                        const bool take = (oLb < pickLb) || (oLb == pickLb && oPick < pick);
+                        pickLb = take ? oLb : pickLb;
+                        pick = take ? oPick : pick;
+                    }
                 }
                 bool offer = pick < 64 && !(pickLb > work.err);
                 if (!offer)
@@ -2846,15 +2853,16 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     }
                     offer = pick < 64;
                 }
-                const u64 offers = __ballot(offer && c == 0);
+                const u64 offers = __ballot(offer && (laneOffers || c == 0));
                 const int numOffers = __popcll(offers);
                 if (numOffers == 0 || numItems + numOffers > offerCap)
                     break;
                 if (pass == 0 && !ptStage)
                 {
-                    maxPasses = (numOffers <= 1) ? CVTT_SPEC_1 : (numOffers <= 2) ? CVTT_SPEC_2 : (numOffers <= 4) ? CVTT_SPEC_4 : (numOffers <= 8) ? CVTT_SPEC_8 : CVTT_SPEC_16;
-                    if (probing)
-                        maxPasses = maxPasses * 2 > 32 ? 32 : maxPasses * 2; // a probe is one unit per partition: twice the partitions per round
+                    if (laneOffers)
+                        maxPasses = numOffers >= 33 ? 1 : numOffers >= 17 ? 2 : numOffers >= 9 ? 4 : numOffers >= 5 ? 8 : 16; // about 64 probes per round
+                    else
+                        maxPasses = (numOffers <= 1) ? CVTT_SPEC_1 : (numOffers <= 2) ? CVTT_SPEC_2 : (numOffers <= 4) ? CVTT_SPEC_4 : (numOffers <= 8) ? CVTT_SPEC_8 : CVTT_SPEC_16;
                 }
                 if (offer)
                 {
@@ -2874,6 +2882,15 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     myCount = pass + 1;
                 }
                 numItems += numOffers;
+            }
+            if (laneOffers)
+            {
+                u32 lo = (u32)offerMask, hi = (u32)(offerMask >> 32);
+                lo |= __shfl_xor(lo, 1);
+                hi |= __shfl_xor(hi, 1);
+                lo |= __shfl_xor(lo, 2);
+                hi |= __shfl_xor(hi, 2);
+                offerMask = ((u64)hi << 32) | lo;
             }
             PROF_MARK(8)
             const bool flush = (numItems == 0); // nothing left to offer: the waiting survivors are searched, then the stage ends
