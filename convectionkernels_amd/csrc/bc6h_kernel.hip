@@ -299,9 +299,13 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                     // seeds of this subset (the reference precomputes them for every partition,
                     // BC67.cpp:2738-2774; recomputing them per precision keeps them out of memory)
                     Unfinished ufep;
+                    // the refiner's sums of the pre-weighted member pixels (EndpointRefiner.h:78-92) do not depend on the indexes:
+                    // the PCA's first pass forms the same sums in the same order, so a round takes them from here instead of
+                    // adding them up pixel by pixel
+                    float vsSubset[3];
                     {
                         Moments<3> m;
-                        pcaMomentsT<3>(F, subsetMask, m);
+                        pcaMomentsT<3>(F, subsetMask, m, vsSubset);
                         pcaFinishT<3>(F, subsetMask, A.w, m, ufep);
                     }
 
@@ -534,7 +538,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                             lf[1] = twosCLHalfToFloat<SIGNED>((int)(short)(a >> 16));
                                             lf[2] = twosCLHalfToFloat<SIGNED>((int)(short)(b & 0xffffu));
                                         }
-                                        const int raw = rawIndexOf(a, b, lf);
+                                        // (the anchor's scan has been done: its index decided the inversion)
+                                        const int raw = (px == fixupIndex) ? fixRaw : rawIndexOf(a, b, lf);
                                         const int index = invert ? (indexRange - 1) - raw : raw;
                                         if (px < 8)
                                             idxLo |= (u32)index << (4 * px);
@@ -573,13 +578,18 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                             {
                                                 const float v = (float)orig[ch] * A.w[ch];
                                                 tv[ch] = tv[ch] + t * v;
-                                                vs[ch] = vs[ch] + v;
                                             }
                                             tt = tt + t * t;
                                             ts = ts + t;
                                             refCount++;
                                         }
                                     }
+                                if (refinePass != numRefineRounds - 1)
+                                {
+#pragma unroll
+                                    for (int ch = 0; ch < 3; ch++)
+                                        vs[ch] = vsSubset[ch];
+                                }
                                 scr[(kScrIdx + (subset * 12 + metaRound) * 2) * 64] = idxLo;
                                 scr[(kScrIdx + (subset * 12 + metaRound) * 2 + 1) * 64] = idxHi;
                                 errR[metaRound * 2 + subset] = subsetError;
