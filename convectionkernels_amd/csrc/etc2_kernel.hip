@@ -1335,8 +1335,31 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
             const int numA0 = prefix[8], numA1 = prefix[16] - prefix[8];
 
             // ---- TestHalfBlock per candidate: lane = candidate (ETC.cpp:94-149, 2793-2828) ----
+            // A half-block candidate only ever matters through a pair whose sum is below the block's best so far
+            // (FindBestDifferentialCombination, ETC.cpp:219-362: every use of an attempt's error is a '<' against that best or
+            // against best - partner).  Its error is a sum of non-negative terms, so once the running sum of EVERY candidate of
+            // a pass has reached the limit the rest of their pixels cannot change anything: the pass stops and leaves the
+            // partial sums (all >= the limit) as the errors.  Limit: the best so far for sector 0; for sector 1, once sector 0
+            // is complete, best - (cheapest sector-0 attempt) -- with a margin of 4 ulp of the best, so that even the float sum
+            // of that pair cannot come out below the best.
+            const float flipBest = bestError;
+            float limit1 = flipBest;
+            bool limit1Ready = false;
             for (int base = 0; base < prefix[16]; base += 64)
             {
+                if (!limit1Ready && base >= prefix[8])
+                {
+                    WAVE_SYNC();
+                    float mn = FLT_MAX;
+                    for (int i = lane; i < numA0; i += 64)
+                        mn = fminf(mn, S.u.a.err[0][i]);
+#pragma unroll
+                    for (int st = 1; st < 64; st <<= 1)
+                        mn = fminf(mn, __shfl_xor(mn, st));
+                    const float l = (flipBest - mn) + flipBest * 2.4e-7f;
+                    limit1 = (l < flipBest) ? l : flipBest; // (also when nothing of sector 0 is below the best: the difference is <= 0, every pass stops at once)
+                    limit1Ready = true;
+                }
                 const int id = base + lane;
                 if (id < prefix[16])
                 {
@@ -1421,6 +1444,8 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                             }
                             totalError = totalError + be;
                             selectors |= bs << (spx * 2);
+                            if (__ballot(totalError < (sector == 0 ? flipBest : limit1)) == 0)
+                                break;
                         }
                     }
                     else
@@ -1444,6 +1469,8 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                             be = 0.0f; // a transparent pixel costs nothing
                         totalError = totalError + be;
                         selectors |= bs << (spx * 2);
+                        if (__ballot(totalError < (sector == 0 ? flipBest : limit1)) == 0)
+                            break;
                     }
                     const int pos = sector == 0 ? id : id - prefix[8];
                     S.u.a.err[sector][pos] = totalError;
