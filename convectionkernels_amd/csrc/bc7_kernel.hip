@@ -253,11 +253,23 @@ __device__ __forceinline__ void quadArgminBroadcast(ShapeBest &b, int lane)
 // `list`: the member pixels in ascending order, 4 bits each (UnitRec::listLo / listHi); best.idxLo / idxHi come back COMPACT: the
 // index of member i in bits [4i, 4i + 4) (expandIndexes puts them at their pixel positions when a block is packed).
 // wantPayload (wave-uniform) = false: only best.err is wanted (probes).
+// A chain cut into pieces (the probes run round 0 of every chain first and the later rounds only once per distinct set of
+// end points): rounds [firstRound, endRound) are run.  firstRound > 0: ep0 / ep1 bring that round's (compressed) end points.
+// endRound < numRefine: ep0 / ep1 take the compressed end points of round endRound away.  r0ep0 / r0ep1: the compressed
+// end points the first executed round used.  (Wave-uniform except for the end points.)
+struct ChainSplit
+{
+    int firstRound, endRound;
+    u32 ep0, ep1;
+    u32 r0ep0, r0ep1;
+};
+
 template <int NRC, bool FAST, bool TRACE>
 __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, u64 list, int maxCount, const ModeDesc md, const Unfinished &u,
                                           int pIter, int tweak, bool active, const CvttBc7Args &A,
                                           const CvttDeviceTables *__restrict__ T, int numRefine, ShapeBest &best,
-                                          const float (&vs)[4], bool wantPayload = true, float *trialErr = nullptr, int captureRound = -1, float *trialErrHbm = nullptr)
+                                          const float (&vs)[4], bool wantPayload = true, float *trialErr = nullptr, int captureRound = -1, float *trialErrHbm = nullptr,
+                                          ChainSplit *split = nullptr)
 {
     const bool isRGB = (NRC == 3);
     const int range = 1 << md.indexBits;
@@ -303,22 +315,41 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, u64 list, int
     const float tf0 = T->tweakFactors[md.indexBits - 2][tweak][0];
     const float tf1 = T->tweakFactors[md.indexBits - 2][tweak][1];
     int ep[2][4];
-#pragma unroll
-    for (int ch = 0; ch < 4; ch++)
+    const int firstRound = split ? split->firstRound : 0, endRound = split ? split->endRound : numRefine;
+    if (firstRound > 0)
     {
-        if (ch < NRC)
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++)
         {
-            ep[0][ch] = (int)clampRound(u.base[ch] + u.offset[ch] * tf0, 255.0f);
-            ep[1][ch] = (int)clampRound(u.base[ch] + u.offset[ch] * tf1, 255.0f);
+            ep[0][ch] = byteI(split->ep0, ch);
+            ep[1][ch] = byteI(split->ep1, ch);
         }
-        else
-            ep[0][ch] = ep[1][ch] = 255;
+    }
+    else
+    {
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++)
+        {
+            if (ch < NRC)
+            {
+                ep[0][ch] = (int)clampRound(u.base[ch] + u.offset[ch] * tf0, 255.0f);
+                ep[1][ch] = (int)clampRound(u.base[ch] + u.offset[ch] * tf1, 255.0f);
+            }
+            else
+                ep[0][ch] = ep[1][ch] = 255;
+        }
     }
 
-    for (int refine = 0; refine < numRefine; refine++)
+    for (int refine = firstRound; refine < endRound; refine++)
     {
         const bool last = (refine == numRefine - 1);
-        compressEndpoints(md, ep, pIter, isRGB);
+        if (refine > firstRound || firstRound == 0)
+            compressEndpoints(md, ep, pIter, isRGB);
+        if (split && refine == firstRound)
+        {
+            split->r0ep0 = packEP(ep[0]);
+            split->r0ep1 = packEP(ep[1]);
+        }
 #ifdef CVTT_BC7_PROFILE
         {
             const u32 k0 = packEP(ep[0]), k1 = packEP(ep[1]);
@@ -535,6 +566,12 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, u64 list, int
                     ep[0][ch] = ep[1][ch] = 0; // overwritten with 255 by compressEndpoints
             }
         }
+    }
+    if (split && endRound < numRefine)
+    {
+        compressEndpoints(md, ep, pIter, isRGB);
+        split->ep0 = packEP(ep[0]);
+        split->ep1 = packEP(ep[1]);
     }
 }
 
@@ -1707,8 +1744,8 @@ __device__ __forceinline__ void makeProjection(const u32 (&pix)[16], const Block
     if constexpr (G8)
     {
     // the four lanes of a quad hold the same block: sub-lane c projects pixels 4c .. 4c+3 and the quad exchanges the words
-    int tid = (int)threadIdx.x;
-    asm volatile("" : "+v"(tid)); // a value of its own: the optimiser otherwise keeps `lane & ~3` of the kernel's prologue alive (spilled) for this
+    int tid = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); // = threadIdx.x (one wave per workgroup), recomputed:
+    asm volatile("" : "+v"(tid)); // the optimiser otherwise keeps the prologue's thread id (or `lane & ~3`) alive, spilled, for this
     const int c = tid & 3;
     u32 myU = 0, myV = 0;
     {
@@ -1882,8 +1919,12 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     // (truncated, i.e. rounded down -- a bound may always be smaller).  Half the bytes of a float table: with that and 64
     // result slots the kernel fits 8 LDS granules = 16 workgroups per CU = 4 waves per SIMD.
     __shared__ unsigned short s_bound[64][16];
-    auto lbLoad = [&](int partition, int b) -> float { return __builtin_bit_cast(float, (u32)s_bound[partition][b] << 16); };
+    // A bound is never negative, so its sign bit is free: it marks the entries that hold a second-tier (full-dimension)
+    // bound already (lbStoreTier2), and readers take the absolute value (a source modifier, no instruction).
+    auto lbLoadRaw = [&](int partition, int b) -> float { return __builtin_bit_cast(float, (u32)s_bound[partition][b] << 16); };
+    auto lbLoad = [&](int partition, int b) -> float { return __builtin_fabsf(lbLoadRaw(partition, b)); };
     auto lbStore = [&](int partition, int b, float v) { s_bound[partition][b] = (unsigned short)(__builtin_bit_cast(u32, v) >> 16); };
+    auto lbStoreTier2 = [&](int partition, int b, float v) { s_bound[partition][b] = (unsigned short)((__builtin_bit_cast(u32, v) >> 16) | 0x8000u); };
     // the same bytes as 32-bit words, [row][block], rows 1..16: where the dual-plane search parks its per-block invariants
     // (row 0 of the 16-bit table, the mode-6 bound, lies below them)
     u32 *const s_raw = reinterpret_cast<u32 *>(&s_bound[0][0]);
@@ -1896,6 +1937,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     __shared__ u32 s_parked[16][2];   // the secondary index set of every block's best mode 4 / 5 candidate, out of the registers until the block is packed
     // the pixel bitmaps of the partitions (subset 1 of a two-subset partition; subsets 1 | 2 << 16 of a three-subset one): the
     // search looks them up per lane many times per round, and a per-lane lookup in the HBM tables is a dependent global load
+    __shared__ float s_static[16];    // static alpha error of the RGB modes, whole block (BC67.cpp:1250-1264), times 0.9999
     __shared__ unsigned short s_pm2[64];
     __shared__ u32 s_pm3[64];
     // best of every (item, subset) = unit of the round: error, endpoints, indexes.  (During the dual-plane search the same
@@ -2418,11 +2460,13 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         }
     };
     int boundsFor = -1; // which bound set s_bound holds: 0 = two subsets RGBA, 1 = two subsets RGB, 2 = three subsets RGB, 3 = mode 6
-    int tier2For = -1;  // ... and for which set the second-tier bounds below have been merged into it,
-    u32 tier2Done = 0;  // for which of this lane's partitions (bit k = partition 4k + c)
+    // (which of its entries have had the second-tier bound merged in is marked in the entries themselves: lbStoreTier2)
     bool tier2Pays = true;
     // static alpha error of the RGB modes, whole block (BC67.cpp:1250-1264)
-    float staticAlphaBlock = 0.0f;
+    // (kept in LDS, one float per block: in a register it lives through every chain round for the sake of two additions per
+    // stage -- and gets spilled)
+    if (c == 0)
+        s_static[blk] = 0.0f;
     if (prune)
     {
         u32 acc = 0;
@@ -2434,7 +2478,8 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             const int d = 255 - byteI(lpix[px], 3);
             acc = (u32)mad24(d, d, (int)acc);
         }
-        staticAlphaBlock = ((A.flags & CVTTMI_FLAG_UNIFORM) ? (float)(int)acc : (float)(int)acc * A.wSq[3]) * 0.9999f;
+        if (c == 0)
+            s_static[blk] = ((A.flags & CVTTMI_FLAG_UNIFORM) ? (float)(int)acc : (float)(int)acc * A.wSq[3]) * 0.9999f;
     }
 
     for (int stageOrder = 0; stageOrder < 6; stageOrder++)
@@ -2558,7 +2603,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                                  subsetBound2D(s2, invScaleSq, delta);
                         }
                         if (!use4)
-                            lb += staticAlphaBlock;
+                            lb += s_static[blk];
                         lbStore(partition, blk, lb);
                         freshAlive |= (lb > work.err) ? 0u : (1u << k);
                     }
@@ -2584,6 +2629,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         u32 aliveBits = (valid && laneRuns) ? everyFourth(enabled, c) : 0u; // `enabled` has no bits past the mode's partitions
         if (mode == 7 && anyBlockHasAlpha && !blockHasNonMaxAlpha)
             aliveBits &= everyFourth(mode7RGB, c); // BC67.cpp:1625-1635: this lane may not take the other partitions
+        u32 tier2Done = 0; // bit k: partition 4k + c has its second-tier bound (none has when the bounds are fresh)
         if (prune)
         {
             if (freshBounds)
@@ -2591,8 +2637,12 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             else
             {
                 for (int k = 0; k * 4 < numPartitions; k++)
-                    if (lbLoad(4 * k + c, blk) > work.err)
+                {
+                    const float raw = lbLoadRaw(4 * k + c, blk);
+                    if (__builtin_fabsf(raw) > work.err)
                         aliveBits &= ~(1u << k);
+                    tier2Done |= (__builtin_bit_cast(u32, raw) >> 31) << k;
+                }
             }
         }
 
@@ -2600,11 +2650,6 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         {
             // second tier: full-dimension bounds of the partitions that are still alive and have none yet.  A partition
             // costs about a fifth of a chain pass here and a seed pass plus chain passes if it stays.
-            if (tier2For != boundSet)
-            {
-                tier2For = boundSet;
-                tier2Done = 0;
-            }
             const u32 todo = aliveBits & ~tier2Done;
             if (tier2Pays && __ballot(todo != 0) != 0)
             {
@@ -2659,14 +2704,12 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                             lb += subsetBoundFull<3>(s0, lw, A.delta3);
                         }
                         if (!use4)
-                            lb += staticAlphaBlock;
-                        if (lb > lbLoad(partition, blk))
-                            lbStore(partition, blk, lb);
+                            lb += s_static[blk];
+                        lbStoreTier2(partition, blk, fmaxf(lb, lbLoad(partition, blk)));
                         if (lb > work.err)
                             aliveBits &= ~(1u << k);
                     }
                 }
-                tier2Done |= todo;
                 // content on which these bounds remove nothing (errors dominated by quantisation, not by the fit of
                 // a line) does not get them again in the later stages of this wave
                 tier2Pays = __ballot(aliveBits != aliveBefore) != 0;
@@ -3108,6 +3151,144 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             PROF_MARK(10)
 
             REFRESH_LANE();
+            // ---- probes with two refine rounds (the default): round 1 only once per distinct set of end points.  The four seed
+            // points of a (unit, p-bits) often refine to the same end points, or to end points round 0 has already tried
+            // (24-47 % of all chain rounds on smooth / photo-like / two-colour content, tools/bc7_dup_profile.py) -- the same
+            // end points on the same pixels give the same error, and a probe wants nothing but the minimum.  So a batch runs
+            // round 0 of its 64 chains, the chains whose round-1 end points are new file them (unit, end points) in a ring in
+            // LDS (the payload words of s_res, idle during a probe), and whenever 64 are waiting one batch runs them; the
+            // minima are taken with ds_min_u32 on the error bits (errors are >= 0). ----
+            const bool dedup = isProbe && numRefine == 2 && (A.prune & 4u) == 0;
+            if (dedup)
+            {
+                constexpr int kRing = 85; // items of three dwords in words 1..4 of the 64 result rows
+                auto ringWord = [&](int item, int j) -> u32 * {
+                    const int flat = item * 3 + j;
+                    return &s_res[flat >> 2][1 + (flat & 3)];
+                };
+                if (lane < numUnits)
+                {
+                    const UnitRec &ru = s_unit[lane];
+                    s_res[ru.slot()][0] = __builtin_bit_cast(u32, ru.scErr); // the single-colour try (FLT_MAX when there is none)
+                }
+                __syncthreads();
+                int ringHead = 0, ringCount = 0;
+                auto runRound1 = [&](int n) {
+                    // lane l < n takes the l-th waiting item
+                    const bool have = lane < n;
+                    int it = ringHead + lane;
+                    it -= it >= kRing ? kRing : 0;
+                    const u32 w0 = have ? *ringWord(it, 0) : 0u;
+                    ChainSplit sp;
+                    sp.firstRound = 1;
+                    sp.endRound = 2;
+                    sp.ep0 = have ? *ringWord(it, 1) : 0u;
+                    sp.ep1 = have ? *ringWord(it, 2) : 0u;
+                    sp.r0ep0 = sp.r0ep1 = 0;
+                    const UnitRec &r = s_unit[w0 & 63u];
+                    const u32 uMask = r.mask();
+                    int maxCount = have ? __popc(uMask) : 0;
+#pragma unroll
+                    for (int step = 1; step < 64; step <<= 1)
+                    {
+                        const int o = __shfl_xor(maxCount, step);
+                        maxCount = o > maxCount ? o : maxCount;
+                    }
+                    maxCount = __builtin_amdgcn_readfirstlane(maxCount);
+                    Unfinished uu;
+#pragma unroll
+                    for (int ch = 0; ch < 4; ch++)
+                        uu.base[ch] = uu.offset[ch] = 0.0f; // not used: the end points come with the item
+                    const float uvs[4] = {0.0f, 0.0f, 0.0f, 0.0f}; // the last round refines nothing
+                    const u64 uList = ((u64)r.listHi << 32) | r.listLo;
+                    ShapeBest b;
+                    if (isRGB)
+                        evalChain<3, FAST, false>(&s_pix[r.blk()][0], uMask, uList, maxCount, md, uu, 0, 0, have, A, T, numRefine, b, uvs, false, nullptr, -1, nullptr, &sp);
+                    else
+                        evalChain<4, FAST, false>(&s_pix[r.blk()][0], uMask, uList, maxCount, md, uu, 0, 0, have, A, T, numRefine, b, uvs, false, nullptr, -1, nullptr, &sp);
+                    if (have)
+                        atomicMin(&s_res[r.slot()][0], __builtin_bit_cast(u32, b.err));
+                    ringHead += n;
+                    ringHead -= ringHead >= kRing ? kRing : 0;
+                    ringCount -= n;
+                    __syncthreads();
+                };
+                for (int u0 = 0; u0 < numUnits; u0 += UPB)
+                {
+                    const int unit = u0 + lane / CP;
+                    const int chain = lane & (CP - 1);
+                    const bool inRange = unit < numUnits;
+                    const UnitRec &r = s_unit[inRange ? unit : 0];
+                    const int tweak = chain & 3, pIter = chain >> 2;
+                    const u32 uMask = r.mask();
+                    const bool active = inRange && tweak < r.numTweak();
+                    int maxCount = active ? __popc(uMask) : 0;
+#pragma unroll
+                    for (int step = 1; step < 64; step <<= 1)
+                    {
+                        const int o = __shfl_xor(maxCount, step);
+                        maxCount = o > maxCount ? o : maxCount;
+                    }
+                    maxCount = __builtin_amdgcn_readfirstlane(maxCount);
+                    Unfinished uu;
+#pragma unroll
+                    for (int ch = 0; ch < 4; ch++)
+                    {
+                        uu.base[ch] = r.base[ch];
+                        uu.offset[ch] = r.offset[ch];
+                    }
+                    const float uvs[4] = {r.vs[0], r.vs[1], r.vs[2], r.vs[3]};
+                    const u64 uList = ((u64)r.listHi << 32) | r.listLo;
+                    PROF_STAGE(stageIter, 0, 1)
+                    PROF_STAGE_LANES(stageIter, 5, active)
+                    ChainSplit sp;
+                    sp.firstRound = 0;
+                    sp.endRound = 1;
+                    sp.ep0 = sp.ep1 = sp.r0ep0 = sp.r0ep1 = 0;
+                    ShapeBest b;
+                    if (isRGB)
+                        evalChain<3, FAST, false>(&s_pix[r.blk()][0], uMask, uList, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b, uvs, false, nullptr, -1, nullptr, &sp);
+                    else
+                        evalChain<4, FAST, false>(&s_pix[r.blk()][0], uMask, uList, maxCount, md, uu, pIter, tweak, active, A, T, numRefine, b, uvs, false, nullptr, -1, nullptr, &sp);
+                    if (active)
+                        atomicMin(&s_res[r.slot()][0], __builtin_bit_cast(u32, b.err));
+                    // is my round 1 new?  Not if a lower seed point of my (unit, p-bits) goes to the same end points, and not
+                    // if some seed point of it has just tried them in round 0
+                    bool needed = active;
+#pragma unroll
+                    for (int o = 0; o < 4; o++)
+                    {
+                        const int src = (lane & ~3) | o;
+                        const bool oAct = __shfl((int)active, src) != 0;
+                        const u32 n0 = __shfl(sp.ep0, src), n1 = __shfl(sp.ep1, src);
+                        const u32 q0 = __shfl(sp.r0ep0, src), q1 = __shfl(sp.r0ep1, src);
+                        if (oAct && o < (lane & 3) && n0 == sp.ep0 && n1 == sp.ep1)
+                            needed = false;
+                        if (oAct && q0 == sp.ep0 && q1 == sp.ep1)
+                            needed = false;
+                    }
+                    const u64 nm = __ballot(needed);
+                    const int nNew = __popcll(nm);
+                    // room for them?  (only when the ring is nearly full: a short batch then)
+                    if (ringCount + nNew > kRing)
+                        runRound1(ringCount < 64 ? ringCount : 64);
+                    if (needed)
+                    {
+                        int it = ringHead + ringCount + (int)__builtin_amdgcn_mbcnt_hi((u32)(nm >> 32), __builtin_amdgcn_mbcnt_lo((u32)nm, 0u));
+                        it -= it >= kRing ? kRing : 0;
+                        *ringWord(it, 0) = (u32)unit;
+                        *ringWord(it, 1) = sp.ep0;
+                        *ringWord(it, 2) = sp.ep1;
+                    }
+                    ringCount += nNew;
+                    __syncthreads();
+                    while (ringCount >= 64)
+                        runRound1(64);
+                }
+                while (ringCount > 0)
+                    runRound1(ringCount < 64 ? ringCount : 64);
+            }
+            else
             // ---- chains: lane l of a batch = (unit l / CP, p-bits (l % CP) / 4, seed point l % 4) ----
             for (int u0 = 0; u0 < numUnits; u0 += UPB)
             {

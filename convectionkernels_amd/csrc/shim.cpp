@@ -1055,7 +1055,8 @@ extern "C"
         args.refineRounds = options->refineRoundsBC7;
         args.numBlocks = static_cast<uint32_t>(numBlocks);
         static const bool noProbe = getenv("CVTTMI_BC7_NOPROBE") && atoi(getenv("CVTTMI_BC7_NOPROBE")) != 0; // developer knob (A/B runs)
-        args.prune = ctx->exhaustive ? 0u : (noProbe ? 3u : 1u);
+        static const bool noDedup = getenv("CVTTMI_BC7_NODEDUP") && atoi(getenv("CVTTMI_BC7_NODEDUP")) != 0; // developer knob (A/B runs)
+        args.prune = ctx->exhaustive ? 0u : ((noProbe ? 3u : 1u) | (noDedup ? 4u : 0u));
         {
             // Slots for one block in a thousand: with the second-tier bounds few blocks of ordinary content keep many
             // partitions; the slots bound the extra wavefronts where every block does, and the second launch is sized
