@@ -88,6 +88,13 @@ constexpr float kBoundGrid8 = 124.0f, kBoundLimit8 = 127.0f;
 #define CVTT_SPEC_16 2
 #endif
 // probe survivors a wave collects before it searches them in full (one full-search chunk holds 32 / 21 partitions)
+#ifndef CVTT_FILTER_STRIKES
+#define CVTT_FILTER_STRIKES 2
+#endif
+#ifndef CVTT_SHARP_COST4
+#define CVTT_SHARP_COST4 32
+#define CVTT_SHARP_COST8 20
+#endif
 #ifndef CVTT_PEND_MIN
 #define CVTT_PEND_MIN 20
 #endif
@@ -1646,6 +1653,181 @@ __device__ __forceinline__ void topEigenvector(const float (&M)[10], float (&e)[
         e[i] = v[i] * inv;
 }
 
+// Second tier, sharpened ("Soundness of the bounds", part 3).  The bound above treats a trial as ANY line plus
+// the worst rounding of the reconstructed colours (delta = 0.5 * |w|, as if every rounding pointed at the pixel).  Two facts
+// about the trials tighten it, both stated for an arbitrary unit vector d (here: the subset's principal direction from a few
+// power iterations -- its accuracy affects only how tight the result is):
+//  * Rounding moves a reconstructed colour by at most 0.5 * w_ch per channel, and only the part of that ACROSS the trial's
+//    line lowers the error.  For a line along u the largest such part is s(u) = 0.5 * sqrt(|w|^2 - min_sigma (u . (sigma w))^2)
+//    (sigma = sign patterns).  With the default channel weights (green and alpha dominate) and a line that follows green, s is
+//    0.16 instead of 0.52.
+//  * The reconstructed colours of a subset are only 2^indexBits points of the line.  Projected on d the pixels are therefore
+//    approximated by that many values: Q_d = the cost of the best clustering of the projections into 2^indexBits groups.  For
+//    four levels a lower bound of it is used, half the sum of the squared gaps between neighbouring projections without the
+//    three largest (a group of m sorted values costs (1/m) sum_{i<j} (t_j - t_i)^2 >= (m-1)/m * its squared gaps).
+// A trial whose line u makes the angle asin(beta) with d (u = alpha d + beta v, v _|_ d) has, before rounding,
+//    error >= alpha^2 R_d + beta^2 L_d - 2 alpha beta rho + max(0, alpha sqrt(Q_d) - beta sqrt(R_d))^2,
+// L_d = d^T S d, R_d = trace(S) - L_d (>= v^T S v), rho = |S d - L_d d| (>= |d^T S v|); the last term is the distance of the
+// projections on u from the (cone of) vectors with few distinct values, which differs from that of the projections on d by at
+// most beta sqrt(v^T S v).  And |u . (sigma w)| >= alpha m_d - beta sqrt(|w|^2 - m_d^2) with m_d = min_sigma |d . (sigma w)|
+// (>= 2 max_ch - sum_ch of |d_ch| w_ch).  [0, 1] is cut into a few intervals of beta; on each, every term is replaced by its worst
+// value there, G - 2 s sqrt(n G) is formed as in the first bound, and the minimum over the intervals is the result.  Margins:
+// every quantity that comes from a cancellation is moved by 1e-5 * trace(S) in the safe direction (the float error of S, of d's
+// length and of the products is below 2e-6 of it), the projections by 2e-3, the result is scaled by 0.9999.
+// (lp: the block's sixteen pixels in LDS.  They are read twice, for the sums and for the projections, rather than kept in
+// registers in between: this function is the register peak of the bounds.)
+template <int N>
+__device__ __forceinline__ float subsetBoundSharp(const u32 *lp, u32 mask, const float (&w)[4], float delta, float wSq, bool fourLevels)
+{
+    RawSums r;
+    {
+        asm volatile("" : "+v"(lp));
+        u32 px[16], CM[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const uint4 v = *reinterpret_cast<const uint4 *>(lp + 4 * i);
+            px[4 * i + 0] = v.x;
+            px[4 * i + 1] = v.y;
+            px[4 * i + 2] = v.z;
+            px[4 * i + 3] = v.w;
+        }
+        channelMajor(px, CM);
+        maskedRawSumsCM(CM, mask, r);
+    }
+    if (r.n < 2)
+        return 0.0f;
+    const float n = (float)r.n;
+    const float inv = __builtin_amdgcn_rcpf(n);
+    Moments<N> m;
+#pragma unroll
+    for (int a = 0; a < N; a++)
+#pragma unroll
+        for (int b = 0; b <= a; b++)
+        {
+            const int v = __mul24(r.n, r.p[tri(a, b)]) - __mul24(r.s[a], r.s[b]);
+            m.cov[tri(a, b)] = (((float)v * inv) * w[a]) * w[b]; // see scatterFromRaw
+        }
+    float rTrue;
+    const float cur = shapeErrorLowerBound<N>(m, n, delta, &rTrue);
+    if (r.n < 3 || !(rTrue >= 0.0f))
+        return cur;
+    float T = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        T += m.cov[tri(i, i)];
+    float e[4];
+    {
+        float M[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++)
+            M[i] = (N == 4 || i < 6) ? m.cov[i < N * (N + 1) / 2 ? i : 0] : 0.0f;
+        topEigenvector(M, e);
+    }
+    float L = 0.0f, Sd[N];
+#pragma unroll
+    for (int a = 0; a < N; a++)
+    {
+        float acc = 0.0f;
+#pragma unroll
+        for (int b = 0; b < N; b++)
+            acc = __fmaf_rn(m.cov[a >= b ? tri(a, b) : tri(b, a)], e[b], acc);
+        Sd[a] = acc;
+        L = __fmaf_rn(e[a], acc, L);
+    }
+    float rho2 = 0.0f, aMax = 0.0f, aSum = 0.0f;
+#pragma unroll
+    for (int a = 0; a < N; a++)
+    {
+        const float t = Sd[a] - L * e[a];
+        rho2 = __fmaf_rn(t, t, rho2);
+        const float ac = fabsf(e[a]) * w[a];
+        aMax = fmaxf(aMax, ac);
+        aSum += ac;
+    }
+    const float eta = 1e-5f * T;
+    const float Llo = fmaxf(L - eta, 0.0f);
+    const float Rlo = fmaxf(T - L - eta, 0.0f);
+    const float sqrtRhi = __builtin_amdgcn_sqrtf(fmaxf(T - L, 0.0f) + eta) * 1.000001f;
+    const float rhoHi = __builtin_amdgcn_sqrtf(rho2) * 1.000001f + eta;
+    const float W2 = wSq * 1.000001f;
+    const float md = fmaxf(2.0f * aMax - aSum, 0.0f) * 0.99999f;
+    const float perp = __builtin_amdgcn_sqrtf(fmaxf(W2 - md * md, 0.0f)) * 1.000001f;
+
+    float sqrtQ = 0.0f;
+    if (fourLevels && r.n > 4)
+    {
+        float g[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++)
+            g[ch] = (ch < N) ? e[ch] * w[ch] : 0.0f;
+        float t[16];
+        asm volatile("" : "+v"(lp));
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const uint4 v = *reinterpret_cast<const uint4 *>(lp + 4 * q);
+            const u32 pw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                float a = 0.0f;
+#pragma unroll
+                for (int ch = 0; ch < N; ch++)
+                    a = __fmaf_rn(g[ch], byteF(pw[k], ch), a);
+                t[4 * q + k] = ((mask >> (4 * q + k)) & 1u) ? a : 1e30f;
+            }
+        }
+        // Batcher's merge exchange, 63 comparators: the members come first, in ascending order
+#define CE(a, b) { const float lo_ = fminf(t[a], t[b]); t[b] = fmaxf(t[a], t[b]); t[a] = lo_; }
+        CE(0,1) CE(2,3) CE(4,5) CE(6,7) CE(8,9) CE(10,11) CE(12,13) CE(14,15) CE(0,2) CE(1,3) CE(4,6) CE(5,7) CE(8,10) CE(9,11) CE(12,14) CE(13,15)
+        CE(1,2) CE(5,6) CE(9,10) CE(13,14) CE(0,4) CE(1,5) CE(2,6) CE(3,7) CE(8,12) CE(9,13) CE(10,14) CE(11,15) CE(2,4) CE(3,5) CE(10,12) CE(11,13)
+        CE(1,2) CE(3,4) CE(5,6) CE(9,10) CE(11,12) CE(13,14) CE(0,8) CE(1,9) CE(2,10) CE(3,11) CE(4,12) CE(5,13) CE(6,14) CE(7,15) CE(4,8) CE(5,9)
+        CE(6,10) CE(7,11) CE(2,4) CE(3,5) CE(6,8) CE(7,9) CE(10,12) CE(11,13) CE(1,2) CE(3,4) CE(5,6) CE(7,8) CE(9,10) CE(11,12) CE(13,14)
+#undef CE
+        float sum = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f; // m1 >= m2 >= m3: the three largest squared gaps
+#pragma unroll
+        for (int j = 0; j < 15; j++)
+        {
+            const float d = (j + 1 < r.n) ? t[j + 1] - t[j] : 0.0f;
+            const float q = d * d;
+            sum += q;
+            const float x1 = fminf(m1, q);
+            m1 = fmaxf(m1, q);
+            const float x2 = fminf(m2, x1);
+            m2 = fmaxf(m2, x1);
+            m3 = fmaxf(m3, x2);
+        }
+        // (the subtraction is of terms of the sum: at worst a few ulps of the largest gap below zero)
+        const float Q = 0.5f * (((sum - m1) - m2) - m3);
+        sqrtQ = fmaxf(__builtin_amdgcn_sqrtf(fmaxf(Q * 0.9999f, 0.0f)) - 2e-3f, 0.0f);
+    }
+
+    // beta = 0, 0.05, 0.1, 0.2, 0.35, 0.6, 1
+    constexpr float kB0sq[6] = {0.0f, 0.0025f, 0.01f, 0.04f, 0.1225f, 0.36f};
+    constexpr float kB1sq[6] = {0.0025f, 0.01f, 0.04f, 0.1225f, 0.36f, 1.0f};
+    constexpr float kB1[6] = {0.05f, 0.1f, 0.2f, 0.35f, 0.6f, 1.0f};
+    constexpr float kA1[6] = {0.998748f, 0.994986f, 0.979794f, 0.936748f, 0.799999f, 0.0f};    // sqrt(1 - beta1^2), rounded down
+    constexpr float kCross[6] = {0.049938f, 0.0995f, 0.19596f, 0.327865f, 0.480001f, 0.5f};     // max of alpha * beta, rounded up
+    float best = FLT_MAX;
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+    {
+        const float e0 = __fmaf_rn(kB0sq[j], Llo - Rlo, Rlo), e1 = __fmaf_rn(kB1sq[j], Llo - Rlo, Rlo);
+        float base = fminf(e0, e1) * 0.999999f - 2.0f * kCross[j] * rhoHi;
+        base = fmaxf(base, rTrue);
+        const float qd = fmaxf(kA1[j] * sqrtQ - kB1[j] * sqrtRhi, 0.0f);
+        const float G = __fmaf_rn(qd, qd, base);
+        const float inner = fmaxf(kA1[j] * md - kB1[j] * perp, 0.0f);
+        const float s2 = 0.25f * (W2 - inner * inner) * 1.000001f;
+        float v = 0.0f;
+        if (G > 4.0001f * n * s2)
+            v = G - 2.0f * __builtin_amdgcn_sqrtf(s2 * n * G) * 1.000001f;
+        best = fminf(best, v);
+    }
+    return fmaxf(cur, best * 0.9999f);
+}
+
 __device__ __forceinline__ int dot4s(u32 a, u32 b, int acc) { return __builtin_amdgcn_sdot4((int)a, (int)b, acc, false); }
 template <bool G8>
 struct Proj2D
@@ -2461,7 +2643,14 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     };
     int boundsFor = -1; // which bound set s_bound holds: 0 = two subsets RGBA, 1 = two subsets RGB, 2 = three subsets RGB, 3 = mode 6
     // (which of its entries have had the second-tier bound merged in is marked in the entries themselves: lbStoreTier2)
-    bool tier2Pays = true;
+    int sharpNoPayBits = 0; // (the same for its second pass)
+    int filterStrikes = 0;  // (and for the sharper bound in the filter of the probes)
+    int tier2NoPayBits = 0; // the second tier removed nothing in a stage with this many index bits: not again, unless a mode has fewer
+    // The second-tier bounds know how many index levels the mode has, and a set of bounds is shared by modes with three and with
+    // two index bits: what is in the table holds for modes with at most boundBits index bits (4 = first tier only, any mode).
+    // The stage orders run the three-bit mode of a set first; its bounds are valid for the two-bit mode that follows, which
+    // computes its own, sharper ones for what is still alive then (marks of the other level are ignored: tier2Bits).
+    int boundBits = 4, tier2Bits = 0;
     // static alpha error of the RGB modes, whole block (BC67.cpp:1250-1264)
     // (kept in LDS, one float per block: in a register it lives through every chain round for the sake of two additions per
     // stage -- and gets spilled)
@@ -2535,8 +2724,11 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         bool freshBounds = false;
         if (prune)
         {
+            if (boundsFor == boundSet && boundBits < md.indexBits)
+                boundsFor = -1; // (no stage order does this: two-bit bounds in the table and a three-bit mode to search)
             if (boundsFor != boundSet)
             {
+                boundBits = 4;
                 __syncthreads();
                 if (boundSet == 3)
                 {
@@ -2649,8 +2841,19 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         if (prune && numSubsets >= 2)
         {
             // second tier: full-dimension bounds of the partitions that are still alive and have none yet.  A partition
-            // costs about a fifth of a chain pass here and a seed pass plus chain passes if it stays.
+            // costs about a fifth of a chain pass here and a seed pass plus chain passes if it stays.  Two passes: the plain
+            // bound (subsetBoundFull) for all of them; then the sharper one (subsetBoundSharp, three times the work) for what the
+            // first pass left -- on noise-like content that is little, and nothing of it goes, so a wave that sees the second
+            // pass remove nothing does not run it again for modes with as many index bits.
+#ifdef CVTT_NO_SHARP_TIER2
+            const bool sharpPays = false;
+#else
+            const bool sharpPays = sharpNoPayBits == 0 || md.indexBits < sharpNoPayBits;
+#endif
+            if (tier2Bits != md.indexBits && sharpPays)
+                tier2Done = 0; // marked by a mode with other index bits
             const u32 todo = aliveBits & ~tier2Done;
+            const bool tier2Pays = tier2NoPayBits == 0 || md.indexBits < tier2NoPayBits;
             if (tier2Pays && __ballot(todo != 0) != 0)
             {
                 const u32 aliveBefore = aliveBits;
@@ -2659,60 +2862,112 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #pragma unroll
                 for (int ch = 0; ch < 4; ch++)
                     lw[ch] = A.w[ch];
-                // the rest of the block: its raw sums are in LDS since the block bounds
-                auto rest = [&](RawSums &d, const RawSums &a) {
-                    d.n = 16 - a.n;
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        d.s[i] = s_scatter[blk][10 + i] - a.s[i];
-#pragma unroll
-                    for (int i = 0; i < 10; i++)
-                        d.p[i] = s_scatter[blk][i] - a.p[i];
-                };
                 u32 CM[4][4];
                 {
                     u32 lpix[16];
                     pixFromLds(lpix);
                     channelMajor(lpix, CM);
                 }
-                // every lane walks its own list: as many rounds as the longest list, not as many as there are slots in use
-                u32 rem = todo;
-                while (__ballot(rem != 0) != 0)
                 {
-                    if (rem != 0)
+                    // the rest of the block: its raw sums are in LDS since the block bounds
+                    auto rest = [&](RawSums &d, const RawSums &a) {
+                        d.n = 16 - a.n;
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            d.s[i] = s_scatter[blk][10 + i] - a.s[i];
+#pragma unroll
+                        for (int i = 0; i < 10; i++)
+                            d.p[i] = s_scatter[blk][i] - a.p[i];
+                    };
+                    // every lane walks its own list: as many rounds as the longest list, not as many as there are slots in use
+                    u32 rem = todo;
+                    while (__ballot(rem != 0) != 0)
                     {
-                        const int k = __ffs((int)rem) - 1;
-                        rem &= rem - 1u;
-                        const int partition = 4 * k + c;
-                        float lb;
-                        RawSums s0, s1;
-                        if (numSubsets == 2)
+                        if (rem != 0)
                         {
-                            maskedRawSumsCM(CM, s_pm2[partition], s1);
-                            rest(s0, s1);
-                            lb = use4 ? subsetBoundFull<4>(s1, lw, A.delta4) : subsetBoundFull<3>(s1, lw, A.delta3);
-                            lb += use4 ? subsetBoundFull<4>(s0, lw, A.delta4) : subsetBoundFull<3>(s0, lw, A.delta3);
+                            const int k = __ffs((int)rem) - 1;
+                            rem &= rem - 1u;
+                            const int partition = 4 * k + c;
+                            float lb;
+                            RawSums s0, s1;
+                            if (numSubsets == 2)
+                            {
+                                maskedRawSumsCM(CM, s_pm2[partition], s1);
+                                rest(s0, s1);
+                                lb = use4 ? subsetBoundFull<4>(s1, lw, A.delta4) : subsetBoundFull<3>(s1, lw, A.delta3);
+                                lb += use4 ? subsetBoundFull<4>(s0, lw, A.delta4) : subsetBoundFull<3>(s0, lw, A.delta3);
+                            }
+                            else
+                            {
+                                maskedRawSumsCM(CM, s_pm3[partition] & 0xffffu, s1);
+                                rest(s0, s1);
+                                lb = subsetBoundFull<3>(s1, lw, A.delta3);
+                                maskedRawSumsCM(CM, s_pm3[partition] >> 16, s1);
+                                rawSumsSub(s0, s1);
+                                lb += subsetBoundFull<3>(s1, lw, A.delta3);
+                                lb += subsetBoundFull<3>(s0, lw, A.delta3);
+                            }
+                            if (!use4)
+                                lb += s_static[blk];
+                            lbStoreTier2(partition, blk, fmaxf(lb, lbLoad(partition, blk)));
+                            if (lb > work.err)
+                                aliveBits &= ~(1u << k);
                         }
-                        else
+                    }
+                }
+                u32 rem2 = todo & aliveBits;
+                if (sharpPays && __ballot(rem2 != 0) != 0)
+                {
+                    const u32 aliveMid = aliveBits;
+                    const bool fourLevels = (md.indexBits == 2);
+                    const float wSq3 = A.wSqSum3, wSq4 = A.wSqSum3 + A.wSq[3];
+                    tier2Bits = md.indexBits;
+                    boundBits = boundBits < md.indexBits ? boundBits : md.indexBits;
+                    bool firstRound = true;
+                    const int sharpNeed = (numSubsets * (fourLevels ? CVTT_SHARP_COST4 : CVTT_SHARP_COST8) + md.numP * 4 - 1) / (md.numP * 4);
+                    while (__ballot(rem2 != 0) != 0)
+                    {
+                        const bool did = rem2 != 0;
+                        bool killed = false;
+                        if (did)
                         {
-                            maskedRawSumsCM(CM, s_pm3[partition] & 0xffffu, s1);
-                            rest(s0, s1);
-                            lb = subsetBoundFull<3>(s1, lw, A.delta3);
-                            maskedRawSumsCM(CM, s_pm3[partition] >> 16, s1);
-                            rawSumsSub(s0, s1);
-                            lb += subsetBoundFull<3>(s1, lw, A.delta3);
-                            lb += subsetBoundFull<3>(s0, lw, A.delta3);
+                            const int k = __ffs((int)rem2) - 1;
+                            rem2 &= rem2 - 1u;
+                            const int partition = 4 * k + c;
+                            // (subset by subset in a rolled loop: the bound of one subset needs some sixty registers)
+                            float lb = 0.0f;
+#pragma unroll 1
+                            for (int sub = 0; sub < numSubsets; sub++)
+                            {
+                                const u32 sm = subsetMaskOf(numSubsets, partition, sub);
+                                lb += use4 ? subsetBoundSharp<4>(&s_pix[blk][0], sm, lw, A.delta4, wSq4, fourLevels) : subsetBoundSharp<3>(&s_pix[blk][0], sm, lw, A.delta3, wSq3, fourLevels);
+                            }
+                            if (!use4)
+                                lb += s_static[blk];
+                            lbStoreTier2(partition, blk, fmaxf(lb, lbLoad(partition, blk)));
+                            if (lb > work.err)
+                            {
+                                aliveBits &= ~(1u << k);
+                                killed = true;
+                            }
                         }
-                        if (!use4)
-                            lb += s_static[blk];
-                        lbStoreTier2(partition, blk, fmaxf(lb, lbLoad(partition, blk)));
-                        if (lb > work.err)
-                            aliveBits &= ~(1u << k);
+                        // One round of this loop costs about numSubsets chain passes (0.6 of that without the sort), and a partition
+                        // it removes saves a probe: 4 * numP chain lanes for a round and a half.  A round that removes fewer
+                        // partitions than it costs ends the loop (the lists of the lanes run out one by one), and when that is
+                        // the very first round the wave does not try again in the stages with as many index bits.
+                        if (__popcll(__ballot(killed)) < sharpNeed)
+                        {
+                            if (firstRound)
+                                sharpNoPayBits = md.indexBits;
+                            break;
+                        }
+                        firstRound = false;
                     }
                 }
                 // content on which these bounds remove nothing (errors dominated by quantisation, not by the fit of
                 // a line) does not get them again in the later stages of this wave
-                tier2Pays = __ballot(aliveBits != aliveBefore) != 0;
+                if (__ballot(aliveBits != aliveBefore) == 0)
+                    tier2NoPayBits = md.indexBits;
             }
         }
 #ifdef CVTT_BC7_PROFILE_SPLIT
@@ -2831,7 +3086,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 int allTotal = 0;
 #pragma unroll
                 for (int b = 0; b < 16; b++)
-                    allTotal += __shfl(kb, 4 * b);
+                    allTotal += __builtin_amdgcn_readlane(kb, 4 * b); // (a scalar: no lane-address register per block to keep alive)
                 allTotal = __builtin_amdgcn_readfirstlane(allTotal);
                 if (allTotal <= 64)
                 {
@@ -2962,7 +3217,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #pragma unroll
                 for (int b = 0; b < 16; b++)
                 {
-                    const int o = __shfl(kb, 4 * b);
+                    const int o = __builtin_amdgcn_readlane(kb, 4 * b);
                     base += (b < blk) ? o : 0;
                     phaseTotal += o;
                 }
@@ -3368,34 +3623,81 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 u64 surv = 0;
                 if (__ballot(iLo + c < iHi) != 0)
                 {
-                    u32 CMf[4][4];
-                    {
-                        u32 lpix[16];
-                        pixFromLds(lpix);
-                        channelMajor(lpix, CMf);
-                    }
                     const bool use4 = (boundSet == 0);
                     const float lwf[4] = {A.w[0], A.w[1], A.w[2], A.w[3]};
-                    for (int i = iLo + c; __ballot(i < iHi) != 0; i += 4)
                     {
-                        if (i < iHi)
+                        u32 CMf[4][4];
                         {
-                            const int partition = (int)(s_item[i] >> 8);
-                            const float eProbed = __builtin_bit_cast(float, s_res[i][0]);
-                            const int ps = probeSubOf(partition);
-                            float lbRest = 0.0f;
-                            for (int sub = 0; sub < numSubsets; sub++)
+                            u32 lpix[16];
+                            pixFromLds(lpix);
+                            channelMajor(lpix, CMf);
+                        }
+                        for (int i = iLo + c; __ballot(i < iHi) != 0; i += 4)
+                        {
+                            if (i < iHi)
                             {
-                                if (sub == ps)
-                                    continue;
-                                RawSums rs;
-                                maskedRawSumsCM(CMf, subsetMaskOf(numSubsets, partition, sub), rs);
-                                lbRest += use4 ? subsetBoundFull<4>(rs, lwf, A.delta4) : subsetBoundFull<3>(rs, lwf, A.delta3);
-                            }
-                            const float lbTotal = (eProbed + lbRest) * 0.9999995f;
+                                const int partition = (int)(s_item[i] >> 8);
+                                const float eProbed = __builtin_bit_cast(float, s_res[i][0]);
+                                const int ps = probeSubOf(partition);
+                                float lbRest = 0.0f;
+                                for (int sub = 0; sub < numSubsets; sub++)
+                                {
+                                    if (sub == ps)
+                                        continue;
+                                    RawSums rs;
+                                    maskedRawSumsCM(CMf, subsetMaskOf(numSubsets, partition, sub), rs);
+                                    lbRest += use4 ? subsetBoundFull<4>(rs, lwf, A.delta4) : subsetBoundFull<3>(rs, lwf, A.delta3);
+                                }
+                                const float lbTotal = (eProbed + lbRest) * 0.9999995f;
 
-                            if (!(lbTotal > work.err))
-                                surv |= 1ull << partition;
+                                if (!(lbTotal > work.err))
+                                    surv |= 1ull << partition;
+                            }
+                        }
+                    }
+                    // what the plain bound of the rest leaves gets the sharper one (in a wave where that one pays: see the second tier)
+                    // (a partition it removes saves a full search, far more than a round of this loop costs: it runs as long as
+                    // it removes anything, and a wave gives it up after CVTT_FILTER_STRIKES calls in a row that began with nothing)
+#ifdef CVTT_NO_SHARP_FILTER
+                    if (false)
+#else
+                    if (filterStrikes < CVTT_FILTER_STRIKES && __ballot(surv != 0) != 0)
+#endif
+                    {
+                        bool firstRound = true;
+                        for (int i = iLo + c; __ballot(i < iHi) != 0; i += 4)
+                        {
+                            const int partition = i < iHi ? (int)(s_item[i] >> 8) : 0;
+                            bool killed = false;
+                            if (i < iHi && ((surv >> partition) & 1ull))
+                            {
+                                const float eProbed = __builtin_bit_cast(float, s_res[i][0]);
+                                const int ps = probeSubOf(partition);
+                                float lbRest = 0.0f;
+#pragma unroll 1
+                                for (int sub = 0; sub < numSubsets; sub++)
+                                {
+                                    if (sub == ps)
+                                        continue;
+                                    const u32 sm = subsetMaskOf(numSubsets, partition, sub);
+                                    lbRest += use4 ? subsetBoundSharp<4>(&s_pix[blk][0], sm, lwf, A.delta4, A.wSqSum3 + A.wSq[3], md.indexBits == 2)
+                                                   : subsetBoundSharp<3>(&s_pix[blk][0], sm, lwf, A.delta3, A.wSqSum3, md.indexBits == 2);
+                                }
+                                const float lbTotal = (eProbed + lbRest) * 0.9999995f;
+                                if (lbTotal > work.err)
+                                {
+                                    surv &= ~(1ull << partition);
+                                    killed = true;
+                                }
+                            }
+                            if (__ballot(killed) == 0)
+                            {
+                                if (firstRound)
+                                    filterStrikes++;
+                                break;
+                            }
+                            filterStrikes = 0;
+                            firstRound = false;
                         }
                     }
                 }
@@ -3413,7 +3715,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     const int kb = __popcll(pend);
 #pragma unroll
                     for (int b = 0; b < 16; b++)
-                        pendTotal += __shfl(kb, 4 * b);
+                        pendTotal += __builtin_amdgcn_readlane(kb, 4 * b);
                     pendTotal = __builtin_amdgcn_readfirstlane(pendTotal);
                 }
                 __syncthreads(); // everybody has read its items before the next list is written

@@ -310,8 +310,9 @@ __device__ __forceinline__ void pcaEndpoints(const u32 (&pix)[16], u32 mask, con
 // scaled down by 1e-4 to absorb the float rounding of S, of this computation and of the
 // reference's own error sums.  A candidate whose bound exceeds the current best can never be
 // committed (the commit needs error <= best), so skipping it leaves the output bit-identical.
+// (rOut, optional: the under-estimated residual itself, or -1 when there is none)
 template <int N>
-__device__ __forceinline__ float shapeErrorLowerBound(const Moments<N> &m, float n, float delta)
+__device__ __forceinline__ float shapeErrorLowerBound(const Moments<N> &m, float n, float delta, float *rOut = nullptr)
 {
     float trace = 0.0f;
 #pragma unroll
@@ -341,6 +342,8 @@ __device__ __forceinline__ float shapeErrorLowerBound(const Moments<N> &m, float
     const float r = trace - lambdaUp;
     float lb = 0.0f;
     // t4 below 1e-30 (lambda_max < 2e-8: absurdly small channel weights) would be summed from denormal products: no bound
+    if (rOut)
+        *rOut = (t4 > 1e-30f) ? r : -1.0f;
     if (r > n * delta * delta && t4 > 1e-30f)
         lb = (r - 2.0f * delta * __builtin_amdgcn_sqrtf(n * r)) * 0.9999f;
     return lb > 0.0f ? lb : 0.0f; // NaN / inf inputs end up as "no bound"

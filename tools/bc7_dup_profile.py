@@ -1,20 +1,21 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): how many single-plane chain rounds of the BC7 search repeat endpoints that another seed point
-of the same (shape, p-bits) already has in this round, or that were evaluated in an earlier round (profile build):
-   CVTTMI_LIB=convectionkernels_amd/lib/variants/libcvtt_mi355x_prof.so python tools/bc7_dup_profile.py [blocks]"""
+"""Developer tool (GPU box, profile build -- see bc7_stage_profile.py): how many chain rounds of the BC7 single-plane search
+start from end points another seed point of the same (unit, p-bit combination) already has in this round / had in an earlier one."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
+import numpy as np, torch
 from convectionkernels_amd import api, synth
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 15
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 14
+want = sys.argv[2:]
 ctx = api.Context(0)
 lib = api.load_library()
 buf = (ctypes.c_ulonglong * 8)()
 for name, b in synth.content_families(N).items():
+    if want and name not in want:
+        continue
     t = torch.from_numpy(b).cuda()
     lib.cvttmi_bc7_dup_read(buf)
     ctx.encode_bc7(t); torch.cuda.synchronize()
     lib.cvttmi_bc7_dup_read(buf)
-    tot = max(1, buf[0])
-    print("%-20s chain rounds per block %8.0f | same as a lower seed point now %.3f | seen in an earlier round %.3f | duplicates by round %s" %
-          (name, buf[0] / N, buf[1] / tot, buf[2] / tot, [round(buf[3 + i] / tot, 3) for i in range(4)]), flush=True)
+    r = [int(v) for v in buf]
+    print("%-20s chain rounds %10d | same as a lower seed now %.3f | seen earlier %.3f | dup by round %s" % (name, r[0], r[1] / max(1, r[0]), r[2] / max(1, r[0]), r[3:7]))
