@@ -92,7 +92,9 @@ constexpr float kBoundGrid8 = 124.0f, kBoundLimit8 = 127.0f;
 #define CVTT_FILTER_STRIKES 2
 #endif
 #ifndef CVTT_SHARP_COST4
-#define CVTT_SHARP_COST4 32
+#define CVTT_SHARP_COST4 64
+#endif
+#ifndef CVTT_SHARP_COST8
 #define CVTT_SHARP_COST8 20
 #endif
 #ifndef CVTT_PEND_MIN
@@ -118,6 +120,7 @@ extern "C" int cvttmi_bc7_stage_read(unsigned long long *out)
 }
 #define PROF_STAGE(stage, slot, n) { const unsigned long long v_ = (unsigned long long)(n); if (threadIdx.x == 0 && v_) atomicAdd(&g_bc7Stage[stage][slot], v_); }
 #define PROF_STAGE_LANES(stage, slot, pred) { const unsigned long long v_ = (unsigned long long)__popcll(__ballot(pred)); if (threadIdx.x == 0 && v_) atomicAdd(&g_bc7Stage[stage][slot], v_); }
+#define PROF_STAGE2(stage, slot, n) { const unsigned long long v_ = (unsigned long long)(n); if (threadIdx.x == 0 && v_) atomicAdd(&g_bc7Stage2[stage][slot], v_); }
 extern "C" int cvttmi_bc7_dup_read(unsigned long long *out)
 {
     unsigned long long zero[8] = {0};
@@ -146,6 +149,7 @@ extern "C" int cvttmi_bc7_prof_read(unsigned long long *out)
 #define PROF_COUNT(slot, n)
 #define PROF_FLUSH
 #define PROF_STAGE(stage, slot, n)
+#define PROF_STAGE2(stage, slot, n)
 #define PROF_STAGE_LANES(stage, slot, pred)
 #endif
 
@@ -1662,9 +1666,9 @@ __device__ __forceinline__ void topEigenvector(const float (&M)[10], float (&e)[
 //    (sigma = sign patterns).  With the default channel weights (green and alpha dominate) and a line that follows green, s is
 //    0.16 instead of 0.52.
 //  * The reconstructed colours of a subset are only 2^indexBits points of the line.  Projected on d the pixels are therefore
-//    approximated by that many values: Q_d = the cost of the best clustering of the projections into 2^indexBits groups.  For
-//    four levels a lower bound of it is used, half the sum of the squared gaps between neighbouring projections without the
-//    three largest (a group of m sorted values costs (1/m) sum_{i<j} (t_j - t_i)^2 >= (m-1)/m * its squared gaps).
+//    approximated by that many values: Q_d = the cost of the best clustering of the projections into 2^indexBits groups
+//    (sum of squared distances to the group means).  It is computed for the two-bit modes, exactly: the projections are
+//    sorted (the groups of an optimal clustering in one dimension are runs) and a dynamic programme places the boundaries.
 // A trial whose line u makes the angle asin(beta) with d (u = alpha d + beta v, v _|_ d) has, before rounding,
 //    error >= alpha^2 R_d + beta^2 L_d - 2 alpha beta rho + max(0, alpha sqrt(Q_d) - beta sqrt(R_d))^2,
 // L_d = d^T S d, R_d = trace(S) - L_d (>= v^T S v), rho = |S d - L_d d| (>= |d^T S v|); the last term is the distance of the
@@ -1755,7 +1759,8 @@ __device__ __forceinline__ float subsetBoundSharp(const u32 *lp, u32 mask, const
     const float perp = __builtin_amdgcn_sqrtf(fmaxf(W2 - md * md, 0.0f)) * 1.000001f;
 
     float sqrtQ = 0.0f;
-    if (fourLevels && r.n > 4)
+    constexpr int kMaxN = 13; // the largest subset of any BC7 partition (a larger one would simply go without Q_d)
+    if (fourLevels && r.n > 4 && r.n <= kMaxN)
     {
         float g[4];
 #pragma unroll
@@ -1785,33 +1790,78 @@ __device__ __forceinline__ float subsetBoundSharp(const u32 *lp, u32 mask, const
         CE(1,2) CE(3,4) CE(5,6) CE(9,10) CE(11,12) CE(13,14) CE(0,8) CE(1,9) CE(2,10) CE(3,11) CE(4,12) CE(5,13) CE(6,14) CE(7,15) CE(4,8) CE(5,9)
         CE(6,10) CE(7,11) CE(2,4) CE(3,5) CE(6,8) CE(7,9) CE(10,12) CE(11,13) CE(1,2) CE(3,4) CE(5,6) CE(7,8) CE(9,10) CE(11,12) CE(13,14)
 #undef CE
-        float sum = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f; // m1 >= m2 >= m3: the three largest squared gaps
+        // The exact cost of the best clustering of the sorted projections into four groups, by dynamic programming over the
+        // group boundaries: D_k[j] = min_i D_(k-1)[i] + cost(i, j), cost(i, j) = sum t^2 - (sum t)^2 / (j - i) over t[i .. j-1]
+        // (empty groups allowed: D_k[0] = 0).  Everything is unrolled over the kMaxN slots a subset can fill, the slots past the
+        // members hold zeros after the shift by t[0], and the last group is taken from suffix sums so that no step depends on
+        // the (per-lane) member count.
+        const int cnt = r.n;
+        const float t0 = t[0];
+        float range = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 15; j++)
+        for (int j = 0; j < kMaxN; j++)
         {
-            const float d = (j + 1 < r.n) ? t[j + 1] - t[j] : 0.0f;
-            const float q = d * d;
-            sum += q;
-            const float x1 = fminf(m1, q);
-            m1 = fmaxf(m1, q);
-            const float x2 = fminf(m2, x1);
-            m2 = fmaxf(m2, x1);
-            m3 = fmaxf(m3, x2);
+            t[j] = (j < cnt) ? t[j] - t0 : 0.0f;
+            range = fmaxf(range, t[j]);
         }
-        // (the subtraction is of terms of the sum: at worst a few ulps of the largest gap below zero)
-        const float Q = 0.5f * (((sum - m1) - m2) - m3);
+        constexpr float kRcp[17] = {0.0f, 1.0f, 1.0f / 2, 1.0f / 3, 1.0f / 4, 1.0f / 5, 1.0f / 6, 1.0f / 7, 1.0f / 8, 1.0f / 9, 1.0f / 10, 1.0f / 11, 1.0f / 12,
+                                    1.0f / 13, 1.0f / 14, 1.0f / 15, 1.0f / 16};
+        float D2[kMaxN + 1], D3[kMaxN + 1];
+        D2[0] = D3[0] = 0.0f;
+        {
+            float su = 0.0f, sq = 0.0f;
+#pragma unroll
+            for (int j = 1; j <= kMaxN; j++)
+            {
+                su += t[j - 1];
+                sq = __fmaf_rn(t[j - 1], t[j - 1], sq);
+                D2[j] = D3[j] = __fmaf_rn(-su * su, kRcp[j], sq); // one group: D_1[j]
+            }
+        }
+        float fin = D3[kMaxN]; // (zeros past the members: an over-estimate of the one-group cost of all of them, harmless in a minimum)
+        {
+            float su0 = 0.0f, sq0 = 0.0f; // prefix sums: D_1[i]
+#pragma unroll
+            for (int i = 1; i < kMaxN; i++)
+            {
+                su0 += t[i - 1];
+                sq0 = __fmaf_rn(t[i - 1], t[i - 1], sq0);
+                const float d1 = __fmaf_rn(-su0 * su0, kRcp[i], sq0);
+                const float d2 = D2[i], d3 = D3[i]; // final: every start below i has been through
+                float su = 0.0f, sq = 0.0f;
+#pragma unroll
+                for (int j = i + 1; j <= kMaxN; j++)
+                {
+                    su += t[j - 1];
+                    sq = __fmaf_rn(t[j - 1], t[j - 1], sq);
+                    const float cst = __fmaf_rn(-su * su, kRcp[j - i], sq);
+                    D2[j] = fminf(D2[j], d1 + cst);
+                    D3[j] = fminf(D3[j], d2 + cst);
+                }
+                // the fourth group, t[i .. cnt-1]: su / sq now hold the sums of everything from i on (zeros past the members)
+                const float m = (float)(cnt - i);
+                const float last = __fmaf_rn(-su * su, __builtin_amdgcn_rcpf(m), sq); // (v_rcp_f32: 1 ulp, inside the margin below)
+                fin = (i < cnt) ? fminf(fin, d3 + last) : fin;
+            }
+        }
+        // float error of a cost: a few ulps of (count * range^2); four of them and the running minima
+        const float Q = fmaxf(fin - 2e-5f * range * range, 0.0f);
         sqrtQ = fmaxf(__builtin_amdgcn_sqrtf(fmaxf(Q * 0.9999f, 0.0f)) - 2e-3f, 0.0f);
     }
 
-    // beta = 0, 0.05, 0.1, 0.2, 0.35, 0.6, 1
-    constexpr float kB0sq[6] = {0.0f, 0.0025f, 0.01f, 0.04f, 0.1225f, 0.36f};
-    constexpr float kB1sq[6] = {0.0025f, 0.01f, 0.04f, 0.1225f, 0.36f, 1.0f};
-    constexpr float kB1[6] = {0.05f, 0.1f, 0.2f, 0.35f, 0.6f, 1.0f};
-    constexpr float kA1[6] = {0.998748f, 0.994986f, 0.979794f, 0.936748f, 0.799999f, 0.0f};    // sqrt(1 - beta1^2), rounded down
-    constexpr float kCross[6] = {0.049938f, 0.0995f, 0.19596f, 0.327865f, 0.480001f, 0.5f};     // max of alpha * beta, rounded up
+    // beta = 0, 0.01, 0.02, 0.03, 0.04, 0.055, 0.07, 0.085, 0.1, 0.125, 0.15, 0.175, 0.2, 0.25, 0.3, 0.375, 0.45, 0.55, 0.7, 0.85, 1: dense
+    // where the minimum usually is (a small angle buys a lot of rounding slack when d is close to the dominant channel)
+    constexpr int kIntervals = 20;
+    constexpr float kB0sq[20] = {0.0f, 0.0001f, 0.0004f, 0.0009f, 0.0016f, 0.003025f, 0.0049f, 0.007225f, 0.01f, 0.015625f, 0.0225f, 0.030625f, 0.04f, 0.0625f, 0.09f, 0.140625f, 0.2025f, 0.3025f, 0.49f, 0.7225f};
+    constexpr float kB1sq[20] = {0.0001f, 0.0004f, 0.0009f, 0.0016f, 0.003025f, 0.0049f, 0.007225f, 0.01f, 0.015625f, 0.0225f, 0.030625f, 0.04f, 0.0625f, 0.09f, 0.140625f, 0.2025f, 0.3025f, 0.49f, 0.7225f, 1.0f};
+    constexpr float kB1[20] = {0.01f, 0.02f, 0.03f, 0.04f, 0.055f, 0.07f, 0.085f, 0.1f, 0.125f, 0.15f, 0.175f, 0.2f, 0.25f, 0.3f, 0.375f, 0.45f, 0.55f, 0.7f, 0.85f, 1.0f};
+    // sqrt(1 - beta1^2), rounded down
+    constexpr float kA1[20] = {0.999948f, 0.999798f, 0.9995479f, 0.9991977f, 0.9984844f, 0.997545f, 0.996379f, 0.9949854f, 0.9921548f, 0.988684f, 0.9845665f, 0.9797939f, 0.9682439f, 0.9539373f, 0.927023f, 0.8930268f, 0.835163f, 0.7141414f, 0.5267816f, 0.0f};
+    // the largest alpha * beta of the interval, rounded up
+    constexpr float kCross[20] = {0.00999952f, 0.01999604f, 0.02998656f, 0.03996807f, 0.05491686f, 0.06982843f, 0.08469255f, 0.09949894f, 0.1240198f, 0.1483032f, 0.1722998f, 0.1959596f, 0.2420619f, 0.2861823f, 0.347635f, 0.4018637f, 0.4593415f, 0.499901f, 0.500001f, 0.4477662f};
     float best = FLT_MAX;
 #pragma unroll
-    for (int j = 0; j < 6; j++)
+    for (int j = 0; j < kIntervals; j++)
     {
         const float e0 = __fmaf_rn(kB0sq[j], Llo - Rlo, Rlo), e1 = __fmaf_rn(kB1sq[j], Llo - Rlo, Rlo);
         float base = fminf(e0, e1) * 0.999999f - 2.0f * kCross[j] * rhoHi;
@@ -2641,16 +2691,24 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             px[4 * i + 3] = v.w;
         }
     };
-    int boundsFor = -1; // which bound set s_bound holds: 0 = two subsets RGBA, 1 = two subsets RGB, 2 = three subsets RGB, 3 = mode 6
-    // (which of its entries have had the second-tier bound merged in is marked in the entries themselves: lbStoreTier2)
-    int sharpNoPayBits = 0; // (the same for its second pass)
-    int filterStrikes = 0;  // (and for the sharper bound in the filter of the probes)
-    int tier2NoPayBits = 0; // the second tier removed nothing in a stage with this many index bits: not again, unless a mode has fewer
-    // The second-tier bounds know how many index levels the mode has, and a set of bounds is shared by modes with three and with
-    // two index bits: what is in the table holds for modes with at most boundBits index bits (4 = first tier only, any mode).
-    // The stage orders run the three-bit mode of a set first; its bounds are valid for the two-bit mode that follows, which
-    // computes its own, sharper ones for what is still alive then (marks of the other level are ignored: tier2Bits).
-    int boundBits = 4, tier2Bits = 0;
+    // Wave-uniform bookkeeping of the bounds, packed into one word of 3-bit fields (six separate ints were six VGPRs to the
+    // register allocator, which cannot tell that they are uniform: they were the first to be spilled):
+    //   WS_BOUNDS_FOR  which bound set s_bound holds, plus one: 1 = two subsets RGBA, 2 = two subsets RGB, 3 = three subsets RGB,
+    //                  4 = mode 6; 0 = none.  (Which of its entries have had the second-tier bound merged in is marked in the
+    //                  entries themselves: lbStoreTier2.)
+    //   WS_T2_NOPAY    the second tier removed nothing in a stage with this many index bits: not again, unless a mode has fewer
+    //   WS_SHARP_NOPAY the same for its second, sharper pass;  WS_STRIKES: and for the sharper bound in the filter of the probes
+    //   WS_BOUND_BITS  The second-tier bounds know how many index levels the mode has, and a set of bounds is shared by modes with
+    //                  three and with two index bits: what is in the table holds for modes with at most this many index bits
+    //                  (4 = first tier only, any mode).  The stage orders run the three-bit mode of a set first; its bounds are
+    //                  valid for the two-bit mode that follows, which computes its own, sharper ones for what is still alive then.
+    //   WS_SHARP_RAN   The marks in the table say "has the plain second-tier bound" (which knows no levels); that the sharper
+    //                  pass has been over the set for a number of index bits is remembered here (the partitions alive in a later
+    //                  stage of the same set were alive then, too).
+    enum : int { WS_BOUNDS_FOR = 0, WS_BOUND_BITS = 3, WS_SHARP_RAN = 6, WS_SHARP_NOPAY = 9, WS_T2_NOPAY = 12, WS_STRIKES = 15 };
+    u32 ws = (4u << WS_BOUND_BITS) | (4u << WS_SHARP_RAN);
+#define WS_GET(f) ((int)((ws >> (f)) & 7u))
+#define WS_SET(f, v) do { ws = (u32)__builtin_amdgcn_readfirstlane((int)((ws & ~(7u << (f))) | ((u32)(v) << (f)))); } while (0)
     // static alpha error of the RGB modes, whole block (BC67.cpp:1250-1264)
     // (kept in LDS, one float per block: in a register it lives through every chain round for the sake of two additions per
     // stage -- and gets spilled)
@@ -2724,11 +2782,12 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         bool freshBounds = false;
         if (prune)
         {
-            if (boundsFor == boundSet && boundBits < md.indexBits)
-                boundsFor = -1; // (no stage order does this: two-bit bounds in the table and a three-bit mode to search)
-            if (boundsFor != boundSet)
+            if (WS_GET(WS_BOUNDS_FOR) == boundSet + 1 && WS_GET(WS_BOUND_BITS) < md.indexBits)
+                WS_SET(WS_BOUNDS_FOR, 0); // (no stage order does this: two-bit bounds in the table and a three-bit mode to search)
+            if (WS_GET(WS_BOUNDS_FOR) != boundSet + 1)
             {
-                boundBits = 4;
+                WS_SET(WS_BOUND_BITS, 4);
+                WS_SET(WS_SHARP_RAN, 4);
                 __syncthreads();
                 if (boundSet == 3)
                 {
@@ -2807,7 +2866,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                         boundsOnGrid(std::false_type{});
                 }
                 __syncthreads();
-                boundsFor = boundSet;
+                WS_SET(WS_BOUNDS_FOR, boundSet + 1);
             }
         }
         PROF_MARK(2)
@@ -2848,13 +2907,13 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #ifdef CVTT_NO_SHARP_TIER2
             const bool sharpPays = false;
 #else
-            const bool sharpPays = sharpNoPayBits == 0 || md.indexBits < sharpNoPayBits;
+            const bool sharpPays = WS_GET(WS_SHARP_NOPAY) == 0 || md.indexBits < WS_GET(WS_SHARP_NOPAY);
 #endif
-            if (tier2Bits != md.indexBits && sharpPays)
-                tier2Done = 0; // marked by a mode with other index bits
             const u32 todo = aliveBits & ~tier2Done;
-            const bool tier2Pays = tier2NoPayBits == 0 || md.indexBits < tier2NoPayBits;
-            if (tier2Pays && __ballot(todo != 0) != 0)
+            const bool tier2Pays = WS_GET(WS_T2_NOPAY) == 0 || md.indexBits < WS_GET(WS_T2_NOPAY);
+            const bool runPlain = tier2Pays && __ballot(todo != 0) != 0;
+            const bool maySharp = sharpPays && WS_GET(WS_SHARP_RAN) > md.indexBits;
+            if (runPlain || (maySharp && __ballot(aliveBits != 0) != 0))
             {
                 const u32 aliveBefore = aliveBits;
                 const bool use4 = (boundSet == 0);
@@ -2862,13 +2921,14 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #pragma unroll
                 for (int ch = 0; ch < 4; ch++)
                     lw[ch] = A.w[ch];
-                u32 CM[4][4];
+                if (runPlain)
                 {
-                    u32 lpix[16];
-                    pixFromLds(lpix);
-                    channelMajor(lpix, CM);
-                }
-                {
+                    u32 CM[4][4];
+                    {
+                        u32 lpix[16];
+                        pixFromLds(lpix);
+                        channelMajor(lpix, CM);
+                    }
                     // the rest of the block: its raw sums are in LDS since the block bounds
                     auto rest = [&](RawSums &d, const RawSums &a) {
                         d.n = 16 - a.n;
@@ -2915,16 +2975,21 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                         }
                     }
                 }
-                u32 rem2 = todo & aliveBits;
-                if (sharpPays && __ballot(rem2 != 0) != 0)
+                u32 rem2 = maySharp ? aliveBits : 0u;
+                const bool fourLevels = (md.indexBits == 2);
+                const int sharpNeed = (numSubsets * (fourLevels ? CVTT_SHARP_COST4 : CVTT_SHARP_COST8) + md.numP * 4 - 1) / (md.numP * 4);
+                // (a wave with fewer candidates than two rounds would have to remove -- noise-like content -- does not start)
+                int sharpCand = __popc(rem2);
+#pragma unroll
+                for (int step = 1; step < 64; step <<= 1)
+                    sharpCand += __shfl_xor(sharpCand, step);
+                if (maySharp && sharpCand >= 2 * sharpNeed)
                 {
                     const u32 aliveMid = aliveBits;
-                    const bool fourLevels = (md.indexBits == 2);
                     const float wSq3 = A.wSqSum3, wSq4 = A.wSqSum3 + A.wSq[3];
-                    tier2Bits = md.indexBits;
-                    boundBits = boundBits < md.indexBits ? boundBits : md.indexBits;
+                    WS_SET(WS_SHARP_RAN, md.indexBits);
+                    WS_SET(WS_BOUND_BITS, WS_GET(WS_BOUND_BITS) < md.indexBits ? WS_GET(WS_BOUND_BITS) : md.indexBits);
                     bool firstRound = true;
-                    const int sharpNeed = (numSubsets * (fourLevels ? CVTT_SHARP_COST4 : CVTT_SHARP_COST8) + md.numP * 4 - 1) / (md.numP * 4);
                     while (__ballot(rem2 != 0) != 0)
                     {
                         const bool did = rem2 != 0;
@@ -2955,10 +3020,13 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                         // it removes saves a probe: 4 * numP chain lanes for a round and a half.  A round that removes fewer
                         // partitions than it costs ends the loop (the lists of the lanes run out one by one), and when that is
                         // the very first round the wave does not try again in the stages with as many index bits.
+                        PROF_STAGE2(stageIter, 0, 1)
+                        PROF_STAGE2(stageIter, 1, __popcll(__ballot(did)))
+                        PROF_STAGE2(stageIter, 2, __popcll(__ballot(killed)))
                         if (__popcll(__ballot(killed)) < sharpNeed)
                         {
                             if (firstRound)
-                                sharpNoPayBits = md.indexBits;
+                                WS_SET(WS_SHARP_NOPAY, md.indexBits);
                             break;
                         }
                         firstRound = false;
@@ -2966,8 +3034,8 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 }
                 // content on which these bounds remove nothing (errors dominated by quantisation, not by the fit of
                 // a line) does not get them again in the later stages of this wave
-                if (__ballot(aliveBits != aliveBefore) == 0)
-                    tier2NoPayBits = md.indexBits;
+                if (runPlain && __ballot(aliveBits != aliveBefore) == 0)
+                    WS_SET(WS_T2_NOPAY, md.indexBits);
             }
         }
 #ifdef CVTT_BC7_PROFILE_SPLIT
@@ -3656,12 +3724,19 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                         }
                     }
                     // what the plain bound of the rest leaves gets the sharper one (in a wave where that one pays: see the second tier)
-                    // (a partition it removes saves a full search, far more than a round of this loop costs: it runs as long as
-                    // it removes anything, and a wave gives it up after CVTT_FILTER_STRIKES calls in a row that began with nothing)
+                    // (a partition it removes saves a full search -- numSubsets * 4 numP chain lanes for two rounds --, a round of
+                    // this loop costs about numSubsets - 1 chain passes: it runs as long as a round removes what it costs, and a
+                    // wave gives it up after CVTT_FILTER_STRIKES calls in a row whose first round did not)
+                    const int filterNeed = ((numSubsets - 1) * (md.indexBits == 2 ? 40 : 26) + numSubsets * md.numP * 4 - 1) / (numSubsets * md.numP * 4);
+                    // (surv is per lane here: sub-lane c has filed the items c, c + 4, ... of its block)
+                    int filterCand = __popcll(surv);
+#pragma unroll
+                    for (int step = 1; step < 64; step <<= 1)
+                        filterCand += __shfl_xor(filterCand, step);
 #ifdef CVTT_NO_SHARP_FILTER
                     if (false)
 #else
-                    if (filterStrikes < CVTT_FILTER_STRIKES && __ballot(surv != 0) != 0)
+                    if (WS_GET(WS_STRIKES) < CVTT_FILTER_STRIKES && filterCand >= 2 * filterNeed)
 #endif
                     {
                         bool firstRound = true;
@@ -3690,13 +3765,16 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                                     killed = true;
                                 }
                             }
-                            if (__ballot(killed) == 0)
+                            PROF_STAGE2(stageIter, 3, 1)
+                            PROF_STAGE2(stageIter, 4, __popcll(__ballot(i < iHi && ((surv >> partition) & 1ull))) + __popcll(__ballot(killed)))
+                            PROF_STAGE2(stageIter, 5, __popcll(__ballot(killed)))
+                            if (__popcll(__ballot(killed)) < filterNeed)
                             {
                                 if (firstRound)
-                                    filterStrikes++;
+                                    WS_SET(WS_STRIKES, WS_GET(WS_STRIKES) + 1);
                                 break;
                             }
-                            filterStrikes = 0;
+                            WS_SET(WS_STRIKES, 0);
                             firstRound = false;
                         }
                     }

@@ -36,7 +36,10 @@ for name, b in synth.content_families(N).items():
         print("   mode %d: alive partitions/block %6.2f | units searched/block %7.2f | chain batches/wave %7.2f | lane use %.2f | offer rounds/wave %6.2f | commits/block %.3f" %
               (m, r[2] / N, r[1] / N, r[0] / (N / 16), r[5] / max(1, r[0] * 64), r[3] / (N / 16), r[4] / N))
         q = [int(buf[48 + si * 8 + k]) for k in range(8)]
-        if q[0]:
+        if q[0] or q[3]:
+            print("           sharper bound: second-tier rounds/wave %.2f, partitions looked at/block %.2f, removed %.3f of them | probe-filter rounds/wave %.2f, looked at/block %.2f, removed %.3f" %
+                  (q[0] / (N / 16), q[1] / N, q[2] / max(1, q[1]), q[3] / (N / 16), q[4] / N, q[5] / max(1, q[4])))
+        if False:
             print("           what-if, of %d searched partitions: ruled out by exact(subset 0) + bound(rest) %.3f | exact(subset 1) + bound(rest) %.3f | larger subset first %.3f | "
                   "larger bound first %.3f | either %.3f | by the total bound at commit time %.3f | beat the best %.4f" %
                   (q[0], q[1] / q[0], q[2] / q[0], q[3] / q[0], q[4] / q[0], q[5] / q[0], q[6] / q[0], q[7] / q[0]))
