@@ -252,6 +252,24 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
     u32 bestEP[6] = {0, 0, 0, 0, 0, 0}; // [subset][3 dwords: (e0r|e0g<<16),(e0b|e1r<<16),(e1g|e1b<<16)]
     u32 bestIdxLo = 0, bestIdxHi = 0;
 
+    // does the delta end point 1 - end point 0 of one subset fit `mode` (BC67.cpp:2597-2663 restricted to that delta)?
+    auto ownDeltaFits = [&](const int (&e)[2][3], int mode, int aPrec) -> bool {
+        if (T->bc6hModeInfo[mode][2] == 0)
+            return true;
+        const int mask = (1 << aPrec) - 1;
+        bool ok = true;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+        {
+            const int lost = 16 - T->bc6hModeInfo[mode][4 + ch];
+            const int bReduced = e[1][ch] & mask & 0xffff;
+            const int d16 = (int)(short)(unsigned short)(e[1][ch] - e[0][ch]);
+            const int delta = (int)(short)(unsigned short)((u32)d16 << lost) >> lost;
+            ok = ok && (((delta + e[0][ch]) & mask & 0xffff) == bReduced);
+        }
+        return ok;
+    };
+
     // the single-subset (4-bit indexes) and the partitioned (3-bit) search are two instantiations of the same body, so
     // that the interpolant table is 16 or 8 entries of registers
     auto searchAll = [&](auto partitionedTag) {
@@ -286,10 +304,19 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
             {
                 const u32 partitionMask = partitioned ? T->partition2[p] : 0u;
                 u32 roundValid0 = 0xfffu, roundValid1 = 0xfffu; // per group (identical in its 8 lanes)
+                // Rounds of subset 0 whose quantised end points fit the delta coding of a mode of this precision in at
+                // least one lane of the wave.  A block can only be committed with such a round (the legality test of
+                // BC67.cpp:2597-2663 includes subset 0's own delta), the commit loop changes no state without a commit,
+                // and the legality is known before a round's pixels are looked at.  So a round nobody can use needs its
+                // indexes only as far as the next refine pass needs them (no error; nothing at all in the last pass), and
+                // a partition in which no round of subset 0 is usable needs neither subset 1 nor the commit loop.
+                u32 usable0 = 0;
 
                 PROF_MARK(6)
                 for (int subset = 0; subset < numSubsets; subset++)
                 {
+                    if (subset == 1 && usable0 == 0)
+                        break;
                     const u32 subsetMask = partitioned ? (subset ? partitionMask : (~partitionMask & 0xffffu)) : 0xffffu;
                     const int fixupIndex = (subset == 0) ? 0 : (int)T->anchor2[p];
                     const int count = __popc(subsetMask);
@@ -506,6 +533,16 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             const u32 qa = ((u32)q[0][0] & 0xffffu) | ((u32)q[0][1] << 16);
                             const u32 qb = ((u32)q[0][2] & 0xffffu) | ((u32)q[1][0] << 16);
                             const u32 qc = ((u32)q[1][1] & 0xffffu) | ((u32)q[1][2] << 16);
+                            bool needError = true; // wave-uniform
+                            if (subset == 0)
+                            {
+                                bool fits = false;
+                                for (int mi = 0; mi < numModesHere; mi++)
+                                    fits = fits || ownDeltaFits(q, (mi == 0) ? modesHere0 : (mi == 1) ? modesHere1 : modesHere2, aPrec);
+                                needError = __ballot(fits) != 0;
+                                if (needError)
+                                    usable0 |= 1u << metaRound;
+                            }
                             // ---- duplicate-round test against every earlier meta round of this subset (group-wide) ----
                             bool anySame = false;
                             for (int prev = 0; prev < metaRound; prev++)
@@ -521,10 +558,15 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 if (subset == 0) roundValid0 &= ~(1u << metaRound); else roundValid1 &= ~(1u << metaRound);
                                 // (its indexes are never read: only valid rounds reach the commit)
                             }
+                            else if (!needError && refinePass == numRefineRounds - 1)
+                            {
+                                // nobody can use this round and no refine pass follows it
+                                errR[metaRound * 2 + subset] = FLT_MAX;
+                            }
                             else
                             {
                                 // ---- error, indexes and refiner sums in pixel order (BC67.cpp:2879-2909) ----
-                                float subsetError = 0.0f;
+                                float subsetError = needError ? 0.0f : FLT_MAX;
                                 u32 idxLo = 0, idxHi = 0;
 #pragma unroll
                                 for (int px = 0; px < 16; px++)
@@ -548,6 +590,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 
                                         const int weight = mad24(weightRcp, raw, 256) >> 9;
                                         const int orig[3] = {(int)(short)(a & 0xffffu), (int)(short)(a >> 16), (int)(short)(b & 0xffffu)};
+                                        if (needError)
+                                        {
                                         float err = 0.0f;
 #pragma unroll
                                         for (int ch = 0; ch < 3; ch++)
@@ -569,6 +613,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                             err = uniformErr ? (err + sq) : (err + sq * A.wSq[ch]);
                                         }
                                         subsetError = subsetError + err;
+                                        }
 
                                         if (refinePass != numRefineRounds - 1)
                                         {
@@ -590,14 +635,17 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     for (int ch = 0; ch < 3; ch++)
                                         vs[ch] = vsSubset[ch];
                                 }
-                                scr[(kScrIdx + (subset * 12 + metaRound) * 2) * 64] = idxLo;
-                                scr[(kScrIdx + (subset * 12 + metaRound) * 2 + 1) * 64] = idxHi;
+                                if (needError)
+                                {
+                                    scr[(kScrIdx + (subset * 12 + metaRound) * 2) * 64] = idxLo;
+                                    scr[(kScrIdx + (subset * 12 + metaRound) * 2 + 1) * 64] = idxHi;
+                                }
                                 errR[metaRound * 2 + subset] = subsetError;
                             }
                             PROF_MARK(4)
                         }
                     }
-                    if (partitioned && subset == 0)
+                    if (partitioned && subset == 0 && usable0 != 0)
                     {
                         // subset 1 reuses the LDS history; the legality pass reads subset 0's from scratch
 #pragma unroll 4
@@ -607,6 +655,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                 }
 
                 // ---- delta-coding legality + commit, BC67.cpp:2914-2986 ----
+                if (usable0 == 0)
+                    continue;
                 const int numMeta1 = partitioned ? 12 : 1;
                 // cheapest valid subset-1 round: no combination with meta0 can beat the best unless this one does
                 float minErr1 = 0.0f;
