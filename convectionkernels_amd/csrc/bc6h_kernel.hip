@@ -242,6 +242,28 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
         }
     }
     const FetchHDR F = {pk01, pk2, A.w};
+    // Does any pixel value of the wave have a zero exponent field (the patterns TwosCLHalfToFloat halves)?  Almost never,
+    // and then the three fix-ups per pixel and round are skipped (unsigned format; wave-uniform).
+    bool pixelFixup = true;
+    if (!SIGNED)
+    {
+        bool z = false;
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+            z = z | ((pk01[px] & 0x7c00u) == 0) | ((pk01[px] & 0x7c000000u) == 0) | ((pk2[px] & 0x7c00u) == 0);
+        pixelFixup = __ballot(z) != 0;
+    }
+    auto pixelToFloat = [&](int v16) -> float {
+        if (SIGNED)
+            return twosCLHalfToFloat<SIGNED>(v16);
+        float f = __half2float(__ushort_as_half((unsigned short)v16));
+        if (pixelFixup)
+        {
+            asm volatile("" ::: "memory"); // keep this a branch: as a select it costs what it is meant to save
+            f = (v16 & 0x7c00) ? f : f * 0.5f;
+        }
+        return f;
+    };
 
     int numTweakRounds = A.seedPoints < 1 ? 1 : (A.seedPoints > 4 ? 4 : A.seedPoints);
     int numRefineRounds = A.refineRounds < 1 ? 1 : (A.refineRounds > 3 ? 3 : A.refineRounds);
@@ -252,20 +274,28 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
     u32 bestEP[6] = {0, 0, 0, 0, 0, 0}; // [subset][3 dwords: (e0r|e0g<<16),(e0b|e1r<<16),(e1g|e1b<<16)]
     u32 bestIdxLo = 0, bestIdxHi = 0;
 
-    // does the delta end point 1 - end point 0 of one subset fit `mode` (BC67.cpp:2597-2663 restricted to that delta)?
-    auto ownDeltaFits = [&](const int (&e)[2][3], int mode, int aPrec) -> bool {
-        if (T->bc6hModeInfo[mode][2] == 0)
+    // A mode of the current precision as one wave-uniform word (a scalar register): mode | transformed << 4 | the bits a
+    // delta loses per channel (16 - bPrec) << 8, 16, 24.  Read from the table once per precision: a table lookup inside a
+    // round is a per-lane memory load the round then waits for.
+    auto modeWord = [&](int mode) -> u32 {
+        const u32 w = (u32)mode | (T->bc6hModeInfo[mode][2] != 0 ? 16u : 0u) | ((16u - T->bc6hModeInfo[mode][4]) << 8) |
+                      ((16u - T->bc6hModeInfo[mode][5]) << 16) | ((16u - T->bc6hModeInfo[mode][6]) << 24);
+        return (u32)__builtin_amdgcn_readfirstlane((int)w);
+    };
+    // does the delta end point 1 - end point 0 of one subset fit the mode (BC67.cpp:2597-2663 restricted to that delta)?
+    auto ownDeltaFits = [&](const int (&e)[2][3], u32 mw, int aPrec) -> bool {
+        if ((mw & 16u) == 0)
             return true;
         const int mask = (1 << aPrec) - 1;
         bool ok = true;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++)
         {
-            const int lost = 16 - T->bc6hModeInfo[mode][4 + ch];
+            const int lost = (int)((mw >> (8 + 8 * ch)) & 31u);
             const int bReduced = e[1][ch] & mask & 0xffff;
             const int d16 = (int)(short)(unsigned short)(e[1][ch] - e[0][ch]);
             const int delta = (int)(short)(unsigned short)((u32)d16 << lost) >> lost;
-            ok = ok && (((delta + e[0][ch]) & mask & 0xffff) == bReduced);
+            ok = ok & (((delta + e[0][ch]) & mask & 0xffff) == bReduced);
         }
         return ok;
     };
@@ -290,15 +320,17 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                 continue;
 
             // the (at most three) modes of this precision, in table order (BC67.cpp:2936-2942)
-            int numModesHere = 0, modesHere0 = 0, modesHere1 = 0, modesHere2 = 0;
+            int numModesHere = 0;
+            u32 modeW0 = 0, modeW1 = 0, modeW2 = 0;
             for (int mode = 0; mode < 14; mode++)
                 if ((T->bc6hModeInfo[mode][1] != 0) == partitioned && T->bc6hModeInfo[mode][3] == aPrec)
                 {
-                    if (numModesHere == 0) modesHere0 = mode;
-                    else if (numModesHere == 1) modesHere1 = mode;
-                    else modesHere2 = mode;
+                    if (numModesHere == 0) modeW0 = modeWord(mode);
+                    else if (numModesHere == 1) modeW1 = modeWord(mode);
+                    else modeW2 = modeWord(mode);
                     numModesHere++;
                 }
+            numModesHere = __builtin_amdgcn_readfirstlane(numModesHere);
 
             for (int p = 0; p < numPartitions; p++)
             {
@@ -480,8 +512,11 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 const float l2 = lf[2] * A.w[2];
                                 float be = 0.0f;
                                 int bi = 0;
+#ifndef CVTT_EXP_SCAN
+#define CVTT_EXP_SCAN indexRange
+#endif
 #pragma unroll
-                                for (int i = 0; i < indexRange; i++)
+                                for (int i = 0; i < CVTT_EXP_SCAN; i++)
                                     {
                                         float d = l0 - iw[i][0];
                                         float e = d * d;
@@ -493,9 +528,11 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                             be = e;
                                         else
                                         {
-                                            if (e < be)
-                                                bi = i;
-                                            be = sseMin(be, e);
+                                            // be = sseMin(be, e) with the index taken along on the same comparison (the errors
+                                            // are sums of squares: no NaN, no -0, so equal values are equal bits)
+                                            const bool lt = e < be;
+                                            bi = lt ? i : bi;
+                                            be = lt ? e : be;
                                         }
                                     }
                                 return bi;
@@ -513,9 +550,9 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             float fixLf[3] = {0.0f, 0.0f, 0.0f};
                             if (!FAST)
                             {
-                                fixLf[0] = twosCLHalfToFloat<SIGNED>((int)(short)(fa & 0xffffu));
-                                fixLf[1] = twosCLHalfToFloat<SIGNED>((int)(short)(fa >> 16));
-                                fixLf[2] = twosCLHalfToFloat<SIGNED>((int)(short)(fb & 0xffffu));
+                                fixLf[0] = pixelToFloat((int)(short)(fa & 0xffffu));
+                                fixLf[1] = pixelToFloat((int)(short)(fa >> 16));
+                                fixLf[2] = pixelToFloat((int)(short)(fb & 0xffffu));
                             }
                             const int fixRaw = rawIndexOf(fetchPixel(fa), fetchPixel(fb), fixLf);
                             PROF_MARK(2)
@@ -536,23 +573,41 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             bool needError = true; // wave-uniform
                             if (subset == 0)
                             {
-                                bool fits = false;
-                                for (int mi = 0; mi < numModesHere; mi++)
-                                    fits = fits || ownDeltaFits(q, (mi == 0) ? modesHere0 : (mi == 1) ? modesHere1 : modesHere2, aPrec);
+                                bool fits = ownDeltaFits(q, modeW0, aPrec);
+                                if (numModesHere > 1)
+                                    fits = fits | ownDeltaFits(q, modeW1, aPrec);
+                                if (numModesHere > 2)
+                                    fits = fits | ownDeltaFits(q, modeW2, aPrec);
                                 needError = __ballot(fits) != 0;
                                 if (needError)
                                     usable0 |= 1u << metaRound;
                             }
                             // ---- duplicate-round test against every earlier meta round of this subset (group-wide) ----
+                            // Only a group whose eight lanes ALL repeat an earlier round skips the round, so the first of the three
+                            // words is compared alone, and the other two only if some group matches in it everywhere.
                             bool anySame = false;
                             for (int prev = 0; prev < metaRound; prev++)
-                                anySame = anySame || (meta[kEpqBase + prev * 3][lane] == qa && meta[kEpqBase + prev * 3 + 1][lane] == qb &&
-                                                      meta[kEpqBase + prev * 3 + 2][lane] == qc);
+                                anySame = anySame || (meta[kEpqBase + prev * 3][lane] == qa);
                             meta[kEpqBase + metaRound * 3][lane] = qa;
                             meta[kEpqBase + metaRound * 3 + 1][lane] = qb;
                             meta[kEpqBase + metaRound * 3 + 2][lane] = qc;
+                            bool groupAllSame = false;
+                            if (metaRound > 0)
+                            {
+                                u64 g = __ballot(anySame);
+                                g &= g >> 1;
+                                g &= g >> 2;
+                                g &= g >> 4;
+                                if ((g & 0x0101010101010101ull) != 0)
+                                {
+                                    anySame = false;
+                                    for (int prev = 0; prev < metaRound; prev++)
+                                        anySame = anySame || (meta[kEpqBase + prev * 3][lane] == qa && meta[kEpqBase + prev * 3 + 1][lane] == qb &&
+                                                              meta[kEpqBase + prev * 3 + 2][lane] == qc);
+                                    groupAllSame = groupBits(__ballot(anySame), lane) == 0xffu;
+                                }
+                            }
                             PROF_MARK(3)
-                            const bool groupAllSame = (metaRound > 0) && (groupBits(__ballot(anySame), lane) == 0xffu);
                             if (groupAllSame)
                             {
                                 if (subset == 0) roundValid0 &= ~(1u << metaRound); else roundValid1 &= ~(1u << metaRound);
@@ -576,9 +631,9 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                         float lf[3] = {0.0f, 0.0f, 0.0f};
                                         if (!FAST)
                                         {
-                                            lf[0] = twosCLHalfToFloat<SIGNED>((int)(short)(a & 0xffffu));
-                                            lf[1] = twosCLHalfToFloat<SIGNED>((int)(short)(a >> 16));
-                                            lf[2] = twosCLHalfToFloat<SIGNED>((int)(short)(b & 0xffffu));
+                                            lf[0] = pixelToFloat((int)(short)(a & 0xffffu));
+                                            lf[1] = pixelToFloat((int)(short)(a >> 16));
+                                            lf[2] = pixelToFloat((int)(short)(b & 0xffffu));
                                         }
                                         // (the anchor's scan has been done: its index decided the inversion)
                                         const int raw = (px == fixupIndex) ? fixRaw : rawIndexOf(a, b, lf);
@@ -696,25 +751,11 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                         }
                         e0[0][0] = (int)(short)(a0 & 0xffffu); e0[0][1] = (int)(short)(a0 >> 16); e0[0][2] = (int)(short)(b0 & 0xffffu);
                         e0[1][0] = (int)(short)(b0 >> 16); e0[1][1] = (int)(short)(c0 & 0xffffu); e0[1][2] = (int)(short)(c0 >> 16);
-                        for (int mi = 0; mi < numModesHere; mi++)
-                        {
-                            const int mode = (mi == 0) ? modesHere0 : (mi == 1) ? modesHere1 : modesHere2;
-                            bool ok = true;
-                            if (T->bc6hModeInfo[mode][2] != 0)
-                            {
-                                const int mask = (1 << aPrec) - 1;
-#pragma unroll
-                                for (int ch = 0; ch < 3; ch++)
-                                {
-                                    const int lost = 16 - T->bc6hModeInfo[mode][4 + ch];
-                                    const int bReduced = e0[1][ch] & mask & 0xffff;
-                                    const int d16 = (int)(short)(unsigned short)(e0[1][ch] - e0[0][ch]);
-                                    const int delta = (int)(short)(unsigned short)((u32)d16 << lost) >> lost;
-                                    ok = ok && (((delta + e0[0][ch]) & mask & 0xffff) == bReduced);
-                                }
-                            }
-                            if (mi == 0) legal0[0] = ok; else if (mi == 1) legal0[1] = ok; else legal0[2] = ok;
-                        }
+                        legal0[0] = ownDeltaFits(e0, modeW0, aPrec);
+                        if (numModesHere > 1)
+                            legal0[1] = ownDeltaFits(e0, modeW1, aPrec);
+                        if (numModesHere > 2)
+                            legal0[2] = ownDeltaFits(e0, modeW2, aPrec);
                     }
                     // a lane whose subset-0 delta fits no mode cannot commit with this meta0 whatever meta1 is
                     if (__ballot(canBeat && (legal0[0] || (numModesHere > 1 && legal0[1]) || (numModesHere > 2 && legal0[2]))) == 0)
@@ -743,13 +784,14 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 
                         for (int mi = 0; mi < numModesHere; mi++)
                         {
-                            const int mode = (mi == 0) ? modesHere0 : (mi == 1) ? modesHere1 : modesHere2;
+                            const u32 mw = (mi == 0) ? modeW0 : (mi == 1) ? modeW1 : modeW2;
+                            const int mode = (int)(mw & 15u);
                             // nobody can commit in this mode: the mode changes no state (BC67.cpp:2954-2955 `continue`)
                             const bool l0 = (mi == 0) ? legal0[0] : (mi == 1) ? legal0[1] : legal0[2];
                             if (__ballot(errorBetter && l0 && !groupDone) == 0)
                                 continue;
-                            const bool transformed = T->bc6hModeInfo[mode][2] != 0;
-                            const int bPrec[3] = {T->bc6hModeInfo[mode][4], T->bc6hModeInfo[mode][5], T->bc6hModeInfo[mode][6]};
+                            const bool transformed = (mw & 16u) != 0;
+                            const int lostBits[3] = {(int)((mw >> 8) & 31u), (int)((mw >> 16) & 31u), (int)((mw >> 24) & 31u)};
 
                             // Evaluate{Partitioned,Single}Legality, BC67.cpp:2597-2663
                             int enc[2][2][3];
@@ -764,7 +806,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 enc[1][1][ch] = partitioned ? e1[1][ch] : 0;
                                 if (transformed)
                                 {
-                                    const int lost = 16 - bPrec[ch];
+                                    const int lost = lostBits[ch];
 #pragma unroll
                                     for (int s = 0; s < 2; s++)
 #pragma unroll

@@ -2,7 +2,7 @@
 """Kernel timing of one format on synthetic BASELINE-style input (developer tool, GPU box).
    python tools/fmt_bench.py bc7|bc7o|bc7b|bc1|bc1x|bc2|bc3|bc4|bc5|bc6hu|bc6hs|etc1|etc2|etc2pt|etc2rgba|eac [size] [reps]   (bc1x / bc7b = with Flags::Better)
    bc7photo|bc7grad|bc7two = EncodeBC7 on (size/4)^2 blocks of the photo-like / smooth opaque gradient / two-colour family of synth.content_families"""
-import sys, os, json
+import sys, os, json, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from convectionkernels_amd import api, synth
@@ -30,4 +30,5 @@ ms = []
 for _ in range(reps):
     a = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
     a.record(); enc(t, out=o); e.record(); torch.cuda.synchronize(); ms.append(a.elapsed_time(e))
-print(json.dumps({"fmt": fmt, "size": size, "blocks": int(b.shape[0]), "ms": min(ms), "mblocks_s": b.shape[0] / min(ms) / 1e3}))
+print(json.dumps({"fmt": fmt, "size": size, "blocks": int(b.shape[0]), "ms": min(ms), "mblocks_s": b.shape[0] / min(ms) / 1e3,
+                  "sha": hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest()[:12], "lib": os.path.basename(os.environ.get("CVTTMI_LIB", ""))}))
