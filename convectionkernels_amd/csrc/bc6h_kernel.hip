@@ -31,6 +31,7 @@ __device__ unsigned long long g_bc6hProf[16];
 #define PROF_DECL unsigned long long profT = __builtin_readcyclecounter(); unsigned long long profAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define PROF_MARK(slot) { const unsigned long long now = __builtin_readcyclecounter(); profAcc[slot] += now - profT; profT = now; }
 #define PROF_FLUSH if (threadIdx.x == 0) { for (int i = 0; i < 8; i++) atomicAdd(&g_bc6hProf[i], profAcc[i]); }
+#define PROF_COUNT(slot, n) { if (threadIdx.x == 0) atomicAdd(&g_bc6hProf[slot], (unsigned long long)(n)); }
 extern "C" int cvttmi_bc6h_prof_read(unsigned long long *out)
 {
     unsigned long long zero[16] = {0};
@@ -42,6 +43,7 @@ extern "C" int cvttmi_bc6h_prof_read(unsigned long long *out)
 #define PROF_DECL
 #define PROF_MARK(slot)
 #define PROF_FLUSH
+#define PROF_COUNT(slot, n) {}
 #endif
 
 namespace
@@ -331,10 +333,22 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                     numModesHere++;
                 }
             numModesHere = __builtin_amdgcn_readfirstlane(numModesHere);
+            // Precisions whose modes all delta-code their end points tightly (8 bits and more: a lane's round fits a mode
+            // with probability 2^-8 ... 2^-18 on content without structure) are searched LAZILY: first the chains of both
+            // subsets without any error (indexes only as far as the refiners need them), then the exact set of
+            // (subset-0 round, subset-1 round) pairs some lane could commit, and only the rounds of that set are evaluated
+            // again, with errors (the replay below: code of its own, so that the chains' registers and branches do not know
+            // about it).  The first partition of a precision that needs a replay switches the rest of the precision back to
+            // the eager search (content whose deltas do fit).
+            bool eagerNow = !(partitioned && aPrec >= 8);
 
             for (int p = 0; p < numPartitions; p++)
             {
                 const u32 partitionMask = partitioned ? T->partition2[p] : 0u;
+                const bool lazy = !eagerNow;
+                if (partitioned && aPrec >= 8) { if (lazy) { PROF_COUNT(13, 1) } else { PROF_COUNT(11, 1) } }
+                u32 cand0 = 0;   // lazy: rounds of subset 0 whose own delta fits a mode in THIS lane
+                u32 invBits = 0; // lazy: bit subset * 12 + round = the round swapped its end points (anchor index in the upper half)
                 u32 roundValid0 = 0xfffu, roundValid1 = 0xfffu; // per group (identical in its 8 lanes)
                 // Rounds of subset 0 whose quantised end points fit the delta coding of a mode of this precision in at
                 // least one lane of the wave.  A block can only be committed with such a round (the legality test of
@@ -512,11 +526,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 const float l2 = lf[2] * A.w[2];
                                 float be = 0.0f;
                                 int bi = 0;
-#ifndef CVTT_EXP_SCAN
-#define CVTT_EXP_SCAN indexRange
-#endif
 #pragma unroll
-                                for (int i = 0; i < CVTT_EXP_SCAN; i++)
+                                for (int i = 0; i < indexRange; i++)
                                     {
                                         float d = l0 - iw[i][0];
                                         float e = d * d;
@@ -581,6 +592,14 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 needError = __ballot(fits) != 0;
                                 if (needError)
                                     usable0 |= 1u << metaRound;
+                                if (lazy && fits)
+                                    cand0 |= 1u << metaRound;
+                            }
+                            if (lazy)
+                            {
+                                needError = false;
+                                if (invert)
+                                    invBits |= 1u << (subset * 12 + metaRound);
                             }
                             // ---- duplicate-round test against every earlier meta round of this subset (group-wide) ----
                             // Only a group whose eight lanes ALL repeat an earlier round skips the round, so the first of the three
@@ -706,6 +725,221 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 #pragma unroll 4
                         for (int e = 0; e < 36; e++)
                             scr[(kScrEpq0 + e) * 64] = meta[kEpqBase + e][lane];
+                    }
+                }
+
+                if (lazy && usable0 != 0)
+                {
+                    // ---- which pairs of rounds could some lane commit? (Evaluate*Legality, BC67.cpp:2597-2663, on end points alone) ----
+                    u32 need0 = 0, need1 = 0;
+                    u32 c0 = cand0 & roundValid0;
+                    PROF_COUNT(8, 1)
+                    PROF_COUNT(12, __popcll(__ballot(c0 != 0)))
+                    while (__ballot(c0 != 0) != 0)
+                    {
+                        PROF_COUNT(9, 1)
+                        const bool act = c0 != 0;
+                        const int m0 = act ? __builtin_ctz(c0) : 0;
+                        c0 &= c0 - 1u;
+                        const u32 a0 = scr[(kScrEpq0 + m0 * 3) * 64], b0 = scr[(kScrEpq0 + m0 * 3 + 1) * 64], cc0 = scr[(kScrEpq0 + m0 * 3 + 2) * 64];
+                        int e0[2][3];
+                        e0[0][0] = (int)(short)(a0 & 0xffffu); e0[0][1] = (int)(short)(a0 >> 16); e0[0][2] = (int)(short)(b0 & 0xffffu);
+                        e0[1][0] = (int)(short)(b0 >> 16); e0[1][1] = (int)(short)(cc0 & 0xffffu); e0[1][2] = (int)(short)(cc0 >> 16);
+                        const bool own0 = ownDeltaFits(e0, modeW0, aPrec);
+                        const bool own1 = numModesHere > 1 && ownDeltaFits(e0, modeW1, aPrec);
+                        const bool own2 = numModesHere > 2 && ownDeltaFits(e0, modeW2, aPrec);
+                        // (the lanes with a candidate are few: one or two of 64 on content without structure, and each fits one
+                        // mode as a rule, so every test is followed by a wave-wide "is anybody still in?")
+                        if (__ballot(act && (own0 || own1 || own2)) == 0)
+                            continue;
+                        for (int m1 = 0; m1 < 12; m1++)
+                        {
+                            const u32 a1 = meta[kEpqBase + m1 * 3][lane], b1 = meta[kEpqBase + m1 * 3 + 1][lane], c1 = meta[kEpqBase + m1 * 3 + 2][lane];
+                            const int x[2][3] = {{(int)(short)(a1 & 0xffffu), (int)(short)(a1 >> 16), (int)(short)(b1 & 0xffffu)},
+                                                 {(int)(short)(b1 >> 16), (int)(short)(c1 & 0xffffu), (int)(short)(c1 >> 16)}};
+                            const bool in = act && ((roundValid1 >> m1) & 1u);
+                            bool ok0 = in && own0, ok1 = in && own1, ok2 = in && own2;
+                            const int mask = (1 << aPrec) - 1;
+                            auto fitsOne = [&](int v, int base, u32 mw, int ch) -> bool {
+                                const int lost = (int)((mw >> (8 + 8 * ch)) & 31u);
+                                const int d16 = (int)(short)(unsigned short)(v - base);
+                                const int delta = (int)(short)(unsigned short)((u32)d16 << lost) >> lost;
+                                return ((delta + base) & mask & 0xffff) == (v & mask & 0xffff);
+                            };
+                            bool alive = true;
+#pragma unroll
+                            for (int epi = 0; epi < 2 && alive; epi++)
+#pragma unroll
+                                for (int ch = 0; ch < 3 && alive; ch++)
+                                {
+                                    ok0 = ok0 && fitsOne(x[epi][ch], e0[0][ch], modeW0, ch);
+                                    if (numModesHere > 1)
+                                        ok1 = ok1 && fitsOne(x[epi][ch], e0[0][ch], modeW1, ch);
+                                    if (numModesHere > 2)
+                                        ok2 = ok2 && fitsOne(x[epi][ch], e0[0][ch], modeW2, ch);
+                                    alive = __ballot(ok0 || ok1 || ok2) != 0;
+                                }
+                            if (ok0 || ok1 || ok2)
+                            {
+                                need0 |= 1u << m0;
+                                need1 |= 1u << m1;
+                            }
+                        }
+                    }
+                    u32 replayRounds = 0; // wave-uniform: bit subset * 12 + round
+                    if (__ballot(need0 != 0) != 0)
+                    {
+#pragma unroll
+                        for (int m = 0; m < 12; m++)
+                        {
+                            if (__ballot((need0 >> m) & 1u) != 0) replayRounds |= 1u << m;
+                            if (__ballot((need1 >> m) & 1u) != 0) replayRounds |= 1u << (12 + m);
+                        }
+                        eagerNow = true;
+                        PROF_COUNT(10, 1)
+                    }
+                    if (replayRounds == 0)
+                        continue; // nobody can commit anything with this partition at this precision
+                    // ---- replay: the rounds of the set again, from their quantised end points, this time with errors ----
+                    for (u32 todo = replayRounds; todo != 0; todo &= todo - 1u)
+                    {
+                        const int bit = __builtin_ctz(todo);
+                        const int rs = bit >= 12 ? 1 : 0, rm = bit - 12 * rs;
+                        const u32 rmask = opaqueUniform(rs ? partitionMask : (~partitionMask & 0xffffu));
+                        u32 ra, rb, rc;
+                        if (rs == 0)
+                        {
+                            ra = scr[(kScrEpq0 + rm * 3) * 64];
+                            rb = scr[(kScrEpq0 + rm * 3 + 1) * 64];
+                            rc = scr[(kScrEpq0 + rm * 3 + 2) * 64];
+                        }
+                        else
+                        {
+                            ra = meta[kEpqBase + rm * 3][lane];
+                            rb = meta[kEpqBase + rm * 3 + 1][lane];
+                            rc = meta[kEpqBase + rm * 3 + 2][lane];
+                        }
+                        // the end points as the round had them before it swapped them (the scan's first-minimum rule sees the order)
+                        const bool was = ((invBits >> bit) & 1u) != 0;
+                        const int s0[3] = {(int)(short)(ra & 0xffffu), (int)(short)(ra >> 16), (int)(short)(rb & 0xffffu)};
+                        const int s1[3] = {(int)(short)(rb >> 16), (int)(short)(rc & 0xffffu), (int)(short)(rc >> 16)};
+                        int unq[2][3], fin[2][3];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                        {
+                            const int q0 = was ? s1[ch] : s0[ch], q1 = was ? s0[ch] : s1[ch];
+                            unq[0][ch] = SIGNED ? unquantizeSigned(q0, aPrec, fin[0][ch]) : unquantizeUnsigned(q0, aPrec, fin[0][ch]);
+                            unq[1][ch] = SIGNED ? unquantizeSigned(q1, aPrec, fin[1][ch]) : unquantizeUnsigned(q1, aPrec, fin[1][ch]);
+                        }
+                        float iw[indexRange][3];
+                        float origin[3], axis[3];
+                        if (FAST)
+                        {
+                            float epDW[3];
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++)
+                            {
+                                origin[ch] = (float)fin[0][ch];
+                                epDW[ch] = ((float)fin[1][ch] - origin[ch]) * A.w[ch];
+                            }
+                            float lenSq = epDW[0] * epDW[0];
+                            lenSq = lenSq + epDW[1] * epDW[1];
+                            lenSq = lenSq + epDW[2] * epDW[2];
+                            lenSq = safeDenom(lenSq);
+                            const float mvdls = maxValue / lenSq;
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++)
+                                axis[ch] = epDW[ch] * A.w[ch] * mvdls;
+                        }
+                        else
+                        {
+#pragma unroll
+                            for (int i = 0; i < indexRange; i++)
+                            {
+                                const int weight = mad24(weightRcp, i, 256) >> 9;
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++)
+                                    iw[i][ch] = twosCLHalfToFloat<SIGNED>(reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight)) * A.w[ch];
+                            }
+                        }
+                        float subsetError = 0.0f;
+                        u32 idxLo = 0, idxHi = 0;
+#pragma unroll 1
+                        for (int px = 0; px < 16; px++)
+                        {
+                            if (((rmask >> px) & 1u) == 0)
+                                continue;
+                            u32 a = 0, b = 0;
+#pragma unroll
+                            for (int k = 0; k < 16; k++)
+                                if (k == px)
+                                {
+                                    a = pk01[k];
+                                    b = pk2[k];
+                                }
+                            float lf[3] = {0.0f, 0.0f, 0.0f};
+                            int raw;
+                            if (FAST)
+                            {
+                                const int c0 = (int)(short)(a & 0xffffu), c1 = (int)(short)(a >> 16), c2 = (int)(short)(b & 0xffffu);
+                                float dist = ((float)c0 - origin[0]) * axis[0];
+                                dist = dist + ((float)c1 - origin[1]) * axis[1];
+                                dist = dist + ((float)c2 - origin[2]) * axis[2];
+                                raw = (int)clampRound(dist, maxValue);
+                            }
+                            else
+                            {
+                                lf[0] = pixelToFloat((int)(short)(a & 0xffffu));
+                                lf[1] = pixelToFloat((int)(short)(a >> 16));
+                                lf[2] = pixelToFloat((int)(short)(b & 0xffffu));
+                                const float l0 = lf[0] * A.w[0], l1 = lf[1] * A.w[1], l2 = lf[2] * A.w[2];
+                                float be = 0.0f;
+                                raw = 0;
+#pragma unroll
+                                for (int i = 0; i < indexRange; i++)
+                                {
+                                    float d = l0 - iw[i][0];
+                                    float e = d * d;
+                                    d = l1 - iw[i][1];
+                                    e = e + d * d;
+                                    d = l2 - iw[i][2];
+                                    e = e + d * d;
+                                    const bool lt = (i == 0) || (e < be);
+                                    raw = lt ? i : raw;
+                                    be = lt ? e : be;
+                                }
+                            }
+                            const int index = was ? (indexRange - 1) - raw : raw;
+                            if (px < 8)
+                                idxLo |= (u32)index << (4 * px);
+                            else
+                                idxHi |= (u32)index << (4 * (px - 8));
+                            const int weight = mad24(weightRcp, raw, 256) >> 9;
+                            const int orig[3] = {(int)(short)(a & 0xffffu), (int)(short)(a >> 16), (int)(short)(b & 0xffffu)};
+                            float err = 0.0f;
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++)
+                            {
+                                const int rec = reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight);
+                                float sq;
+                                if (FAST)
+                                {
+                                    const int r16 = (int)(short)rec;
+                                    const u32 du = (u32)((r16 > orig[ch] ? r16 : orig[ch]) - (r16 > orig[ch] ? orig[ch] : r16)) & 0xffffu;
+                                    sq = (float)(int)(du * du);
+                                }
+                                else
+                                {
+                                    const float d = twosCLHalfToFloat<SIGNED>(rec) - lf[ch];
+                                    sq = d * d;
+                                }
+                                err = uniformErr ? (err + sq) : (err + sq * A.wSq[ch]);
+                            }
+                            subsetError = subsetError + err;
+                        }
+                        scr[(kScrIdx + (rs * 12 + rm) * 2) * 64] = idxLo;
+                        scr[(kScrIdx + (rs * 12 + rm) * 2 + 1) * 64] = idxHi;
+                        errR[rm * 2 + rs] = subsetError;
                     }
                 }
 

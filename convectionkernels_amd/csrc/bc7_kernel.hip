@@ -2058,6 +2058,26 @@ struct Sums2D
     int n, u, v, uu, vv, uv;
 };
 
+// 8-bit grid, the subset given as the byte masks of CvttDeviceTables::subsetByteMask (one 16-byte load instead of four
+// nibble -> byte-mask expansions per subset: those were a third of the instructions of a first-tier bound, a quarter-rate
+// v_mul_lo_u32 among them)
+__device__ __forceinline__ void maskedSumsSel(const Proj2D<true> &P, int n, const uint4 &sel, Sums2D &m)
+{
+    m.n = n;
+    m.u = m.v = m.uu = m.vv = m.uv = 0;
+    const u32 s4[4] = {sel.x, sel.y, sel.z, sel.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        const u32 um = P.U[k] & s4[k], vm = P.V[k] & s4[k];
+        m.u = dot4s(um, 0x01010101u, m.u);
+        m.v = dot4s(vm, 0x01010101u, m.v);
+        m.uu = dot4s(um, P.U[k], m.uu);
+        m.vv = dot4s(vm, P.V[k], m.vv);
+        m.uv = dot4s(um, P.V[k], m.uv);
+    }
+}
+
 template <bool G8>
 __device__ __forceinline__ void maskedSums(const Proj2D<G8> &P, u32 mask, Sums2D &m)
 {
@@ -2100,14 +2120,16 @@ __device__ __forceinline__ void maskedSums(const Proj2D<G8> &P, u32 mask, Sums2D
 // Lower bound on the error of any trial of the subset with sums `m`.  |coordinates| <= 2040 and
 // n <= 16 keep n*sum(uu) and sum(u)^2 below 2^31, so A, B, C are exact; the float steps that
 // follow are protected by relative margins on the large terms.
+template <bool G8 = false>
 __device__ __forceinline__ float subsetBound2D(const Sums2D &m, float invScaleSq, float delta)
 {
     if (m.n < 2)
         return 0.0f;
-    // |sum u|, |sum v| <= 16 * 2040 fit 24 bits: v_mul_i32_i24 is a full-rate instruction, v_mul_lo_u32 is not
-    const int a = m.n * m.uu - __mul24(m.u, m.u);
-    const int c = m.n * m.vv - __mul24(m.v, m.v);
-    const int b = m.n * m.uv - __mul24(m.u, m.v);
+    // |sum u|, |sum v| <= 16 * 2040 fit 24 bits: v_mul_i32_i24 is a full-rate instruction, v_mul_lo_u32 is not; on the 8-bit
+    // grid the sums of squares (<= 16 * 128^2) fit as well
+    const int a = (G8 ? __mul24(m.n, m.uu) : m.n * m.uu) - __mul24(m.u, m.u);
+    const int c = (G8 ? __mul24(m.n, m.vv) : m.n * m.vv) - __mul24(m.v, m.v);
+    const int b = (G8 ? __mul24(m.n, m.uv) : m.n * m.uv) - __mul24(m.u, m.v);
     const float fa = (float)a, fc = (float)c, fb = (float)b;
     const float half = (fa + fc) * 0.5f;
     const float diff = (fa - fc) * 0.5f;
@@ -2823,40 +2845,73 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                         makeProjection(lpix, bsL, A, use4, scale, P);
                     }
                     PROF_MARK(7)
+                    // the byte masks of the next partition are loaded while this one is computed
+                    const bool two = boundSet < 2;
+                    auto selOf = [&](int partition, int which) -> uint4 {
+                        return *reinterpret_cast<const uint4 *>(T->subsetByteMask[two ? partition : 64 + 2 * partition + which]);
+                    };
+                    uint4 selA = make_uint4(0, 0, 0, 0), selB = make_uint4(0, 0, 0, 0);
+                    if constexpr (G8)
+                    {
+                        selA = selOf(c, 0);
+                        if (!two)
+                            selB = selOf(c, 1);
+                    }
                     for (int k = 0; k < 16; k++)
                     {
                         const int partition = 4 * k + c;
                         float lb;
+                        uint4 selA1 = selA, selB1 = selB;
+                        if constexpr (G8)
+                        {
+                            const int nextPartition = (k < 15 ? partition + 4 : partition);
+                            selA1 = selOf(nextPartition, 0);
+                            if (!two)
+                                selB1 = selOf(nextPartition, 1);
+                        }
                         if (boundSet < 2)
                         {
                             Sums2D s1, s0;
-                            maskedSums(P, s_pm2[partition], s1);
+                            if constexpr (G8)
+                                maskedSumsSel(P, __popc((u32)s_pm2[partition]), selA, s1);
+                            else
+                                maskedSums(P, s_pm2[partition], s1);
                             s0.n = 16 - s1.n;
                             s0.u = P.tU - s1.u;
                             s0.v = P.tV - s1.v;
                             s0.uu = P.tUU - s1.uu;
                             s0.vv = P.tVV - s1.vv;
                             s0.uv = P.tUV - s1.uv;
-                            lb = subsetBound2D(s0, invScaleSq, delta) + subsetBound2D(s1, invScaleSq, delta);
+                            lb = subsetBound2D<G8>(s0, invScaleSq, delta) + subsetBound2D<G8>(s1, invScaleSq, delta);
                         }
                         else
                         {
                             Sums2D s1, s2, s0;
+                            if constexpr (G8)
+                            {
+                                maskedSumsSel(P, __popc(s_pm3[partition] & 0xffffu), selA, s1);
+                                maskedSumsSel(P, __popc(s_pm3[partition] >> 16), selB, s2);
+                            }
+                            else
+                            {
                             maskedSums(P, s_pm3[partition] & 0xffffu, s1);
                             maskedSums(P, s_pm3[partition] >> 16, s2);
+                            }
                             s0.n = 16 - s1.n - s2.n;
                             s0.u = P.tU - s1.u - s2.u;
                             s0.v = P.tV - s1.v - s2.v;
                             s0.uu = P.tUU - s1.uu - s2.uu;
                             s0.vv = P.tVV - s1.vv - s2.vv;
                             s0.uv = P.tUV - s1.uv - s2.uv;
-                            lb = subsetBound2D(s0, invScaleSq, delta) + subsetBound2D(s1, invScaleSq, delta) +
-                                 subsetBound2D(s2, invScaleSq, delta);
+                            lb = subsetBound2D<G8>(s0, invScaleSq, delta) + subsetBound2D<G8>(s1, invScaleSq, delta) +
+                                 subsetBound2D<G8>(s2, invScaleSq, delta);
                         }
                         if (!use4)
                             lb += s_static[blk];
                         lbStore(partition, blk, lb);
                         freshAlive |= (lb > work.err) ? 0u : (1u << k);
+                        selA = selA1;
+                        selB = selB1;
                     }
                     freshBounds = true;
                     };

@@ -41,6 +41,10 @@ struct CvttDeviceTables
     uint8_t s3tcSingleColor[8][256][4];
     // ETC_UseFakeBT709 rounding table (tools/gen_fake709_rounding.py): [r << 8 | g << 4 | b] = nearest cell corner
     uint8_t fake709Rounding[4096];
+    // Byte masks of the subsets the first-tier BC7 bounds sum over on the 8-bit grid (bc7_kernel.hip, maskedSums): pixel i
+    // of the subset -> byte i % 4 of word i / 4 is 0xff.  [partition] = subset 1 of a two-subset partition,
+    // [64 + 2 * partition + s] = subset 1 + s of a three-subset partition.
+    uint32_t subsetByteMask[192][4];
 };
 
 // The caller's plan plus two bitmaps derived on the host: which shapes the plan's

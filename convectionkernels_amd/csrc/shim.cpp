@@ -165,6 +165,18 @@ namespace
                 t.shapes3[i][s] = k_shapes3[i * 3 + s];
             t.subsetMask3[i][0] = k_shape_mask[k_shapes3[i * 3 + 1]];
             t.subsetMask3[i][1] = k_shape_mask[k_shapes3[i * 3 + 2]];
+            for (int which = 0; which < 3; which++)
+            {
+                const uint32_t bits = which == 0 ? t.partition2[i] : t.subsetMask3[i][which - 1];
+                uint32_t *dst = which == 0 ? t.subsetByteMask[i] : t.subsetByteMask[64 + 2 * i + (which - 1)];
+                for (int w = 0; w < 4; w++)
+                {
+                    dst[w] = 0;
+                    for (int b = 0; b < 4; b++)
+                        if ((bits >> (4 * w + b)) & 1u)
+                            dst[w] |= 0xffu << (8 * b);
+                }
+            }
             t.anchor2[i] = k_anchor2[i];
             t.anchor3[i][0] = k_anchor3[i * 2 + 0];
             t.anchor3[i][1] = k_anchor3[i * 2 + 1];

@@ -92,6 +92,31 @@ def test_gpu_vs_reference_on_this_box(gpu_ctx, ref_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("signed", [False, True])
+def test_gpu_usable_rounds_vary_inside_a_wave(gpu_ctx, oracle_lib, signed):
+    """The kernel computes a round's error only when some lane of the WAVE can commit with it (the delta-coding legality
+    of the round's end points is known before its pixels are looked at) and skips subset 1 and the commit loop of a
+    partition in which no round of subset 0 is usable.  Blocks whose deltas fit the transformed modes (ramps, narrow
+    ranges, solid, two colours) are shuffled block by block among noise blocks whose deltas never do, so that inside
+    every wave -- and inside every 8-block group, where the reference couples the lanes -- usable and unusable rounds mix
+    at every precision."""
+    from convectionkernels_amd import api
+    rcp = oracle_lib.probe_rcp()
+    gpu_ctx.set_rcp_table(rcp)
+    mixed = content.mixed_hdr_blocks(4242, 40, signed=signed)
+    noise = content.config_blocks_hdr(7, 64, 80)  # 320 blocks of config-3 noise
+    blocks = np.concatenate([mixed, noise])
+    rng = np.random.Generator(np.random.PCG64(11))
+    blocks = np.ascontiguousarray(blocks[rng.permutation(len(blocks))])
+    for opt_kw in ({}, {"flags": pyref.FLAG_BC6H_FAST_INDEXING, "seed_points": 3}, {"refine_bc6h": 1}):
+        ob = pyref.make_options(**opt_kw)
+        exp = oracle_lib.encode_bc6h(blocks, ob, signed, rcp, threads=8)
+        got = gpu_ctx.encode_bc6h(blocks, api.Options.frombytes(ob), signed=signed)
+        bad = np.nonzero((got != exp).any(axis=1))[0]
+        assert bad.size == 0, (opt_kw, bad[:8])
+
+
+@pytest.mark.gpu
 def test_gpu_config3_full_size_hash(gpu_ctx):
     """BASELINE configs[2]: EncodeBC6HU on 4096x4096 random HDR (seed 3): SHA-256 of the 16 MiB output equals the
     reference's (canonical build, recorded RCPPS table)"""

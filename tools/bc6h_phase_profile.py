@@ -15,3 +15,5 @@ ctx.encode_bc6h(t); torch.cuda.synchronize()
 lib.cvttmi_bc6h_prof_read(buf)
 tot = float(sum(buf[:8]))
 print({names[i]: round(buf[i] / tot, 4) for i in range(7)}, "cycles/wave", tot / (t.shape[0] / 64))
+waves = t.shape[0] / 64
+print("per wave: lazy partitions %.1f, eager partitions (prec >= 8) %.1f, pair searches %.2f, their rounds %.2f (lanes with a candidate %.2f), replays %.3f" % (buf[13] / waves, buf[11] / waves, buf[8] / waves, buf[9] / waves, buf[12] / waves, buf[10] / waves))
