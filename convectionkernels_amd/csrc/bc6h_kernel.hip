@@ -56,7 +56,11 @@ namespace
 //         EPQ0 36 dwords + IDX 2 subsets x 12 rounds x 2 dwords (4 bits per pixel) = 84 dwords,
 //         written once per round, read only by the legality pass / at a commit
 constexpr int kEpqBase = 0, kMetaDwords = 36; // the 24 per-round errors live in registers (uniform dynamic index)
-constexpr int kScrEpq0 = 0, kScrIdx = 36, kScratchDwords = 84;
+constexpr int kScrEpq0 = 0, kScrIdx = 36, kScrPca = 84, kScratchDwords = 84 + 32 * 2 * 9;
+// kScrPca: the PCA seeds (base, offset) and the pre-weighted pixel sums of every (partition, subset), 9 floats: they do not depend
+// on the precision, so the first partitioned precision files them and the other five read them back (147 KB per wave, written
+// once and read five times in coalesced 256-byte lines: about 0.1 TB/s at 8 Mblocks/s) instead of running three passes over
+// the pixels and eight power iterations with IEEE divisions again
 // Waves per SIMD the register allocator must leave room for.  4 (128 VGPRs, 48 dwords of spill) instead of 3 (149, no
 // spill) measures +3.5 %: the shim feeds the kernel 2^18 blocks = 4 096 waves = 4 per SIMD at a time, which 3 slots take
 // in two rounds (3 + 1), and gfx950 overlaps the plain f32 instructions of an EVEN number of resident waves
@@ -302,6 +306,24 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
         return ok;
     };
 
+    // PCA seeds of a subset and the sums of its pre-weighted pixels; slot >= 0: filed for the later precisions (kScrPca)
+    auto pcaSeeds = [&](u32 subsetMask, Unfinished &u, float (&sums)[3], int slot) {
+        Moments<3> m;
+        pcaMomentsT<3>(F, subsetMask, m, sums);
+        pcaFinishT<3>(F, subsetMask, A.w, m, u);
+        if (slot >= 0)
+        {
+            u32 *dst = scr + (size_t)(kScrPca + slot * 9) * 64;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+            {
+                dst[ch * 64] = __float_as_uint(u.base[ch]);
+                dst[(3 + ch) * 64] = __float_as_uint(u.offset[ch]);
+                dst[(6 + ch) * 64] = __float_as_uint(sums[ch]);
+            }
+        }
+    };
+
     // the single-subset (4-bit indexes) and the partitioned (3-bit) search are two instantiations of the same body, so
     // that the interpolant table is 16 or 8 entries of registers
     auto searchAll = [&](auto partitionedTag) {
@@ -361,9 +383,18 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                 PROF_MARK(6)
                 for (int subset = 0; subset < numSubsets; subset++)
                 {
-                    if (subset == 1 && usable0 == 0)
-                        break;
                     const u32 subsetMask = partitioned ? (subset ? partitionMask : (~partitionMask & 0xffffu)) : 0xffffu;
+                    if (subset == 1 && usable0 == 0)
+                    {
+                        if (aPrec == 11)
+                        {
+                            // nobody needs subset 1 here, but the later precisions need its seeds
+                            Unfinished u1;
+                            float v1[3];
+                            pcaSeeds(subsetMask, u1, v1, p * 2 + 1);
+                        }
+                        break;
+                    }
                     const int fixupIndex = (subset == 0) ? 0 : (int)T->anchor2[p];
                     const int count = __popc(subsetMask);
                     const float wRcp = T->rcpTable[count];
@@ -376,11 +407,19 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                     // the PCA's first pass forms the same sums in the same order, so a round takes them from here instead of
                     // adding them up pixel by pixel
                     float vsSubset[3];
+                    if (partitioned && aPrec != 11)
                     {
-                        Moments<3> m;
-                        pcaMomentsT<3>(F, subsetMask, m, vsSubset);
-                        pcaFinishT<3>(F, subsetMask, A.w, m, ufep);
+                        const u32 *src = scr + (size_t)(kScrPca + (p * 2 + subset) * 9) * 64;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                        {
+                            ufep.base[ch] = __uint_as_float(src[ch * 64]);
+                            ufep.offset[ch] = __uint_as_float(src[(3 + ch) * 64]);
+                            vsSubset[ch] = __uint_as_float(src[(6 + ch) * 64]);
+                        }
                     }
+                    else
+                        pcaSeeds(subsetMask, ufep, vsSubset, partitioned ? p * 2 + subset : -1);
 
                     PROF_MARK(0)
                     for (int tweak = 0; tweak < 4; tweak++)
