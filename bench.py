@@ -551,6 +551,7 @@ def run_single(args):
             result["host_path"] = hp
         result["configs"] = per_config_legs(torch, api, synth, ctx, dev, h, rcp, rcp_gold, same_lut, args)
         result["content_families"] = family_legs(torch, api, synth, ctx, dev, rcp, args.no_cpu)
+        result["bc6h_content_families"] = bc6h_family_legs(torch, api, synth, ctx, dev, rcp, args.no_cpu)
         # the one-GPU rate on the workload the N > 1 runs shard (one 16384^2 image): the base of a strong-scaling curve
         base = result["configs"].get("5a_bc7_16384")
         if base:
@@ -630,6 +631,38 @@ def family_legs(torch, api, synth, ctx, dev, rcp, no_cpu, n=1 << 20, check=1 << 
         t = torch.from_numpy(b).to(dev)
         out = ctx.encode_bc7(t, opt, plan)
         ms, _ = timed_encode(torch, lambda: ctx.encode_bc7(t, opt, plan, out=out), 2)
+        res[name] = {"mblocks_s": n / ms / 1e3, "kernel_ms": ms}
+        if cpu:
+            got = out[:check].cpu().numpy()
+            exp = cpu[1](np.ascontiguousarray(b[:check]))
+            res[name]["mismatches_vs_cpu"] = int((got != exp[:check]).any(axis=1).sum())
+            res[name]["blocks_checked"] = int(check)
+            res[name]["cpu_kind"] = cpu[0]
+        del t, out
+    return res
+
+
+def bc6h_family_legs(torch, api, synth, ctx, dev, rcp, no_cpu, n=1 << 17, check=1 << 11):
+    """EncodeBC6HU on three kinds of HDR content: the search skips what the delta coding of the end points rules out, so
+    its rate depends on how close together a block's end points are (noise = BASELINE config 3: nearly everything is ruled
+    out at the higher precisions; smooth content: nearly nothing is).  Each family is compared with the CPU path on its
+    first `check` blocks."""
+    res = {}
+    opt = api.Options()
+    ob = np.frombuffer(opt.tobytes(), np.uint8).copy()
+    cpu = None
+    if not no_cpu:
+        from oracle import pyref
+        if pyref.RefLib.available(fast=True) and (pyref.RefLib(fast=True).probe_rcp() == rcp).all():
+            ref = pyref.RefLib(fast=True)
+            cpu = ("reference", lambda b: ref.encode_mt("bc6hu", b, ob, None, threads=usable_cores(), budget_s=60.0, chunk_blocks=64)[0])
+        else:
+            orc = pyref.OracleLib()
+            cpu = ("port", lambda b: orc.encode_bc6h(b, ob, False, rcp, usable_cores()))
+    for name, b in synth.hdr_content_families(n).items():
+        t = torch.from_numpy(b).to(dev)
+        out = ctx.encode_bc6h(t, opt, signed=False)
+        ms, _ = timed_encode(torch, lambda: ctx.encode_bc6h(t, opt, signed=False, out=out), 2)
         res[name] = {"mblocks_s": n / ms / 1e3, "kernel_ms": ms}
         if cpu:
             got = out[:check].cpu().numpy()

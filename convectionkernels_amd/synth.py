@@ -98,3 +98,32 @@ def content_families(n, seed=2026):
     hi[:, :, 3] = rng.integers(248, 256, (n, 16))
     f["alpha 248..255"] = hi
     return f
+
+
+def hdr_content_families(n, seed=2027):
+    """Three kinds of PixelBlockF16 content, (n, 16, 4) int16 half bit patterns, alpha = 1.0: the BC6H search skips what the
+    delta coding of the end points rules out, so its rate depends on whether a block's end points are close
+    together.  `noise`: BASELINE config 3 (every channel an independent positive normal half); `smooth ramps`: a linear
+    gradient per block in linear light; `narrow range`: bright colours within +-40 half codes of a base colour."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    yy, xx = np.divmod(np.arange(16), 4)
+    f = {}
+    r = rng.integers(0, 1 << 62, (n, 16, 3), dtype=np.int64)
+    noise = np.empty((n, 16, 4), np.uint16)
+    noise[..., :3] = (((1 + (r >> 10) % 29) << 10) | (r & 0x3FF)).astype(np.uint16)
+    noise[..., 3] = 0x3C00
+    f["noise"] = noise.view(np.int16)
+    c0 = rng.uniform(0.05, 4.0, (n, 1, 3))
+    dx = rng.normal(0, 0.2, (n, 1, 3))
+    dy = rng.normal(0, 0.2, (n, 1, 3))
+    lin = np.clip(c0 + xx[None, :, None] * dx + yy[None, :, None] * dy, 0, 60000)
+    ramp = np.empty((n, 16, 4), np.uint16)
+    ramp[..., :3] = lin.astype(np.float16).view(np.uint16)
+    ramp[..., 3] = 0x3C00
+    f["smooth ramps"] = ramp.view(np.int16)
+    base = rng.integers(0x3000, 0x7000, (n, 1, 3))
+    nar = np.empty((n, 16, 4), np.uint16)
+    nar[..., :3] = (base + rng.integers(-40, 41, (n, 16, 3))).astype(np.uint16)
+    nar[..., 3] = 0x3C00
+    f["narrow range"] = nar.view(np.int16)
+    return f
