@@ -642,7 +642,7 @@ def family_legs(torch, api, synth, ctx, dev, rcp, no_cpu, n=1 << 20, check=1 << 
     return res
 
 
-def bc6h_family_legs(torch, api, synth, ctx, dev, rcp, no_cpu, n=1 << 17, check=1 << 11):
+def bc6h_family_legs(torch, api, synth, ctx, dev, rcp, no_cpu, n=1 << 19, check=1 << 11):
     """EncodeBC6HU on three kinds of HDR content: the search skips what the delta coding of the end points rules out, so
     its rate depends on how close together a block's end points are (noise = BASELINE config 3: nearly everything is ruled
     out at the higher precisions; smooth content: nearly nothing is).  Each family is compared with the CPU path on its

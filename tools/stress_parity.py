@@ -80,16 +80,30 @@ def main():
     h = rng.integers(0, 0x7C00, (n6, 16, 4)).astype(np.uint16); h[:, :, 3] = 0x3C00
     base = rng.integers(0x3000, 0x7000, (n6, 1, 3)); nar = (base + rng.integers(-60, 61, (n6, 16, 3))).astype(np.uint16)
     h2 = np.zeros((n6, 16, 4), np.uint16); h2[:, :, :3] = nar; h2[:, :, 3] = 0x3C00
-    for name, hb in ((("wide noise", h), ("narrow", h2)) if STAGE in ("all", "hdr") else ()):
+    # + the three families of bench.py's bc6h_content_families, and everything shuffled block by block: the BC6H search decides
+    # wave by wave (64 blocks) what the delta coding rules out, so blocks whose deltas fit must also sit next to blocks whose
+    # deltas never do, inside waves and inside the reference's 8-block groups
+    hdr = []
+    if STAGE in ("all", "hdr"):
+        from convectionkernels_amd import synth
+        hdr = [("wide noise", h), ("narrow", h2)] + [(k, v.view(np.uint16)) for k, v in synth.hdr_content_families(n6, SEED).items()]
+        allb = np.concatenate([v for _, v in hdr])
+        hdr.append(("shuffled mix", np.ascontiguousarray(allb[rng.permutation(allb.shape[0])[: 2 * n6]])))
+    fastopt = pyref.make_options(flags=pyref.FLAG_BC6H_FAST_INDEXING)
+    gpu_fast = api.Options(flags=api.Flags.BC6H_FastIndexing)
+    for name, hb in hdr:
         for sg in (False, True):
             hb2 = hb.copy()
             if sg:
-                hb2[:, :, :3] |= (rng.integers(0, 2, (n6, 16, 3)) << 15).astype(np.uint16)
+                hb2[:, :, :3] |= (rng.integers(0, 2, hb2[:, :, :3].shape) << 15).astype(np.uint16)
             b = hb2.view(np.int16)
-            g = ctx.encode_bc6h(torch.from_numpy(b).cuda(), signed=sg).cpu().numpy()
-            r = ref_parallel(lambda x: canon.encode_bc6h(x, o, sg), b, 16, threads)
-            bad = int((g != r).any(axis=1).sum()); total_bad += bad
-            print("BC6H%s %-24s %8d blocks  mismatches %d" % ("S" if sg else "U", name, b.shape[0], bad), flush=True)
+            for label, go, ro in (("", None, o), (" fast", gpu_fast, fastopt)):
+                if label and name not in ("shuffled mix", "noise"):
+                    continue
+                g = (ctx.encode_bc6h(torch.from_numpy(b).cuda(), signed=sg) if go is None else ctx.encode_bc6h(torch.from_numpy(b).cuda(), go, signed=sg)).cpu().numpy()
+                r = ref_parallel(lambda x: canon.encode_bc6h(x, ro, sg), b, 16, threads)
+                bad = int((g != r).any(axis=1).sum()); total_bad += bad
+                print("BC6H%s%s %-24s %8d blocks  mismatches %d" % ("S" if sg else "U", label, name, b.shape[0], bad), flush=True)
     if STAGE in ("all", "rows"):
         better = pyref.make_options(flags=pyref.FLAGS_BETTER)
         gpu_better = api.Options(flags=api.Flags.Better)
