@@ -754,6 +754,8 @@ __device__ __forceinline__ u32 rotatePixel(u32 pk, int rotation)
     return pk;
 }
 
+__device__ __forceinline__ void levelTable(int e0, int e1, bool threeBit, u32 &tabLo, u32 &tabHi);
+
 // One (mode, rotation, index selector) configuration of the dual-plane modes 4/5
 // (reference BC67.cpp:1725-1940): sub-lane c runs seed point c.  `pix` is already rotated so
 // that byte 3 is the separately coded channel; w/wSq/rcpW are rotated the same way.
@@ -860,6 +862,16 @@ __device__ __forceinline__ void evalDual(const u32 *sP, u32 minMax, int mode, in
             const v2f ax01 = {axis[0], axis[1]}, ax23 = {axis[2], axis[3]};
             const v2f w01 = {rw[0], rw[1]}, w23 = {rw[2], 1.0f};
             const v2f rcpMax2 = {rgbRcpMax, alphaRcpMax};
+            // slow indexing: the 4 / 8 values an index can reconstruct, per channel, as bytes (the fast path's level tables):
+            // the three candidates of a pixel are then one v_perm_b32 per channel instead of a weight and a multiply-add each
+            u32 tLo[4] = {0, 0, 0, 0}, tHi[4] = {0, 0, 0, 0};
+            if (!FAST)
+            {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                    levelTable(ep[0][ch], ep[1][ch], rgbPrec == 3, tLo[ch], tHi[ch]);
+                levelTable(ep[0][3], ep[1][3], alphaPrec == 3, tLo[3], tHi[3]);
+            }
 
             u32 err[4] = {0, 0, 0, 0};
             float slowRGB = 0.0f, slowA = 0.0f;
@@ -901,27 +913,18 @@ __device__ __forceinline__ void evalDual(const u32 *sP, u32 minMax, int mode, in
                 {
                     // reference BC67.cpp:1834-1880
                     float eRGB = 0.0f, eA = 0.0f;
-#pragma unroll
-                    for (int probe = 0; probe < 3; probe++)
-                    {
-                        int candRGB = iRGB, candA = iA;
-                        if (probe == 1)
-                        {
-                            candRGB = (iRGB > 1 ? iRGB : 1) - 1;
-                            candA = (iA > 1 ? iA : 1) - 1;
-                        }
-                        if (probe == 2)
-                        {
-                            candRGB = (iRGB + 1 < rgbRange - 1) ? iRGB + 1 : rgbRange - 1;
-                            candA = (iA + 1 < alphaRange - 1) ? iA + 1 : alphaRange - 1;
-                        }
-                        const int wgt = mad24(rgbWR, candRGB, 256) >> 9;
-                        u32 e3[3];
-                        e3[0] = channelError<0>(wgt, recDelta[0], recBase[0], pk);
-                        e3[1] = channelError<1>(wgt, recDelta[1], recBase[1], pk);
-                        e3[2] = channelError<2>(wgt, recDelta[2], recBase[2], pk);
-                        const int wa = mad24(alphaWR, candA, 256) >> 9;
-                        const u32 e1 = channelError<3>(wa, recDelta[3], recBase[3], pk);
+                    const int c1R = (iRGB > 1 ? iRGB : 1) - 1, c2R = (iRGB + 1 < rgbRange - 1) ? iRGB + 1 : rgbRange - 1;
+                    const int c1A = (iA > 1 ? iA : 1) - 1, c2A = (iA + 1 < alphaRange - 1) ? iA + 1 : alphaRange - 1;
+                    const u32 selR = (u32)iRGB | ((u32)c1R << 8) | ((u32)c2R << 16) | 0x0c000000u;
+                    const u32 selA = (u32)iA | ((u32)c1A << 8) | ((u32)c2A << 16) | 0x0c000000u;
+                    // byte k = the value candidate k reconstructs
+                    const u32 rec0 = __builtin_amdgcn_perm(tHi[0], tLo[0], selR), rec1 = __builtin_amdgcn_perm(tHi[1], tLo[1], selR),
+                              rec2 = __builtin_amdgcn_perm(tHi[2], tLo[2], selR), rec3 = __builtin_amdgcn_perm(tHi[3], tLo[3], selA);
+                    auto probeOne = [&](auto kTag, int candRGB, int candA) {
+                        constexpr int K = decltype(kTag)::value;
+                        const int d0 = subByteK<K, 0>(rec0, pk), d1 = subByteK<K, 1>(rec1, pk), d2 = subByteK<K, 2>(rec2, pk), d3 = subByteK<K, 3>(rec3, pk);
+                        const u32 e3[3] = {(u32)__mul24(d0, d0), (u32)__mul24(d1, d1), (u32)__mul24(d2, d2)};
+                        const u32 e1 = (u32)__mul24(d3, d3);
                         float er, ea;
                         if (uniformErr)
                         {
@@ -935,7 +938,7 @@ __device__ __forceinline__ void evalDual(const u32 *sP, u32 minMax, int mode, in
                             er = er + (float)(int)e3[2] * rwSq[2];
                             ea = (float)(int)e1 * rwSq[3];
                         }
-                        if (probe == 0)
+                        if (K == 0)
                         {
                             eRGB = er;
                             eA = ea;
@@ -948,7 +951,10 @@ __device__ __forceinline__ void evalDual(const u32 *sP, u32 minMax, int mode, in
                             if (bR) fRGB = (float)candRGB;
                             if (bA) fA = (float)candA;
                         }
-                    }
+                    };
+                    probeOne(std::integral_constant<int, 0>{}, iRGB, iA);
+                    probeOne(std::integral_constant<int, 1>{}, c1R, c1A);
+                    probeOne(std::integral_constant<int, 2>{}, c2R, c2A);
                     slowRGB = slowRGB + eRGB;
                     slowA = slowA + eA;
                     iRGB = (int)fRGB;

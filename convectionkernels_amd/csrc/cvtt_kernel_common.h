@@ -100,6 +100,27 @@ __device__ __forceinline__ int subByte1(int sum, u32 pk)
         asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_3" : "=v"(r) : "v"(sum), "v"(pk));
     return r;
 }
+// byte K of `recs` (a reconstructed channel value) minus channel CH of the pixel: one SDWA subtract
+template <int K, int CH>
+__device__ __forceinline__ int subByteK(u32 recs, u32 pk)
+{
+    int r;
+#define CVTT_SUBK(k, c) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #k " src1_sel:BYTE_" #c : "=v"(r) : "v"(recs), "v"(pk))
+    if (K == 0)
+    {
+        if (CH == 0) CVTT_SUBK(0, 0); else if (CH == 1) CVTT_SUBK(0, 1); else if (CH == 2) CVTT_SUBK(0, 2); else CVTT_SUBK(0, 3);
+    }
+    else if (K == 1)
+    {
+        if (CH == 0) CVTT_SUBK(1, 0); else if (CH == 1) CVTT_SUBK(1, 1); else if (CH == 2) CVTT_SUBK(1, 2); else CVTT_SUBK(1, 3);
+    }
+    else
+    {
+        if (CH == 0) CVTT_SUBK(2, 0); else if (CH == 1) CVTT_SUBK(2, 1); else if (CH == 2) CVTT_SUBK(2, 2); else CVTT_SUBK(2, 3);
+    }
+#undef CVTT_SUBK
+    return r;
+}
 // squared error of channel CH for interpolation weight w, added to acc
 template <int CH>
 __device__ __forceinline__ u32 accumulateChannelError(int w, int delta4, int base4, u32 pk, u32 acc)
