@@ -459,21 +459,25 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, u64 list, int
                         if (probe == 1) cand = (index > 1 ? index : 1) - 1;
                         if (probe == 2) cand = (index + 1 < range - 1) ? index + 1 : range - 1;
                         const int wgt = mad24(weightRcp, cand, 256) >> 9;
-                        u32 e4[4] = {0, 0, 0, 0};
-                        e4[0] = channelError<0>(wgt, recDelta[0], recBase[0], pk);
-                        e4[1] = channelError<1>(wgt, recDelta[1], recBase[1], pk);
-                        e4[2] = channelError<2>(wgt, recDelta[2], recBase[2], pk);
-                        if (NRC == 4)
-                            e4[3] = channelError<3>(wgt, recDelta[3], recBase[3], pk);
+                        // the reconstructed channel is byte 1 of w * delta4 + base4; its difference to the pixel and the
+                        // square are taken as floats (exact on these integers, see evalDual: plain f32 instructions)
+                        const float xs[4] = {x01.x, x01.y, x23.x, x23.y};
+                        float e4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int ch = 0; ch < NRC; ch++)
+                        {
+                            const float d = byteF((u32)madI24(wgt, recDelta[ch], recBase[ch]), 1) - xs[ch];
+                            e4[ch] = d * d;
+                        }
                         float e;
                         if (uniformErr)
-                            e = (float)(int)(e4[0] + e4[1] + e4[2] + e4[3]);
+                            e = ((e4[0] + e4[1]) + e4[2]) + e4[3];
                         else
                         {
-                            e = (float)(int)e4[0] * A.wSq[0];
-                            e = e + (float)(int)e4[1] * A.wSq[1];
-                            e = e + (float)(int)e4[2] * A.wSq[2];
-                            e = e + (float)(int)e4[3] * A.wSq[3];
+                            e = e4[0] * A.wSq[0];
+                            e = e + e4[1] * A.wSq[1];
+                            e = e + e4[2] * A.wSq[2];
+                            e = e + e4[3] * A.wSq[3];
                         }
                         if (probe == 0)
                             bestE = e;
@@ -922,21 +926,25 @@ __device__ __forceinline__ void evalDual(const u32 *sP, u32 minMax, int mode, in
                               rec2 = __builtin_amdgcn_perm(tHi[2], tLo[2], selR), rec3 = __builtin_amdgcn_perm(tHi[3], tLo[3], selA);
                     auto probeOne = [&](auto kTag, int candRGB, int candA) {
                         constexpr int K = decltype(kTag)::value;
-                        const int d0 = subByteK<K, 0>(rec0, pk), d1 = subByteK<K, 1>(rec1, pk), d2 = subByteK<K, 2>(rec2, pk), d3 = subByteK<K, 3>(rec3, pk);
-                        const u32 e3[3] = {(u32)__mul24(d0, d0), (u32)__mul24(d1, d1), (u32)__mul24(d2, d2)};
-                        const u32 e1 = (u32)__mul24(d3, d3);
+                        // (rec - px)^2 as floats: byte -> float conversions, a subtract and a multiply are exact on these
+                        // integers (|d| <= 255, d^2 < 2^24), so the squares are the numbers the integer form converts -- and
+                        // they are plain f32 instructions, which a second wave can issue alongside (SDWA and 24-bit
+                        // multiplies cannot)
+                        const float d0 = byteF(rec0, K) - x01.x, d1 = byteF(rec1, K) - x01.y, d2 = byteF(rec2, K) - x23.x, d3 = byteF(rec3, K) - x23.y;
+                        const float e3[3] = {d0 * d0, d1 * d1, d2 * d2};
+                        const float e1 = d3 * d3;
                         float er, ea;
                         if (uniformErr)
                         {
-                            er = (float)(int)(e3[0] + e3[1] + e3[2]);
-                            ea = (float)(int)e1;
+                            er = (e3[0] + e3[1]) + e3[2];
+                            ea = e1;
                         }
                         else
                         {
-                            er = (float)(int)e3[0] * rwSq[0];
-                            er = er + (float)(int)e3[1] * rwSq[1];
-                            er = er + (float)(int)e3[2] * rwSq[2];
-                            ea = (float)(int)e1 * rwSq[3];
+                            er = e3[0] * rwSq[0];
+                            er = er + e3[1] * rwSq[1];
+                            er = er + e3[2] * rwSq[2];
+                            ea = e1 * rwSq[3];
                         }
                         if (K == 0)
                         {
