@@ -886,9 +886,9 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                         for (int i = 0; i < 3; i++)
                         {
                             const float e = e3[i];
-                            if (e < pixelError)
-                                sel = (u32)(i + 1);
-                            pixelError = sseMin(e, pixelError);
+                            const bool lt = e < pixelError; // equal values are equal bits (sums of squares): one comparison serves both
+                            sel = lt ? (u32)(i + 1) : sel;
+                            pixelError = lt ? e : pixelError;
                         }
                         error = error + pixelError;
                         selectors |= sel << (px * 2);
@@ -1109,9 +1109,10 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                             e0 = E(c0[0], c0[1], c0[2], S.pix[px], S.pw[px]);
                             e1 = E(c1[0], c1[1], c1[2], S.pix[px], S.pw[px]);
                         }
-                        if (e1 < e0)
+                        const bool lt = e1 < e0;
+                        if (lt)
                             signBits |= 1u << px;
-                        S.u.h.err[r][px] = sseMin(e0, e1);
+                        S.u.h.err[r][px] = lt ? e1 : e0;
                     }
                     S.u.h.sign[r] = (unsigned short)signBits;
                 }
@@ -1140,8 +1141,8 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                     for (int px = 0; px < 16; px++)
                     {
                         const float e0 = S.u.h.err[ci0][px], e1 = S.u.h.err[ci1][px];
-                        totalError = totalError + sseMin(e0, e1);
                         const bool oneBetter = e1 < e0;
+                        totalError = totalError + (oneBetter ? e1 : e0);
                         if (oneBetter)
                             sectorBits |= 1u << px;
                         signBits |= (1u << px) & (oneBetter ? s1 : s0);
@@ -1432,18 +1433,10 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                             e23 = e23 + dd * dd;
                             dd = mw23[2] - p2;
                             e23 = e23 + dd * dd;
-                            const float e4[4] = {e01.x, e01.y, e23.x, e23.y};
-                            float be = FLT_MAX;
-                            u32 bs = 0;
-#pragma unroll
-                            for (int s = 0; s < 4; s++)
-                            {
-                                if (e4[s] < be)
-                                    bs = (u32)s;
-                                be = sseMin(e4[s], be);
-                            }
+                            // only the candidate's error is kept (the winners' selectors are recomputed), and the four values are
+                            // sums of squares -- no NaN, no -0 -- so the SSE minimum chain is three v_min_f32
+                            const float be = __builtin_fminf(__builtin_fminf(__builtin_fminf(e01.x, e01.y), e23.x), e23.y);
                             totalError = totalError + be;
-                            selectors |= bs << (spx * 2);
                             if (__ballot(totalError < (sector == 0 ? flipBest : limit1)) == 0)
                                 break;
                         }
