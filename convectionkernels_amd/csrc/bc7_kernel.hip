@@ -760,13 +760,20 @@ __device__ __forceinline__ u32 rotatePixel(u32 pk, int rotation)
 
 __device__ __forceinline__ void levelTable(int e0, int e1, bool threeBit, u32 &tabLo, u32 &tabHi);
 
+struct DualInv
+{
+    const u32 *words; // s_raw + block index
+    int rowSq[4], rowVs[4];
+    u32 minMax;
+};
+
 // One (mode, rotation, index selector) configuration of the dual-plane modes 4/5
 // (reference BC67.cpp:1725-1940): sub-lane c runs seed point c.  `pix` is already rotated so
 // that byte 3 is the separately coded channel; w/wSq/rcpW are rotated the same way.
 template <bool FAST>
 // `sP`: the block's 16 pixels in LDS, already rotated (byte 3 = the separately coded channel), read four at a time in every
 // round instead of living in 16 registers; `minMax` = min | max << 8 of the separately coded channel.
-__device__ __forceinline__ void evalDual(const u32 *sP, u32 minMax, int mode, int indexSelector, const Unfinished &uRGB,
+__device__ __forceinline__ void evalDual(const u32 *sP, const DualInv &inv, int mode, int indexSelector, const Unfinished &uRGB,
                                          int numTweak, const float (&rw)[4], const float (&rwSq)[4],
                                          const float (&rrcpW)[4], u32 flags, const CvttDeviceTables *__restrict__ T,
                                          int numRefine, int lane, ShapeBest &bestRGB, ShapeBest &bestA)
@@ -792,6 +799,7 @@ __device__ __forceinline__ void evalDual(const u32 *sP, u32 minMax, int mode, in
     bestRGB.ep0 = bestRGB.ep1 = bestRGB.idxLo = bestRGB.idxHi = 0;
     bestA.ep0 = bestA.ep1 = bestA.idxLo = bestA.idxHi = 0;
 
+    const u32 minMax = inv.minMax;
     const int alphaMin = (int)(minMax & 0xffu), alphaMax = (int)(minMax >> 8);
 
     const int tweak = c;
@@ -879,7 +887,7 @@ __device__ __forceinline__ void evalDual(const u32 *sP, u32 minMax, int mode, in
 
             u32 err[4] = {0, 0, 0, 0};
             float slowRGB = 0.0f, slowA = 0.0f;
-            v2f tv01 = {0.0f, 0.0f}, tv23 = {0.0f, 0.0f}, vs01 = {0.0f, 0.0f}, vs23 = {0.0f, 0.0f};
+            v2f tv01 = {0.0f, 0.0f}, tv23 = {0.0f, 0.0f};
             v2f tt2 = {0.0f, 0.0f}, ts2 = {0.0f, 0.0f}; // {RGB plane, alpha plane}
             u32 rgbLo = 0, rgbHi = 0, aLo = 0, aHi = 0;
 
@@ -978,8 +986,6 @@ __device__ __forceinline__ void evalDual(const u32 *sP, u32 minMax, int mode, in
                     const v2f v01 = x01 * w01, v23 = x23 * w23;
                     tv01 = tv01 + tt * v01;
                     tv23 = tv23 + t2 * v23;
-                    vs01 = vs01 + v01;
-                    vs23 = vs23 + v23;
                     tt2 = tt2 + t2 * t2;
                     ts2 = ts2 + t2;
                 }
@@ -1053,8 +1059,11 @@ __device__ __forceinline__ void evalDual(const u32 *sP, u32 minMax, int mode, in
             if (!last)
             {
                 // EndpointRefiner<3> / <1>::GetRefinedEndpointsLDR, 16 contributions each
+                // (the sums of the pre-weighted pixels do not depend on the indexes: taken once per block, see evalDualFast)
+                const float vs[4] = {__builtin_bit_cast(float, inv.words[inv.rowVs[0]]), __builtin_bit_cast(float, inv.words[inv.rowVs[1]]),
+                                     __builtin_bit_cast(float, inv.words[inv.rowVs[2]]), __builtin_bit_cast(float, inv.words[inv.rowVs[3]])};
                 {
-                    const float tv[4] = {tv01.x, tv01.y, tv23.x, tv23.y}, vs[4] = {vs01.x, vs01.y, vs23.x, vs23.y};
+                    const float tv[4] = {tv01.x, tv01.y, tv23.x, tv23.y};
                     const float ttRGB = tt2.x, tsRGB = ts2.x;
                     float adenom = (ttRGB * 16.0f - tsRGB * tsRGB) * wRcp16;
                     const bool z = (adenom == 0.0f);
@@ -1075,7 +1084,7 @@ __device__ __forceinline__ void evalDual(const u32 *sP, u32 minMax, int mode, in
                     }
                 }
                 {
-                    const float tv[4] = {tv01.x, tv01.y, tv23.x, tv23.y}, vs[4] = {vs01.x, vs01.y, vs23.x, vs23.y};
+                    const float tv[4] = {tv01.x, tv01.y, tv23.x, tv23.y};
                     const float ttA = tt2.y, tsA = ts2.y;
                     float adenom = (ttA * 16.0f - tsA * tsA) * wRcp16;
                     const bool z = (adenom == 0.0f);
@@ -1142,12 +1151,6 @@ __device__ __forceinline__ u32 nibblesOf(u32 b4)
 // They wait in LDS (rows of 16 words, one word per block of the wave) and are read where they are used -- the pixel loop of
 // the search is the place with the fewest registers to spare: `rowSq[ch]` / `rowVs[ch]` = word offset of channel position
 // ch's sum(px^2) / refiner sum, `minMax` = min | max << 8 of the separately coded channel.
-struct DualInv
-{
-    const u32 *words; // s_raw + block index
-    int rowSq[4], rowVs[4];
-    u32 minMax;
-};
 // `sP`: the block's pixels in LDS, channel-major and already in rotated channel order: four words (channel positions 0..3)
 // per group g of four pixels, read again in every round (one 128-bit load per group) instead of living in 16 registers.
 __device__ __forceinline__ void evalDualFast(const u32 *sP, const DualInv &inv, int mode, int indexSelector, const Unfinished &uRGB,
@@ -2610,7 +2613,6 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 }
             }
             ShapeBest b, bA;
-            if (FAST)
             {
                 DualInv inv;
                 const int sepCh = (rotation == 0) ? 3 : rotation - 1; // the original channel that is coded on its own
@@ -2625,11 +2627,11 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 inv.rowSq[3] = (1 + sepCh) * 16;
                 inv.rowVs[3] = (13 + sepCh) * 16;
                 inv.minMax = s_raw[(5 + sepCh) * 16 + (lane >> 2)];
-                evalDualFast(s_P, inv, mode, indexSelector, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
+                if (FAST)
+                    evalDualFast(s_P, inv, mode, indexSelector, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
+                else
+                    evalDual<FAST>(s_P, inv, mode, indexSelector, u, numTweak, rw, rwSq, rrcpW, A.flags, T, numRefine, lane, b, bA);
             }
-            else
-                evalDual<FAST>(s_P, s_raw[(5 + ((rotation == 0) ? 3 : rotation - 1)) * 16 + (lane >> 2)], mode, indexSelector, u, numTweak, rw, rwSq, rrcpW,
-                               A.flags, T, numRefine, lane, b, bA);
 
 #ifdef CVTT_BC7_DEBUG
             if (blockIdx.x * 16u + (u32)(lane >> 2) == g_bc7DbgBlock && c == 0)
