@@ -961,20 +961,22 @@ __device__ __forceinline__ void evalDual(const u32 *sP, const DualInv &inv, int 
                         }
                         else
                         {
+                            // (the winner is tracked as an integer and converted once; equal errors are equal bits, so the
+                            // comparison that moves the index also serves the minimum)
                             const bool bR = er < eRGB, bA = ea < eA;
-                            eRGB = sseMin(er, eRGB);
-                            eA = sseMin(ea, eA);
-                            if (bR) fRGB = (float)candRGB;
-                            if (bA) fA = (float)candA;
+                            eRGB = bR ? er : eRGB;
+                            eA = bA ? ea : eA;
+                            iRGB = bR ? candRGB : iRGB;
+                            iA = bA ? candA : iA;
                         }
                     };
                     probeOne(std::integral_constant<int, 0>{}, iRGB, iA);
                     probeOne(std::integral_constant<int, 1>{}, c1R, c1A);
                     probeOne(std::integral_constant<int, 2>{}, c2R, c2A);
+                    fRGB = (float)iRGB;
+                    fA = (float)iA;
                     slowRGB = slowRGB + eRGB;
                     slowA = slowA + eA;
-                    iRGB = (int)fRGB;
-                    iA = (int)fA;
                 }
 
                 if (!last)
