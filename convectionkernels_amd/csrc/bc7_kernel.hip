@@ -452,12 +452,13 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, u64 list, int
                 {
                     // slow indexing: also probe index-1 / index+1 (reference BC67.cpp:1367-1386)
                     float bestE = 0.0f;
+                    const int index0 = index;
 #pragma unroll
                     for (int probe = 0; probe < 3; probe++)
                     {
-                        int cand = index;
-                        if (probe == 1) cand = (index > 1 ? index : 1) - 1;
-                        if (probe == 2) cand = (index + 1 < range - 1) ? index + 1 : range - 1;
+                        int cand = index0;
+                        if (probe == 1) cand = (index0 > 1 ? index0 : 1) - 1;
+                        if (probe == 2) cand = (index0 + 1 < range - 1) ? index0 + 1 : range - 1;
                         const int wgt = mad24(weightRcp, cand, 256) >> 9;
                         // the reconstructed channel is byte 1 of w * delta4 + base4; its difference to the pixel and the
                         // square are taken as floats (exact on these integers, see evalDual: plain f32 instructions)
@@ -483,15 +484,15 @@ __device__ __forceinline__ void evalChain(const u32 *lp, u32 mask, u64 list, int
                             bestE = e;
                         else
                         {
-                            // both alternatives derive from the initial index (BC67.cpp:1367-1386)
+                            // both alternatives derive from the initial index (BC67.cpp:1367-1386); the winner is tracked as an
+                            // integer and converted once, and the comparison that moves it also serves the minimum
                             const bool better = e < bestE;
-                            bestE = sseMin(bestE, e);
-                            if (better)
-                                fidx = (float)cand;
+                            bestE = better ? e : bestE;
+                            index = better ? cand : index;
                         }
                     }
                     slowErr = slowErr + bestE;
-                    index = (int)fidx;
+                    fidx = (float)index;
                 }
 
                 if (!last)
