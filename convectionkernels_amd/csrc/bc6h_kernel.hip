@@ -21,6 +21,18 @@
 //   * the "meta round" results of a partition (errors, endpoints of the subset being searched)
 //     live in LDS, [entry][lane] so every access is conflict free; indexes and subset 0's
 //     endpoints go to an L2-resident scratch that only the commit path reads back.
+//
+// What is NOT searched ("Round 3"): nine of the ten two-subset modes delta-code three of their four end
+// points, the reference's commit loop skips a (round, round, mode) triple whose deltas do not fit with a `continue` that
+// changes no state (BC67.cpp:2954-2955), and whether a triple fits depends on the rounds' quantised end points alone --
+// known before a round looks at a pixel.  So
+//   * a round whose end points fit no mode in any lane of the wave runs without errors (`needError`), and not at all in the
+//     last refine pass; a partition without a usable subset-0 round skips subset 1 and the commit loop (`usable0`);
+//   * precisions of 8 bits and more are searched lazily (`lazy`): chains of both subsets without errors, then the exact set of
+//     round pairs some lane could commit, then a replay of just those rounds with errors (a separate block of code);
+//   * the PCA seeds of the 64 (partition, subset) pairs are computed by the first precision and read back by the others.
+// On content without structure that is two thirds of the reference's work; the output is bit-identical because every
+// skipped piece is one the reference computes and then cannot use.
 #include "cvtt_kernel_common.h"
 #include <hip/hip_fp16.h>
 #include <type_traits>
@@ -61,10 +73,9 @@ constexpr int kScrEpq0 = 0, kScrIdx = 36, kScrPca = 84, kScratchDwords = 84 + 32
 // on the precision, so the first partitioned precision files them and the other five read them back (147 KB per wave, written
 // once and read five times in coalesced 256-byte lines: about 0.1 TB/s at 8 Mblocks/s) instead of running three passes over
 // the pixels and eight power iterations with IEEE divisions again
-// Waves per SIMD the register allocator must leave room for.  4 (128 VGPRs, 48 dwords of spill) instead of 3 (149, no
-// spill) measures +3.5 %: the shim feeds the kernel 2^18 blocks = 4 096 waves = 4 per SIMD at a time, which 3 slots take
-// in two rounds (3 + 1), and gfx950 overlaps the plain f32 instructions of an EVEN number of resident waves
-// (profiles/r02/valu_order.txt).
+// Waves per SIMD the register allocator must leave room for.  4 (128 VGPRs, spills) instead of 3 (150-167, none) measured
+// +3.5 % in round 2 and +9 % with round 3's code (127.5 against 139.5 ms at 4096^2): gfx950 overlaps the plain f32
+// instructions of an EVEN number of resident waves (profiles/r02/valu_order.txt).
 #ifndef CVTT_BC6H_WAVES
 #define CVTT_BC6H_WAVES 4
 #endif
