@@ -2028,6 +2028,13 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
     for (int tableIndex = 0; tableIndex < 16; tableIndex++)
     {
         const int pos[4] = {T->eacPositive[tableIndex][0], T->eacPositive[tableIndex][1], T->eacPositive[tableIndex][2], T->eacPositive[tableIndex][3]};
+        // the table's row of the rounding table (13 entries of 2 bits) and its four positive modifiers as two wave-uniform
+        // words: a pixel's lookups are bit-field extracts instead of a per-lane byte load and a select chain
+        u32 roundBits = 0;
+        for (int i = 0; i < 13; i++)
+            roundBits |= (u32)T->eacRounding[tableIndex][i] << (2 * i);
+        roundBits = (u32)__builtin_amdgcn_readfirstlane((int)roundBits);
+        const u32 posWord = (u32)__builtin_amdgcn_readfirstlane(pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24));
         for (int r = 0; r < 10; r++)
         {
             const int subrange = r % 3, mainRange = r / 3;
@@ -2089,8 +2096,8 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
                     if (rem < 0) li--;
                     if (rem >= multiplier) li++;
                     li = li >= 13 ? 12 : li;
-                    const int index = T->eacRounding[tableIndex][li];
-                    const int pOff = index == 0 ? pos[0] : (index == 1 ? pos[1] : (index == 2 ? pos[2] : pos[3]));
+                    const int index = (int)((roundBits >> (2 * li)) & 3u);
+                    const int pOff = (int)((posWord >> (8 * index)) & 0xffu);
                     const int sign = refl2 < 0 ? -1 : 0;
                     const int quantizedOffset = (pOff ^ sign) * multiplier;
                     int q = baseAlpha + quantizedOffset;
