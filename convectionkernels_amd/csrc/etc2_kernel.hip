@@ -367,6 +367,26 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
     const EtcErr E = {(A.flags & CVTTMI_FLAG_UNIFORM) != 0, A.rw, A.gw, A.bw, FAKE};
     const bool fakeAccurate = (A.flags & CVTTMI_FLAG_ETC_FAKE_BT709_ACCURATE) != 0;
     constexpr bool ETC1 = MODE == 1, PUNCH = MODE == 2;
+    // The eight tables' small and large ETC1 modifiers and T / H distances as bytes of wave-uniform words: a candidate's table
+    // is a per-lane value, and looking it up in memory was up to four loads (and their latency) at the head of every pass of
+    // 64 candidates; one v_perm_b32 picks the byte instead.
+    u32 mSLo = 0, mSHi = 0, mLLo = 0, mLHi = 0, thLo = 0, thHi = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+    {
+        mSLo |= (u32)T->etc1Modifiers[t][2] << (8 * t);
+        mSHi |= (u32)T->etc1Modifiers[4 + t][2] << (8 * t);
+        mLLo |= (u32)T->etc1Modifiers[t][3] << (8 * t);
+        mLHi |= (u32)T->etc1Modifiers[4 + t][3] << (8 * t);
+        thLo |= (u32)T->thDistance[t] << (8 * t);
+        thHi |= (u32)T->thDistance[4 + t] << (8 * t);
+    }
+    mSLo = (u32)__builtin_amdgcn_readfirstlane((int)mSLo); mSHi = (u32)__builtin_amdgcn_readfirstlane((int)mSHi);
+    mLLo = (u32)__builtin_amdgcn_readfirstlane((int)mLLo); mLHi = (u32)__builtin_amdgcn_readfirstlane((int)mLHi);
+    thLo = (u32)__builtin_amdgcn_readfirstlane((int)thLo); thHi = (u32)__builtin_amdgcn_readfirstlane((int)thHi);
+    auto smallMod = [&](int table) -> int { return (int)__builtin_amdgcn_perm(mSHi, mSLo, (u32)table | 0x0c0c0c00u); };
+    auto largeMod = [&](int table) -> int { return (int)__builtin_amdgcn_perm(mLHi, mLLo, (u32)table | 0x0c0c0c00u); };
+    auto thDist = [&](int table) -> int { return (int)__builtin_amdgcn_perm(thHi, thLo, (u32)table | 0x0c0c0c00u); };
 
     // ---- load: pixel px by lane px.  Punch-through: pixels whose alpha is below the threshold are transparent and
     // count as black from here on (ETC.cpp:1670-1720) ----
@@ -774,7 +794,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
             for (int id = lane; id < 8 * span; id += 64)
             {
                 const int tbl = id / span, kk = id - tbl * span;
-                const int modifierAddend = (int)(short)((kk - numLine) * (T->thDistance[tbl] * 2));
+                const int modifierAddend = (int)(short)((kk - numLine) * (thDist(tbl) * 2));
                 int packed = 0, q3[3], targets[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++)
@@ -850,7 +870,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                     if (zeroSlot && exact && !((presentMask >> table) & 1u))
                         continue;
                     const int packed = zeroSlot ? 0 : (int)S.tColors[table][ci];
-                    const int modifier = T->thDistance[table];
+                    const int modifier = thDist(table);
                     int lc[3][3];
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++)
@@ -934,7 +954,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                 int lineTotalM[3];
                 lineTotalsJ(~isoM & 0xffffu, lineTotalM);
                 const int numLineM = 16 - __popc(isoM);
-                const int modifierOffset = T->thDistance[tbl] * 2;
+                const int modifierOffset = thDist(tbl) * 2;
                 const int lineDivisor = numLineM * 34;
                 const int lineAddend = (numLineM << 4) | numLineM;
                 int n = 0, last = -1;
@@ -1028,7 +1048,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                 const int kk = sector ? j - (2 * counts[0] + 1) : j;
                 const int cnt = sector ? counts[1] : counts[0];
                 const int k = kk - cnt;
-                const int modifier = T->thDistance[table];
+                const int modifier = thDist(table);
                 int q[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++)
@@ -1081,7 +1101,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                     const int table = isB ? tabB : tabA;
                     const int li = isB ? r - rowsA : r;
                     const int n0 = isB ? nB0 : nA0;
-                    const int modifier = T->thDistance[table];
+                    const int modifier = thDist(table);
                     const int packed = li < n0 ? S.dColors[table * 2][li] : S.dColors[table * 2 + 1][li - n0];
                     int c0[3], c1[3];
 #pragma unroll
@@ -1302,7 +1322,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                     const u32 sectorMask = flip == 0 ? (sector ? 0xccccu : 0x3333u) : (sector ? 0xff00u : 0x00ffu);
                     const int count = __popc(transMask & sectorMask);
                     const int denominator = (count > 1 ? count : 1) << 8, addend = count << 7, cumulativeMax = 255 * count;
-                    const int modifier = T->etc1Modifiers[table][3];
+                    const int modifier = largeMod(table);
                     for (int om = -count; om <= count; om++)
                     {
                         const int off = (int)(short)(om * modifier);
@@ -1380,14 +1400,14 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
 #pragma unroll
                         for (int s = 0; s < 4; s++)
                         {
-                            const int v = u + T->etc1Modifiers[table][s];
+                            const int v = u + (s == 0 ? -largeMod(table) : s == 1 ? -smallMod(table) : s == 2 ? smallMod(table) : largeMod(table));
                             modified[s][ch] = v < 0 ? 0 : (v > 255 ? 255 : v);
                         }
                     }
                     if (punch)
                     {
                         // TestHalfBlockPunchthrough, ETC.cpp:151-217: colour - m, colour, colour + m
-                        const int m = T->etc1Modifiers[table][3];
+                        const int m = largeMod(table);
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++)
                         {
@@ -1628,10 +1648,10 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                     {
                         const int q = (int)((colr >> (ch * 5)) & 31u);
                         const int u = bD == 1 ? ((q << 3) | (q >> 2)) : ((q << 4) | q);
-                        int v = u + T->etc1Modifiers[table][sel];
+                        int v = u + (sel == 0 ? -largeMod(table) : sel == 1 ? -smallMod(table) : sel == 2 ? smallMod(table) : largeMod(table));
                         if (punch)
                         {
-                            const int md = T->etc1Modifiers[table][3];
+                            const int md = largeMod(table);
                             v = sel == 0 ? (u > md ? u : md) - md : (sel == 1 ? u : u + md);
                         }
                         m[ch] = v < 0 ? 0 : (v > 255 ? 255 : v);
@@ -1770,7 +1790,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
             for (int half = 0; half < 2; half++)
             {
                 const int table = half * 4 + (lane >> 4), px = lane & 15;
-                const int modifier = T->thDistance[table];
+                const int modifier = thDist(table);
                 int hq[3], hc[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++)
@@ -1800,7 +1820,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                 const int numLineM = __popc(lineM);
                 const int clusterMaxLine = __builtin_amdgcn_readfirstlane(groupMax(numLineM));
                 const bool mine = jb == own;
-                const int modifierOffset = T->thDistance[tbl] * 2;
+                const int modifierOffset = thDist(tbl) * 2;
                 const int lineDivisor = numLineM * 34;
                 const int lineAddend = (numLineM << 4) | numLineM;
                 int n = 0, last = -1;
@@ -1863,7 +1883,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                 {
                     int table;
                     const int packed = candidateOf(id, table);
-                    const int modifier = T->thDistance[table];
+                    const int modifier = thDist(table);
                     int lc[2][3];
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++)
@@ -1903,7 +1923,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                 const bool useH = __shfl((int)candH, wId & 63) != 0;
                 int table;
                 const int packed = candidateOf(wId, table);
-                const int modifier = T->thDistance[table];
+                const int modifier = thDist(table);
                 const int packedH2 = (int)S.u.h.color[0][table];
                 int lc[2][3];
 #pragma unroll
