@@ -1384,13 +1384,17 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                 const int id = base + lane;
                 if (id < prefix[16])
                 {
-                    int slot = 0;
+                    // (list and first entry from the same comparisons: prefix[slot] afterwards is a second select chain)
+                    int slot = 0, start = 0;
 #pragma unroll
                     for (int i = 1; i < 16; i++)
-                        if (id >= prefix[i])
-                            slot = i;
+                    {
+                        const bool ge = id >= prefix[i];
+                        slot = ge ? i : slot;
+                        start = ge ? prefix[i] : start;
+                    }
                     const int sector = slot >> 3, table = slot & 7;
-                    const int packed = S.dColors[slot][id - prefix[slot]];
+                    const int packed = S.dColors[slot][id - start];
                     int modified[4][3];
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++)
@@ -1436,8 +1440,14 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                             mw01[ch] = pk2{(float)modified[0][ch] * w, (float)modified[1][ch] * w};
                             mw23[ch] = pk2{(float)modified[2][ch] * w, (float)modified[3][ch] * w};
                         }
-                        for (int spx = 0; spx < 8; spx++)
+                        // two pixels per trip (the pair of a half-block row for flip 0, neighbours for flip 1): the loop is not
+                        // unrolled because of its exit, and per pixel its bookkeeping was a fifth of the body
+                        for (int sp2 = 0; sp2 < 4; sp2++)
                         {
+#pragma unroll
+                            for (int h = 0; h < 2; h++)
+                            {
+                            const int spx = sp2 * 2 + h;
                             const int px = flip == 0 ? ((spx >> 1) * 4 + (spx & 1) + sector * 2) : (spx + sector * 8);
                             const float *pw = S.pw[px];
                             const pk2 p0 = pk2{pw[0], pw[0]}, p1 = pk2{pw[1], pw[1]}, p2 = pk2{pw[2], pw[2]};
@@ -1457,6 +1467,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                             // sums of squares -- no NaN, no -0 -- so the SSE minimum chain is three v_min_f32
                             const float be = __builtin_fminf(__builtin_fminf(__builtin_fminf(e01.x, e01.y), e23.x), e23.y);
                             totalError = totalError + be;
+                            }
                             if (__ballot(totalError < (sector == 0 ? flipBest : limit1)) == 0)
                                 break;
                         }
