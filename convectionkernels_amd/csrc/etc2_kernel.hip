@@ -858,14 +858,17 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                 if (e < prefix[8] + 8)
                 {
                     const bool zeroSlot = e >= prefix[8];
-                    int table = 0;
+                    int table = 0, start = 0;
 #pragma unroll
                     for (int t = 1; t < 8; t++)
-                        if (e >= prefix[t])
-                            table = t;
+                    {
+                        const bool ge = e >= prefix[t];
+                        table = ge ? t : table;
+                        start = ge ? prefix[t] : start;
+                    }
                     if (zeroSlot)
                         table = e - prefix[8];
-                    const int ci = zeroSlot ? S.tCount[table] : e - prefix[table];
+                    const int ci = zeroSlot ? S.tCount[table] : e - start;
                     const int id = (table << 8) | ci;
                     if (zeroSlot && exact && !((presentMask >> table) & 1u))
                         continue;
