@@ -19,6 +19,7 @@
 // from the group's 512 bytes of pixels, lane l standing in for group member l & 7: no workgroup barrier.
 // Alpha kernel: integer-only and lane independent, one lane per block.
 #include "cvtt_kernel_common.h"
+#include <type_traits>
 
 namespace
 {
@@ -888,34 +889,46 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                     float error = 0.0f;
                     EtcErr::f32x2 lw01[3];
                     E.weigh2(lw01, lc[0], lc[1]);
-                    for (int px = 0; px < 16; px++)
-                    {
-                        float pixelError = S.isoErr[px];
-                        u32 sel = 0;
-                        float e3[3];
-                        if (!E.uniform)
+                    // the metric is a run-time flag: decided once per pass, not per pixel (as a test inside the loop it was four
+                    // branches per pixel and kept the sixteen trips from being unrolled)
+                    auto tPixels = [&](auto uniTag) {
+                        constexpr bool UNI = decltype(uniTag)::value;
+                        const EtcErr EE = {UNI, E.rw, E.gw, E.bw, E.fake};
+                        EtcWaveShared &S = shared1; // (static storage: named again here, a generic lambda does not capture the outer reference)
+#pragma unroll 2
+                        for (int px = 0; px < 16; px++)
                         {
-                            const EtcErr::f32x2 e01 = E.err2(lw01, S.pw[px]);
-                            e3[0] = e01.x;
-                            e3[1] = e01.y;
-                        }
-                        else
-                        {
-                            e3[0] = E.wu(lc[0][0], lc[0][1], lc[0][2], S.pix[px], S.pw[px]);
-                            e3[1] = E.wu(lc[1][0], lc[1][1], lc[1][2], S.pix[px], S.pw[px]);
-                        }
-                        e3[2] = E.wu(lc[2][0], lc[2][1], lc[2][2], S.pix[px], S.pw[px]); // sic: never the fake metric
+                            float pixelError = S.isoErr[px];
+                            u32 sel = 0;
+                            float e3[3];
+                            if (!UNI)
+                            {
+                                const EtcErr::f32x2 e01 = EE.err2(lw01, S.pw[px]);
+                                e3[0] = e01.x;
+                                e3[1] = e01.y;
+                            }
+                            else
+                            {
+                                e3[0] = EE.wu(lc[0][0], lc[0][1], lc[0][2], S.pix[px], S.pw[px]);
+                                e3[1] = EE.wu(lc[1][0], lc[1][1], lc[1][2], S.pix[px], S.pw[px]);
+                            }
+                            e3[2] = EE.wu(lc[2][0], lc[2][1], lc[2][2], S.pix[px], S.pw[px]); // sic: never the fake metric
 #pragma unroll
-                        for (int i = 0; i < 3; i++)
-                        {
-                            const float e = e3[i];
-                            const bool lt = e < pixelError; // equal values are equal bits (sums of squares): one comparison serves both
-                            sel = lt ? (u32)(i + 1) : sel;
-                            pixelError = lt ? e : pixelError;
+                            for (int i = 0; i < 3; i++)
+                            {
+                                const float e = e3[i];
+                                const bool lt = e < pixelError; // equal values are equal bits (sums of squares): one comparison serves both
+                                sel = lt ? (u32)(i + 1) : sel;
+                                pixelError = lt ? e : pixelError;
+                            }
+                            error = error + pixelError;
+                            selectors |= sel << (px * 2);
                         }
-                        error = error + pixelError;
-                        selectors |= sel << (px * 2);
-                    }
+                    };
+                    if (E.uniform)
+                        tPixels(std::true_type{});
+                    else
+                        tPixels(std::false_type{});
                     if (zeroSlot && !exact)
                     {
                         if (error < zErr || (error == zErr && id < zId))
