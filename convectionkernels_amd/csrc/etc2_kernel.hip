@@ -1131,25 +1131,36 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                     u32 signBits = 0;
                     EtcErr::f32x2 cw[3];
                     E.weigh2(cw, c0, c1);
-                    for (int px = 0; px < 16; px++)
-                    {
-                        float e0, e1;
-                        if (!FAKE && !E.uniform)
+                    // (the metric flag is decided once per pass, as in the T modes)
+                    auto hPixels = [&](auto uniTag) {
+                        constexpr bool UNI = decltype(uniTag)::value;
+                        const EtcErr EE = {UNI, E.rw, E.gw, E.bw, E.fake};
+                        EtcWaveShared &S = shared1;
+#pragma unroll 2
+                        for (int px = 0; px < 16; px++)
                         {
-                            const EtcErr::f32x2 e01 = E.err2(cw, S.pw[px]);
-                            e0 = e01.x;
-                            e1 = e01.y;
+                            float e0, e1;
+                            if (!FAKE && !UNI)
+                            {
+                                const EtcErr::f32x2 e01 = EE.err2(cw, S.pw[px]);
+                                e0 = e01.x;
+                                e1 = e01.y;
+                            }
+                            else
+                            {
+                                e0 = EE(c0[0], c0[1], c0[2], S.pix[px], S.pw[px]);
+                                e1 = EE(c1[0], c1[1], c1[2], S.pix[px], S.pw[px]);
+                            }
+                            const bool lt = e1 < e0;
+                            if (lt)
+                                signBits |= 1u << px;
+                            S.u.h.err[r][px] = lt ? e1 : e0;
                         }
-                        else
-                        {
-                            e0 = E(c0[0], c0[1], c0[2], S.pix[px], S.pw[px]);
-                            e1 = E(c1[0], c1[1], c1[2], S.pix[px], S.pw[px]);
-                        }
-                        const bool lt = e1 < e0;
-                        if (lt)
-                            signBits |= 1u << px;
-                        S.u.h.err[r][px] = lt ? e1 : e0;
-                    }
+                    };
+                    if (E.uniform)
+                        hPixels(std::true_type{});
+                    else
+                        hPixels(std::false_type{});
                     S.u.h.sign[r] = (unsigned short)signBits;
                 }
             }
