@@ -227,7 +227,6 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
     u32 *const scr = scratch + (size_t)blockIdx.x * (kScratchDwords * 64) + lane; // entry e at scr[e * 64]
     const u32 blockIndex = blockIdx.x * 64u + (u32)lane;
     const bool valid = blockIndex < A.numBlocks;
-    const bool uniformErr = (A.flags & CVTTMI_FLAG_UNIFORM) != 0;
 
     PROF_DECL
     // ---- load + clamp to the "2CL" domain (BC67.cpp:2691-2715) ----
@@ -734,7 +733,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                                 const float d = twosCLHalfToFloat<SIGNED>(rec) - lf[ch];
                                                 sq = d * d;
                                             }
-                                            err = uniformErr ? (err + sq) : (err + sq * A.wSq[ch]);
+                                            err = err + sq * A.wSq[ch]; // (Flags::Uniform: the weights are 1.0 and the product is exact, no second form needed)
                                         }
                                         subsetError = subsetError + err;
                                         }
@@ -983,7 +982,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     const float d = twosCLHalfToFloat<SIGNED>(rec) - lf[ch];
                                     sq = d * d;
                                 }
-                                err = uniformErr ? (err + sq) : (err + sq * A.wSq[ch]);
+                                err = err + sq * A.wSq[ch]; // (Flags::Uniform: the weights are 1.0 and the product is exact, no second form needed)
                             }
                             subsetError = subsetError + err;
                         }
