@@ -1246,9 +1246,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
             // half-block membership: flip 0 = left/right 2x4 columns, flip 1 = top/bottom (g_flipTables, ETC.cpp:47-57)
             // pixel list of (flip, sector): computed on the fly
             // ---- base colours of the cluster fit (ETC.cpp:2690-2760): all 2 x 624 (sector, table, offset) candidates in
-            // parallel, one per lane and pass, parked in the (still unused) attempt-error area; the order-dependent
-            // removal of consecutive duplicates follows, one lane per (sector, table) ----
-            unsigned short *const rawColors = reinterpret_cast<unsigned short *>(&S.u.a.err[0][0]); // [16][82]
+            // parallel, with the order-dependent removal of consecutive duplicates folded in ----
             if (!punch)
             {
                 int cum[2][3] = {{0, 0, 0}, {0, 0, 0}};
@@ -1264,64 +1262,101 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                         cum[1][ch] += inSector ? v : 0;
                     }
                 }
-                for (int id = lane; id < 2 * kMaxAttempts; id += 64)
+                // One pass over the 624 (table, offset) pairs, 64 per trip, both sectors per lane (they share table and offset).
+                // A colour stays iff it differs from its predecessor in its list (ETC.cpp:2762-2775): the predecessor is the
+                // neighbouring lane's colour (the last lane's of the previous trip for lane 0), so the kept colours are filed
+                // straight into their lists at ballot-prefix positions -- no raw array, no second pass of LDS round trips.  A trip
+                // covers at most two tables (the shortest list has 57 entries): `A` = the table of lane 0, `B` = the next one.
+                int cs[8];
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                    cs[t] = __builtin_amdgcn_readfirstlane((int)T->clusterStart[t]);
+                int keptA[2] = {0, 0}, prevLast[2] = {-1, -1}, curT = 0; // wave-uniform
+                int offNext = T->clusterOffsets[lane < kMaxAttempts ? lane : 0];
+                for (int base = 0; base < kMaxAttempts; base += 64)
                 {
-                    const int sector = id >= kMaxAttempts ? 1 : 0;
-                    const int f = id - sector * kMaxAttempts;
-                    int table = 0;
+                    const int f = base + lane;
+                    const bool in = f < kMaxAttempts;
+                    const int off = offNext;
+                    if (base + 64 < kMaxAttempts)
+                        offNext = T->clusterOffsets[f + 64 < kMaxAttempts ? f + 64 : 0];
+                    int table = 0, start = 0;
 #pragma unroll
                     for (int t = 1; t < 8; t++)
-                        if (f >= T->clusterStart[t])
-                            table = t;
-                    const int off = T->clusterOffsets[f];
-                    int packed = 0;
-                    if (FAKE)
                     {
-                        int offsetCumulative[3], q3[3];
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++)
-                        {
-                            const int cu = (int)(short)((sector ? cum[1][ch] : cum[0][ch]) + off);
-                            offsetCumulative[ch] = cu < 0 ? 0 : (cu > 2040 ? 2040 : cu);
-                        }
-                        resolveHalfFake(q3, offsetCumulative, d == 1, fakeAccurate, T);
-                        packed = q3[0] | (q3[1] << 5) | (q3[2] << 10);
+                        const bool ge = f >= cs[t];
+                        table = ge ? t : table;
+                        start = ge ? cs[t] : start;
                     }
-                    else
+                    const int oi = f - start;
+                    const int tLo = __builtin_amdgcn_readfirstlane(table);
+                    if (tLo != curT)
                     {
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++)
+                        // the previous table ended exactly at the end of the previous trip
+                        if (lane == 0)
                         {
-                            int cu = (int)(short)((sector ? cum[1][ch] : cum[0][ch]) + off);
-                            cu = cu < 0 ? 0 : (cu > 2040 ? 2040 : cu);
-                            const u32 q = d == 1 ? ((((u32)cu << 5) - (u32)cu + ((u32)cu >> 3) + 1024u) & 0xffffu) >> 11
-                                                 : ((((u32)cu << 5) - ((u32)cu << 1) + ((u32)cu >> 3) + 2048u) & 0xffffu) >> 12;
-                            packed |= (int)q << (ch * 5);
+                            S.dCount[curT] = keptA[0];
+                            S.dCount[8 + curT] = keptA[1];
                         }
+                        keptA[0] = keptA[1] = 0;
+                        curT = tLo;
                     }
-                    rawColors[(sector * 8 + table) * 82 + (f - T->clusterStart[table])] = (unsigned short)packed;
-                }
-                WAVE_SYNC();
-                // removal of consecutive duplicates (ETC.cpp:2762-2775): a colour stays iff it differs from its
-                // predecessor; positions by ballot prefix, 64 candidates of one (sector, table) list at a time
-                for (int slot = 0; slot < 16; slot++)
-                {
-                    const int numOffsets = T->clusterCount[slot & 7];
-                    int kept = 0;
-                    for (int c0 = 0; c0 < numOffsets; c0 += 64)
+                    const bool isA = table == tLo;
+                    const bool crossing = __ballot(in && !isA) != 0;
+#pragma unroll
+                    for (int sector = 0; sector < 2; sector++)
                     {
-                        const int oi = c0 + lane;
-                        const bool in = oi < numOffsets;
-                        const int cur = in ? (int)rawColors[slot * 82 + oi] : -1;
-                        const int prev = (in && oi > 0) ? (int)rawColors[slot * 82 + oi - 1] : -1;
-                        const bool keep = in && (oi == 0 || cur != prev);
-                        const u64 bal = __ballot(keep);
+                        int packed = 0;
+                        if (FAKE)
+                        {
+                            int offsetCumulative[3], q3[3];
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++)
+                            {
+                                const int cu = (int)(short)(cum[sector][ch] + off);
+                                offsetCumulative[ch] = cu < 0 ? 0 : (cu > 2040 ? 2040 : cu);
+                            }
+                            resolveHalfFake(q3, offsetCumulative, d == 1, fakeAccurate, T);
+                            packed = q3[0] | (q3[1] << 5) | (q3[2] << 10);
+                        }
+                        else
+                        {
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++)
+                            {
+                                int cu = (int)(short)(cum[sector][ch] + off);
+                                cu = cu < 0 ? 0 : (cu > 2040 ? 2040 : cu);
+                                const u32 q = d == 1 ? ((((u32)cu << 5) - (u32)cu + ((u32)cu >> 3) + 1024u) & 0xffffu) >> 11
+                                                     : ((((u32)cu << 5) - ((u32)cu << 1) + ((u32)cu >> 3) + 2048u) & 0xffffu) >> 12;
+                                packed |= (int)q << (ch * 5);
+                            }
+                        }
+                        int prevCol = __shfl_up(packed, 1);
+                        if (lane == 0)
+                            prevCol = prevLast[sector];
+                        const bool keep = in && (oi == 0 || packed != prevCol);
+                        const u64 balA = __ballot(keep && isA), balB = __ballot(keep && !isA);
+                        const u64 below = (1ull << lane) - 1ull;
+                        const int pos = isA ? keptA[sector] + __popcll(balA & below) : __popcll(balB & below);
                         if (keep)
-                            S.dColors[slot][kept + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)cur;
-                        kept += __popcll(bal);
+                            S.dColors[sector * 8 + table][pos] = (unsigned short)packed;
+                        if (crossing)
+                        {
+                            if (lane == 0)
+                                S.dCount[sector * 8 + tLo] = keptA[sector] + __popcll(balA);
+                            keptA[sector] = __popcll(balB);
+                        }
+                        else
+                            keptA[sector] += __popcll(balA);
+                        prevLast[sector] = __builtin_amdgcn_readlane(packed, 63);
                     }
-                    if (lane == 0)
-                        S.dCount[slot] = kept;
+                    if (crossing)
+                        curT = tLo + 1;
+                }
+                if (lane == 0)
+                {
+                    S.dCount[curT] = keptA[0];
+                    S.dCount[8 + curT] = keptA[1];
                 }
             }
             if (punch && lane < 16)
