@@ -1048,7 +1048,6 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
 
         float hBestErr = FLT_MAX; // best H candidate so far (only committed if it beats bestError)
         int hBestId = 0x7fffffff;
-        u32 hBestBits = 0;        // sectorBits | signBits << 16
         int hBestC0 = 0, hBestC1 = 0;
 
         // base colours of all eight tables and both sectors (ETC.cpp:691-737), one (table, sector, premultiplier) per lane
@@ -1128,7 +1127,6 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                         c0[ch] = u + modifier < 255 ? u + modifier : 255;
                         c1[ch] = u - modifier > 0 ? u - modifier : 0;
                     }
-                    u32 signBits = 0;
                     EtcErr::f32x2 cw[3];
                     E.weigh2(cw, c0, c1);
                     // (the metric flag is decided once per pass, as in the T modes)
@@ -1151,17 +1149,13 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                                 e0 = EE(c0[0], c0[1], c0[2], S.pix[px], S.pw[px]);
                                 e1 = EE(c1[0], c1[1], c1[2], S.pix[px], S.pw[px]);
                             }
-                            const bool lt = e1 < e0;
-                            if (lt)
-                                signBits |= 1u << px;
-                            S.u.h.err[r][px] = lt ? e1 : e0;
+                            S.u.h.err[r][px] = __builtin_fminf(e0, e1); // (which of the two it was is worked out again for the winning pair)
                         }
                     };
                     if (E.uniform)
                         hPixels(std::true_type{});
                     else
                         hPixels(std::false_type{});
-                    S.u.h.sign[r] = (unsigned short)signBits;
                 }
             }
             WAVE_SYNC();
@@ -1182,24 +1176,17 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                     const int i0 = k % n0;
                     const int i1 = (k / n0) < n1 - 1 ? (k / n0) : n1 - 1;
                     const int ci0 = rowBase + i0, ci1 = rowBase + n0 + i1;
-                    const u32 s0 = S.u.h.sign[ci0], s1 = S.u.h.sign[ci1];
+                    // only the pair's error: which colour and which sign every pixel takes is worked out again for the one pair
+                    // that wins (below), instead of being carried as two bit masks through every pixel of every pair
                     float totalError = 0.0f;
-                    u32 sectorBits = 0, signBits = 0;
+#pragma unroll
                     for (int px = 0; px < 16; px++)
-                    {
-                        const float e0 = S.u.h.err[ci0][px], e1 = S.u.h.err[ci1][px];
-                        const bool oneBetter = e1 < e0;
-                        totalError = totalError + (oneBetter ? e1 : e0);
-                        if (oneBetter)
-                            sectorBits |= 1u << px;
-                        signBits |= (1u << px) & (oneBetter ? s1 : s0);
-                    }
+                        totalError = totalError + __builtin_fminf(S.u.h.err[ci0][px], S.u.h.err[ci1][px]); // sums of squares: no NaN, no -0
                     const int id = table * 1024 + k;
                     if (totalError < hBestErr || (totalError == hBestErr && id < hBestId))
                     {
                         hBestErr = totalError;
                         hBestId = id;
-                        hBestBits = sectorBits | (signBits << 16);
                         hBestC0 = S.dColors[table * 2][i0];
                         hBestC1 = S.dColors[table * 2 + 1][i1];
                     }
@@ -1217,11 +1204,49 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
             const bool mine = (hBestId == wId) && (hBestErr == wErr);
             const u64 who = __ballot(mine);
             const int src = __ffsll((long long)who) - 1;
-            const u32 bits = __shfl(hBestBits, src);
             const int bc0 = __shfl(hBestC0, src), bc1 = __shfl(hBestC1, src);
             const int table = wId >> 10;
-            u32 sectorBits = bits & 0xffffu;
-            const u32 signBits = bits >> 16;
+            // the winner's sector and sign bits: lane px works out pixel px again (the operations of the colour rows above)
+            u32 sectorBits, signBits;
+            {
+                const int px = lane & 15;
+                const int modifier = thDist(table);
+                float rowErr[2];
+                bool rowSign[2];
+#pragma unroll
+                for (int w = 0; w < 2; w++)
+                {
+                    const int packed = w ? bc1 : bc0;
+                    int c0[3], c1[3];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                    {
+                        const int q = (packed >> ((2 - ch) * 5)) & 15;
+                        const int u = (q << 4) | q;
+                        c0[ch] = u + modifier < 255 ? u + modifier : 255;
+                        c1[ch] = u - modifier > 0 ? u - modifier : 0;
+                    }
+                    float e0, e1;
+                    if (!FAKE && !E.uniform)
+                    {
+                        EtcErr::f32x2 cw[3];
+                        E.weigh2(cw, c0, c1);
+                        const EtcErr::f32x2 e01 = E.err2(cw, S.pw[px]);
+                        e0 = e01.x;
+                        e1 = e01.y;
+                    }
+                    else
+                    {
+                        e0 = E(c0[0], c0[1], c0[2], S.pix[px], S.pw[px]);
+                        e1 = E(c1[0], c1[1], c1[2], S.pix[px], S.pw[px]);
+                    }
+                    rowSign[w] = e1 < e0;
+                    rowErr[w] = rowSign[w] ? e1 : e0;
+                }
+                const bool oneBetter = rowErr[1] < rowErr[0];
+                sectorBits = (u32)(__ballot(lane < 16 && oneBetter) & 0xffffull);
+                signBits = (u32)(__ballot(lane < 16 && (oneBetter ? rowSign[1] : rowSign[0])) & 0xffffull);
+            }
             emitH(outHi, outLo, bc0, bc1, sectorBits, signBits, table, true);
         }
         WAVE_SYNC();
