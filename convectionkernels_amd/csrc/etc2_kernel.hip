@@ -43,7 +43,8 @@ struct EtcWaveShared
     {
         struct
         {
-            float err[72][16];       // H mode: min error of colour ci +/- modifier per pixel, two tables at a time
+            float err[16][72];       // H mode: min error of colour ci +/- modifier per pixel, two tables at a time; [pixel][colour]: the
+                                     // lanes of a pass hold consecutive colours, so every access is one run of consecutive words
             unsigned short color[2][36];
             unsigned short sign[72];
         } h;
@@ -1149,7 +1150,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                                 e0 = EE(c0[0], c0[1], c0[2], S.pix[px], S.pw[px]);
                                 e1 = EE(c1[0], c1[1], c1[2], S.pix[px], S.pw[px]);
                             }
-                            S.u.h.err[r][px] = __builtin_fminf(e0, e1); // (which of the two it was is worked out again for the winning pair)
+                            S.u.h.err[px][r] = __builtin_fminf(e0, e1); // (which of the two it was is worked out again for the winning pair)
                         }
                     };
                     if (E.uniform)
@@ -1181,7 +1182,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                     float totalError = 0.0f;
 #pragma unroll
                     for (int px = 0; px < 16; px++)
-                        totalError = totalError + __builtin_fminf(S.u.h.err[ci0][px], S.u.h.err[ci1][px]); // sums of squares: no NaN, no -0
+                        totalError = totalError + __builtin_fminf(S.u.h.err[px][ci0], S.u.h.err[px][ci1]); // sums of squares: no NaN, no -0
                     const int id = table * 1024 + k;
                     if (totalError < hBestErr || (totalError == hBestErr && id < hBestId))
                     {
@@ -1901,7 +1902,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                     hc[ch] = u - modifier > 0 ? u - modifier : 0;
                 }
                 const float e = E.wu(hc[0], hc[1], hc[2], S.pix[px], S.pw[px]);
-                S.u.h.err[table][px] = ((transMask >> px) & 1u) ? 0.0f : e;
+                S.u.h.err[px][table] = ((transMask >> px) & 1u) ? 0.0f : e;
                 if (px == 0)
                     S.u.h.color[0][table] = (unsigned short)((hq[0] << 10) | (hq[1] << 5) | hq[2]);
             }
@@ -1998,7 +1999,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                         const float e1 = E.wu(lc[1][0], lc[1][1], lc[1][2], S.pix[px], S.pw[px]);
                         const float le = ((transMask >> px) & 1u) ? 0.0f : sseMin(e0, e1);
                         tErr = tErr + sseMin(le, S.isoErr[px]);
-                        hErr = hErr + sseMin(le, S.u.h.err[table][px]);
+                        hErr = hErr + sseMin(le, S.u.h.err[px][table]);
                     }
                     // H mode stores the order of its two colours in the low table bit and cannot swap them here
                     const bool hLegal = (packed < (int)S.u.h.color[0][table]) == ((table & 1) == 0);
@@ -2040,7 +2041,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                     const bool tr = ((transMask >> px) & 1u) != 0;
                     const float le = tr ? 0.0f : sseMin(e0, e1);
                     u32 sel = (e0 <= e1) ? 1u : 3u;
-                    if ((useH ? S.u.h.err[table][px] : S.isoErr[px]) < le)
+                    if ((useH ? S.u.h.err[px][table] : S.isoErr[px]) < le)
                         sel = 0u;
                     if (tr)
                         sel = 2u;
