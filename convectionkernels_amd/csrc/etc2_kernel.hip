@@ -845,15 +845,14 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
             prefix[t + 1] = prefix[t] + S.tCount[t];
         // attempt 0: zero slots tracked apart (tentative); attempt 1 (rare): the slots of the tables in presentMask are
         // candidates like the others, the rest is skipped.  One copy of the evaluation loop serves both.
-        float candErr = FLT_MAX, wErr = FLT_MAX;
-        int candId = 0x7fffffff, wId = 0x7fffffff;
-        u32 candSel = 0, presentMask = 0;
+        float wErr = FLT_MAX;
+        int wId = 0x7fffffff;
+        u32 presentMask = 0;
         for (int attempt = 0; attempt < 2; attempt++)
         {
             const bool exact = attempt == 1;
             float rErr = FLT_MAX, zErr = FLT_MAX;
             int rId = 0x7fffffff, zId = 0x7fffffff;
-            u32 rSel = 0;
             for (int base = 0; base < prefix[8] + 8; base += 64)
             {
                 const int e = base + lane;
@@ -886,7 +885,6 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                         lc[1][ch] = u;
                         lc[2][ch] = u - modifier > 0 ? u - modifier : 0;
                     }
-                    u32 selectors = 0;
                     float error = 0.0f;
                     EtcErr::f32x2 lw01[3];
                     E.weigh2(lw01, lc[0], lc[1]);
@@ -900,7 +898,6 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                         for (int px = 0; px < 16; px++)
                         {
                             float pixelError = S.isoErr[px];
-                            u32 sel = 0;
                             float e3[3];
                             if (!UNI)
                             {
@@ -914,16 +911,10 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                                 e3[1] = EE.wu(lc[1][0], lc[1][1], lc[1][2], S.pix[px], S.pw[px]);
                             }
                             e3[2] = EE.wu(lc[2][0], lc[2][1], lc[2][2], S.pix[px], S.pw[px]); // sic: never the fake metric
-#pragma unroll
-                            for (int i = 0; i < 3; i++)
-                            {
-                                const float e = e3[i];
-                                const bool lt = e < pixelError; // equal values are equal bits (sums of squares): one comparison serves both
-                                sel = lt ? (u32)(i + 1) : sel;
-                                pixelError = lt ? e : pixelError;
-                            }
+                            // only the candidate's error (sums of squares: three v_min_f32); the selectors are worked out again
+                            // for the one candidate that wins
+                            pixelError = __builtin_fminf(__builtin_fminf(__builtin_fminf(pixelError, e3[0]), e3[1]), e3[2]);
                             error = error + pixelError;
-                            selectors |= sel << (px * 2);
                         }
                     };
                     if (E.uniform)
@@ -942,13 +933,9 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                     {
                         rErr = error;
                         rId = id;
-                        rSel = selectors;
                     }
                 }
             }
-            candErr = rErr;
-            candId = rId;
-            candSel = rSel;
             wErr = rErr;
             wId = rId;
             waveArgmin(wErr, wId);
@@ -1013,12 +1000,53 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
         if (wErr < bestError)
         {
             bestError = wErr;
-            // the winner's selectors sit in the lane that evaluated it
-            const u64 who = __ballot(candId == wId && candErr == wErr);
-            const u32 selectors = __shfl(candSel, __ffsll((long long)who) - 1);
             const int table = wId >> 8, ci = wId & 255;
             const int packed = ci < S.tCount[table] ? (int)S.tColors[table][ci] : 0;
             const int lineColor[3] = {packed & 15, (packed >> 5) & 15, (packed >> 10) & 15};
+            // the winner's selectors: lane px works out pixel px again (the operations of the candidate loop: first minimum
+            // among the isolated colour and the three line colours, strict '<')
+            u32 selectors = 0;
+            {
+                const int px = lane & 15;
+                const int modifier = thDist(table);
+                int lc[3][3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    const int u = (lineColor[ch] << 4) | lineColor[ch];
+                    lc[0][ch] = u + modifier < 255 ? u + modifier : 255;
+                    lc[1][ch] = u;
+                    lc[2][ch] = u - modifier > 0 ? u - modifier : 0;
+                }
+                float e3[3];
+                if (!E.uniform)
+                {
+                    EtcErr::f32x2 lw01[3];
+                    E.weigh2(lw01, lc[0], lc[1]);
+                    const EtcErr::f32x2 e01 = E.err2(lw01, S.pw[px]);
+                    e3[0] = e01.x;
+                    e3[1] = e01.y;
+                }
+                else
+                {
+                    e3[0] = E.wu(lc[0][0], lc[0][1], lc[0][2], S.pix[px], S.pw[px]);
+                    e3[1] = E.wu(lc[1][0], lc[1][1], lc[1][2], S.pix[px], S.pw[px]);
+                }
+                e3[2] = E.wu(lc[2][0], lc[2][1], lc[2][2], S.pix[px], S.pw[px]);
+                float pixelError = S.isoErr[px];
+                u32 sel = 0;
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    if (e3[i] < pixelError)
+                    {
+                        sel = (u32)(i + 1);
+                        pixelError = e3[i];
+                    }
+                const u64 b0 = __ballot(lane < 16 && (sel & 1u)), b1 = __ballot(lane < 16 && (sel & 2u));
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    selectors |= (u32)(((b0 >> i) & 1ull) | (((b1 >> i) & 1ull) << 1)) << (2 * i);
+            }
             emitT(outHi, outLo, lineColor, isoQ, selectors, table);
         }
         DBG_TAP(1 + call);
