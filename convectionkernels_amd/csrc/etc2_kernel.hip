@@ -340,10 +340,10 @@ __device__ __forceinline__ void emitH(u32 &outHi, u32 &outLo, int bc0, int bc1, 
 
 #ifdef CVTT_ETC_PROFILE
 // developer-only: wave cycles per stage (0 planar, 1/2 T mode calls, 3 H mode, 4 cluster fit), summed over waves
-__device__ unsigned long long g_etcProf[8];
+__device__ unsigned long long g_etcProf[16];
 extern "C" int cvttmi_etc_prof_read(unsigned long long *out)
 {
-    unsigned long long zero[8] = {0};
+    unsigned long long zero[16] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_etcProf), sizeof(zero)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_etcProf), zero, sizeof(zero)) != hipSuccess) return -1;
     return 0;
@@ -466,11 +466,14 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
 #ifdef CVTT_ETC_PROFILE
     unsigned long long profT = __builtin_readcyclecounter();
 #define DBG_TAP(i) do { const unsigned long long now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_etcProf[i], now - profT); profT = now; } while (0)
+#define DBG_COUNT(i, n) do { if (lane == 0) atomicAdd(&g_etcProf[i], (unsigned long long)(n)); } while (0)
 #elif defined(CVTT_ETC_DEBUG)
     float *dbg = reinterpret_cast<float *>(A.debug) + (size_t)blockIndex * 8;
 #define DBG_TAP(i) do { if (lane == 0 && A.debug) dbg[i] = bestError; } while (0)
+#define DBG_COUNT(i, n) do {} while (0)
 #else
 #define DBG_TAP(i) do {} while (0)
+#define DBG_COUNT(i, n) do {} while (0)
 #endif
 
     u32 isolatedMask = 0; // bit px: pixel is "isolated" / sector 1
@@ -1691,28 +1694,121 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                 else
                 {
                     // slow path: walk sector 0's attempts in (error, index) order without sorting;
-                    // for each, the cheapest legal partner (lowest (error, index)) of sector 1
+                    // for each, the cheapest legal partner (lowest (error, index)) of sector 1.
+                    // A step of the walk is two scans over all ~460 attempts of a sector, and a walk takes about twenty steps, most of
+                    // them without a commit.  What the walk can still touch is small: sector-0 attempts after the current one
+                    // that are below the best and pass the walk's own `best - e0 < m1` exit (a prefix of the sorted order, both
+                    // tests being monotone in e0), and sector-1 attempts below best - m0 (the bound on every later maxError1).
+                    // If both sets fit the wave they are dealt to the lanes (one entry each) and the remaining steps are two
+                    // wave-wide minima instead of two scans; otherwise the walk goes on as before.  Same steps, same tests,
+                    // same order: the sets only leave out what the walk's exits and the `pE < maxError1` test rule out.
                     float prevE = -1.0f;
                     int prevI = -1;
                     float blockBest = blockBest0;
+                    bool compact = false;
+                    DBG_COUNT(12, 1);
+                    constexpr int kPerLane = 2, kCap = 64 * kPerLane; // entries of a set per lane / in all
+                    float ce0[kPerLane], ce1[kPerLane];
+                    int ci0[kPerLane], cj1[kPerLane];
+                    u32 cc0[kPerLane], cc1[kPerLane];
+#pragma unroll
+                    for (int k = 0; k < kPerLane; k++)
+                    {
+                        ce0[k] = ce1[k] = FLT_MAX;
+                        ci0[k] = cj1[k] = 0x7fffffff;
+                        cc0[k] = cc1[k] = 0;
+                    }
+                    unsigned short *const stage = &S.tColors[0][0]; // 2 x kCap attempt numbers: the T modes' colour lists are dead by now
+                    // deal what the walk can still touch to the lanes (see above); called before the first step and, while the sets
+                    // are too large for the wave, again after every commit (each tightens them)
+                    auto tryCompact = [&]() {
+                        WAVE_SYNC();
+                        int cnt0 = 0, cnt1 = 0;
+                        const float bound1 = bestError - m0;
+                        const u64 below = (1ull << lane) - 1ull;
+                        for (int base = 0; base < numA0; base += 64)
+                        {
+                            const int i = base + lane;
+                            const float e = i < numA0 ? S.u.a.err[0][i] : FLT_MAX;
+                            const bool after = (e > prevE) || (e == prevE && i > prevI);
+                            const bool alive = i < numA0 && after && e < blockBest0 && e < blockBest && !((bestError - e) < m1);
+                            const u64 bal = __ballot(alive);
+                            const int slot = cnt0 + __popcll(bal & below);
+                            if (alive && slot < kCap)
+                                stage[slot] = (unsigned short)i;
+                            cnt0 += __popcll(bal);
+                        }
+                        for (int base = 0; base < numA1; base += 64)
+                        {
+                            const int j = base + lane;
+                            const float e = j < numA1 ? S.u.a.err[1][j] : FLT_MAX;
+                            const bool alive = j < numA1 && e < blockBest0 && e < bound1;
+                            const u64 bal = __ballot(alive);
+                            const int slot = cnt1 + __popcll(bal & below);
+                            if (alive && slot < kCap)
+                                stage[kCap + slot] = (unsigned short)j;
+                            cnt1 += __popcll(bal);
+                        }
+                        WAVE_SYNC();
+                        DBG_COUNT(9, 1);
+                        DBG_COUNT(13, cnt0);
+                        DBG_COUNT(14, cnt1);
+                        if (cnt0 <= kCap && cnt1 <= kCap)
+                        {
+                            DBG_COUNT(10, 1);
+                            compact = true;
+#pragma unroll
+                            for (int k = 0; k < kPerLane; k++)
+                            {
+                                if (lane + 64 * k < cnt0)
+                                {
+                                    ci0[k] = (int)stage[lane + 64 * k];
+                                    ce0[k] = S.u.a.err[0][ci0[k]];
+                                    cc0[k] = colorOf(0, ci0[k]);
+                                }
+                                if (lane + 64 * k < cnt1)
+                                {
+                                    cj1[k] = (int)stage[kCap + lane + 64 * k];
+                                    ce1[k] = S.u.a.err[1][cj1[k]];
+                                    cc1[k] = colorOf(1, cj1[k]);
+                                }
+                            }
+                        }
+                    };
+                    tryCompact();
                     for (;;)
                     {
                         // next attempt of sector 0 in sorted order among those with error < blockBest0
                         float nE = FLT_MAX;
                         int nI = 0x7fffffff;
-                        for (int i = lane; i < numA0; i += 64)
+                        if (!compact)
                         {
-                            const float e = S.u.a.err[0][i];
-                            const bool after = (e > prevE) || (e == prevE && i > prevI);
-                            if (e < blockBest0 && after && ((e < nE) || (e == nE && i < nI)))
+                            for (int i = lane; i < numA0; i += 64)
                             {
-                                nE = e;
-                                nI = i;
+                                const float e = S.u.a.err[0][i];
+                                const bool after = (e > prevE) || (e == prevE && i > prevI);
+                                if (e < blockBest0 && after && ((e < nE) || (e == nE && i < nI)))
+                                {
+                                    nE = e;
+                                    nI = i;
+                                }
                             }
+                        }
+                        else
+                        {
+                            // (FLT_MAX / 0x7fffffff where a lane has no entry or the entry has had its turn)
+#pragma unroll
+                            for (int k = 0; k < kPerLane; k++)
+                                if (ce0[k] < nE || (ce0[k] == nE && ci0[k] < nI))
+                                {
+                                    nE = ce0[k];
+                                    nI = ci0[k];
+                                }
                         }
                         waveArgmin(nE, nI);
                         if (nI == 0x7fffffff)
                             break;
+                        DBG_COUNT(compact ? 11 : 8, 1);
                         prevE = nE;
                         prevI = nI;
                         const float error0 = nE;
@@ -1721,19 +1817,50 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                         const float maxError1 = bestError - error0;
                         if (maxError1 < m1)
                             break;
-                        const u32 c0 = colorOf(0, nI);
+                        u32 c0;
+                        if (!compact)
+                            c0 = colorOf(0, nI);
+                        else
+                        {
+                            u32 mine = 0;
+                            bool have = false;
+#pragma unroll
+                            for (int k = 0; k < kPerLane; k++)
+                                if (ci0[k] == nI)
+                                {
+                                    mine = cc0[k];
+                                    have = true;
+                                    ce0[k] = FLT_MAX; // this entry has had its turn
+                                    ci0[k] = 0x7fffffff;
+                                }
+                            const u64 who = __ballot(have);
+                            c0 = __shfl(mine, __ffsll((long long)who) - 1);
+                        }
                         // the sorted scan of sector 1 stops at the first entry with error >= maxError1,
                         // so the partner is the cheapest LEGAL entry provided it is below maxError1
                         float pE = FLT_MAX;
                         int pI = 0x7fffffff;
-                        for (int j = lane; j < numA1; j += 64)
+                        if (!compact)
                         {
-                            const float e = S.u.a.err[1][j];
-                            if (e < blockBest0 && legal(c0, colorOf(1, j)) && ((e < pE) || (e == pE && j < pI)))
+                            for (int j = lane; j < numA1; j += 64)
                             {
-                                pE = e;
-                                pI = j;
+                                const float e = S.u.a.err[1][j];
+                                if (e < blockBest0 && legal(c0, colorOf(1, j)) && ((e < pE) || (e == pE && j < pI)))
+                                {
+                                    pE = e;
+                                    pI = j;
+                                }
                             }
+                        }
+                        else
+                        {
+#pragma unroll
+                            for (int k = 0; k < kPerLane; k++)
+                                if (cj1[k] != 0x7fffffff && legal(c0, cc1[k]) && (ce1[k] < pE || (ce1[k] == pE && cj1[k] < pI)))
+                                {
+                                    pE = ce1[k];
+                                    pI = cj1[k];
+                                }
                         }
                         waveArgmin(pE, pI);
                         if (pI != 0x7fffffff && pE < maxError1)
@@ -1747,6 +1874,8 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                             bPacked1 = colorOf(1, pI) << 16;
                             bTable0 = tableOf(0, nI);
                             bTable1 = tableOf(1, pI);
+                            if (!compact)
+                                tryCompact();
                         }
                     }
                 }
