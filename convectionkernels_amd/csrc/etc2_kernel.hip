@@ -71,6 +71,16 @@ __device__ __forceinline__ int udivSmall(int n, int d)
     return q;
 }
 
+// ceil(2^20 / d) for 1 <= d <= 128 (one float division with the two possible corrections, per EAC candidate)
+__device__ __forceinline__ int udivSmall20(int d)
+{
+    int q = (int)(1048576.0f * __frcp_rn((float)d));
+    int r = 1048576 - q * d;
+    if (r < 0) { q--; r += d; }
+    if (r >= d) { q++; r -= d; }
+    return r == 0 ? q : q + 1;
+}
+
 __device__ __forceinline__ u32 bswap32(u32 v) { return __builtin_bswap32(v); }
 
 // wave-wide argmin of (err, id); ties -> lowest id.  All lanes receive the winner.
@@ -2357,7 +2367,10 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
                     base2 = base2 < 0 ? 0 : (base2 > 510 ? 510 : base2);
                     baseAlpha = (base2 + 1) >> 1;
                 }
-                const float rcpMul = __frcp_rn((float)multiplier);
+                // lookup / multiplier for lookup < 2^12, multiplier <= 128: (lookup * ceil(2^20 / multiplier)) >> 20 is exact
+                // (the excess of the magic number adds less than lookup / 2^20 < 1/256 to a quotient whose fraction is at most
+                // 127/128), one 24-bit multiply and a shift per pixel; the magic number is per candidate
+                const u32 magic = (u32)udivSmall20(multiplier);
                 u32 idxLo = 0, idxHi = 0, totalError = 0;
 #pragma unroll
                 for (int px = 0; px < 16; px++)
@@ -2366,11 +2379,7 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
                     const int refl2 = (a - baseAlpha) * 2 + multiplier;
                     const int absv = refl2 < 0 ? -refl2 : refl2;
                     const int lookup = absv >> 1;
-                    // lookup / multiplier (lookup < 2^12, multiplier <= 128)
-                    int li = (int)((float)lookup * rcpMul);
-                    const int rem = lookup - li * multiplier;
-                    if (rem < 0) li--;
-                    if (rem >= multiplier) li++;
+                    int li = (int)(__umul24((u32)lookup, magic) >> 20);
                     li = li >= 13 ? 12 : li;
                     const int index = (int)((roundBits >> (2 * li)) & 3u);
                     const int pOff = (int)((posWord >> (8 * index)) & 0xffu);

@@ -297,3 +297,16 @@ def test_gpu_alloc_time_axes(gpu_ctx, oracle_lib):
             got = fn(b, eo, compression_data=data)
             bad = np.nonzero((got != want).any(axis=1))[0]
             assert bad.size == 0, (mode, bad[:8])
+
+
+def test_eac_magic_number_division_is_exact():
+    """csrc/etc2_kernel.hip (EAC alpha / R11) divides a pixel's lookup value by the candidate's multiplier as
+    (lookup * ceil(2^20 / multiplier)) >> 20 with a 24-bit multiply: exact for every lookup < 2^12 and multiplier <= 128
+    (the ranges of ETC.cpp's EAC search), and the product stays below 2^32."""
+    n = np.arange(4096, dtype=np.uint64)
+    for d in range(1, 129):
+        m = -(-(1 << 20) // d)
+        assert m < (1 << 24)
+        p = n * np.uint64(m)
+        assert int(p.max()) < (1 << 32)
+        assert ((p >> np.uint64(20)) == n // np.uint64(d)).all(), d
