@@ -808,7 +808,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
             const int lineAddend = (numLine << 4) | numLine;
             for (int id = lane; id < 8 * span; id += 64)
             {
-                const int tbl = id / span, kk = id - tbl * span;
+                const int tbl = udivSmall(id, span), kk = id - tbl * span; // (id < 2^16, span <= 33: the float form, not a 32-bit division)
                 const int modifierAddend = (int)(short)((kk - numLine) * (thDist(tbl) * 2));
                 int packed = 0, q3[3], targets[3];
 #pragma unroll
@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
             const int perTable = 2 * counts[0] + 1 + 2 * counts[1] + 1; // 34
             for (int id = lane; id < 8 * perTable; id += 64)
             {
-                const int table = id / perTable, j = id - table * perTable;
+                const int table = udivSmall(id, perTable), j = id - table * perTable;
                 const int sector = j < 2 * counts[0] + 1 ? 0 : 1;
                 const int kk = sector ? j - (2 * counts[0] + 1) : j;
                 const int cnt = sector ? counts[1] : counts[0];
@@ -1215,8 +1215,9 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                     const int k = isB ? kk - pairsA : kk;
                     const int n0 = isB ? nB0 : nA0, n1 = isB ? nB1 : nA1;
                     const int rowBase = isB ? rowsA : 0;
-                    const int i0 = k % n0;
-                    const int i1 = (k / n0) < n1 - 1 ? (k / n0) : n1 - 1;
+                    const int kq = udivSmall(k, n0); // (k < 2^11, n0 <= 18)
+                    const int i0 = k - kq * n0;
+                    const int i1 = kq < n1 - 1 ? kq : n1 - 1;
                     const int ci0 = rowBase + i0, ci1 = rowBase + n0 + i1;
                     // only the pair's error: which colour and which sign every pixel takes is worked out again for the one pair
                     // that wins (below), instead of being carried as two bit masks through every pixel of every pair
