@@ -61,10 +61,21 @@ struct EtcWaveShared
     int planarRange[3][3][2];
 };
 
+// v_min_f32 of two values known not to be NaN (sums of squares read back from LDS): __builtin_fminf on loaded values makes
+// the compiler canonicalise both operands first (two v_max_f32 per minimum)
+__device__ __forceinline__ float minLoaded(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ int udivSmall(int n, int d)
 {
-    // exact n / d for 0 <= n < 2^16, 0 < d < 2^12 (integer divisions of ETC.cpp:446, 546, 717)
-    int q = (int)((float)n * __frcp_rn((float)d));
+    // exact n / d for 0 <= n < 2^16, 0 < d < 2^12 (integer divisions of ETC.cpp:446, 546, 717).  v_rcp_f32 (1 ulp) is enough:
+    // the product is within 0.02 of n / d, so the truncated value is off by at most one, which the two corrections undo
+    // (__frcp_rn is a full IEEE division sequence under -fhip-fp32-correctly-rounded-divide-sqrt: twenty instructions)
+    int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
     const int r = n - q * d;
     if (r < 0) q--;
     if (r >= d) q++;
@@ -74,7 +85,7 @@ __device__ __forceinline__ int udivSmall(int n, int d)
 // ceil(2^20 / d) for 1 <= d <= 128 (one float division with the two possible corrections, per EAC candidate)
 __device__ __forceinline__ int udivSmall20(int d)
 {
-    int q = (int)(1048576.0f * __frcp_rn((float)d));
+    int q = (int)(1048576.0f * __builtin_amdgcn_rcpf((float)d));
     int r = 1048576 - q * d;
     if (r < 0) { q--; r += d; }
     if (r >= d) { q++; r -= d; }
@@ -926,7 +937,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                             e3[2] = EE.wu(lc[2][0], lc[2][1], lc[2][2], S.pix[px], S.pw[px]); // sic: never the fake metric
                             // only the candidate's error (sums of squares: three v_min_f32); the selectors are worked out again
                             // for the one candidate that wins
-                            pixelError = __builtin_fminf(__builtin_fminf(__builtin_fminf(pixelError, e3[0]), e3[1]), e3[2]);
+                            pixelError = __builtin_fminf(minLoaded(pixelError, e3[0]), __builtin_fminf(e3[1], e3[2]));
                             error = error + pixelError;
                         }
                     };
@@ -1224,7 +1235,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                     float totalError = 0.0f;
 #pragma unroll
                     for (int px = 0; px < 16; px++)
-                        totalError = totalError + __builtin_fminf(S.u.h.err[px][ci0], S.u.h.err[px][ci1]); // sums of squares: no NaN, no -0
+                        totalError = totalError + minLoaded(S.u.h.err[px][ci0], S.u.h.err[px][ci1]); // sums of squares: no NaN, no -0
                     const int id = table * 1024 + k;
                     if (totalError < hBestErr || (totalError == hBestErr && id < hBestId))
                     {
