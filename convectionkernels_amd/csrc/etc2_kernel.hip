@@ -918,7 +918,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                         constexpr bool UNI = decltype(uniTag)::value;
                         const EtcErr EE = {UNI, E.rw, E.gw, E.bw, E.fake};
                         EtcWaveShared &S = shared1; // (static storage: named again here, a generic lambda does not capture the outer reference)
-#pragma unroll 2
+#pragma unroll 4
                         for (int px = 0; px < 16; px++)
                         {
                             float pixelError = S.isoErr[px];
@@ -1187,7 +1187,7 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
                         constexpr bool UNI = decltype(uniTag)::value;
                         const EtcErr EE = {UNI, E.rw, E.gw, E.bw, E.fake};
                         EtcWaveShared &S = shared1;
-#pragma unroll 2
+#pragma unroll 4
                         for (int px = 0; px < 16; px++)
                         {
                             float e0, e1;
