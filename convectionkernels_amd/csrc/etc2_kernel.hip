@@ -2383,7 +2383,7 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
                 // (the excess of the magic number adds less than lookup / 2^20 < 1/256 to a quotient whose fraction is at most
                 // 127/128), one 24-bit multiply and a shift per pixel; the magic number is per candidate
                 const u32 magic = (u32)udivSmall20(multiplier);
-                u32 idxLo = 0, idxHi = 0, totalError = 0;
+                u32 totalError = 0; // (only the error: the winner's indexes are worked out again after the search)
 #pragma unroll
                 for (int px = 0; px < 16; px++)
                 {
@@ -2402,11 +2402,6 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
                     q = q < qLo ? qLo : (q > qHi ? qHi : q);
                     const int d = q - a;
                     totalError += (u32)(d * d);
-                    const u32 code = (u32)(index + 4 - (sign & 4));
-                    if (px < 8)
-                        idxLo |= code << (3 * px);
-                    else
-                        idxHi |= code << (3 * (px - 8));
                 }
                 if (totalError < bestTotalError)
                 {
@@ -2414,10 +2409,26 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
                     bestTable = tableIndex;
                     bestBase = baseAlpha;
                     bestMultiplier = multiplier;
-                    bestIdxLo = idxLo;
-                    bestIdxHi = idxHi;
                 }
             }
+        }
+    }
+    // the winner's indexes (the operations of the candidate loop, once)
+    {
+        const u32 magic = (u32)udivSmall20(bestMultiplier);
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+        {
+            const int refl2 = (pixel[px] - bestBase) * 2 + bestMultiplier;
+            const int absv = refl2 < 0 ? -refl2 : refl2;
+            int li = (int)(__umul24((u32)(absv >> 1), magic) >> 20);
+            li = li >= 13 ? 12 : li;
+            const int index = T->eacRounding[bestTable][li];
+            const u32 code = (u32)(index + 4 - ((refl2 < 0 ? -1 : 0) & 4));
+            if (px < 8)
+                bestIdxLo |= code << (3 * px);
+            else
+                bestIdxHi |= code << (3 * (px - 8));
         }
     }
     if (is11)
