@@ -18,9 +18,9 @@
 //     registers and every pixel scans them in order (strict '<', IndexSelectorHDR.h:125-139);
 //     the anchor pixel goes first because its index decides the endpoint inversion, and a
 //     round that turns out to be a duplicate never looks at the other pixels;
-//   * the "meta round" results of a partition (errors, endpoints of the subset being searched)
-//     live in LDS, [entry][lane] so every access is conflict free; indexes and subset 0's
-//     endpoints go to an L2-resident scratch that only the commit path reads back.
+//   * the "meta round" results of a partition (errors and quantised end points of both subsets) live in LDS, [entry][lane]
+//     so every access is conflict free; indexes are not kept (the winner's are selected again after the search) and nothing
+//     goes to memory between the load of the block and the store of its 16 bytes.
 //
 // What is NOT searched ("Round 3"): nine of the ten two-subset modes delta-code three of their four end
 // points, the reference's commit loop skips a (round, round, mode) triple whose deltas do not fit with a `continue` that
@@ -30,7 +30,6 @@
 //     last refine pass; a partition without a usable subset-0 round skips subset 1 and the commit loop (`usable0`);
 //   * precisions of 8 bits and more are searched lazily (`lazy`): chains of both subsets without errors, then the exact set of
 //     round pairs some lane could commit, then a replay of just those rounds with errors (a separate block of code);
-//   * the PCA seeds of the 64 (partition, subset) pairs are computed by the first precision and read back by the others.
 // On content without structure that is two thirds of the reference's work; the output is bit-identical because every
 // skipped piece is one the reference computes and then cannot use.
 #include "cvtt_kernel_common.h"
@@ -60,24 +59,23 @@ extern "C" int cvttmi_bc6h_prof_read(unsigned long long *out)
 
 namespace
 {
-// ---- per-partition "meta round" state, dwords per lane ----
-//   ERR : 12 rounds x 2 subsets (subset error)                                         = 24  -> LDS
-//   EPQ : 12 rounds x 3 dwords (6 x int16: ep0.rgb, ep1.rgb) of the subset being searched = 36 -> LDS
-//         (duplicate-round test + legality pass); subset 0's copy moves to scratch when subset 1 starts
-//   scratch (HBM/L2, [wave][entry][lane], one coalesced 256-byte line per access):
-//         EPQ0 36 dwords + IDX 2 subsets x 12 rounds x 2 dwords (4 bits per pixel) = 84 dwords,
-//         written once per round, read only by the legality pass / at a commit
-constexpr int kEpqBase = 0, kMetaDwords = 36; // the 24 per-round errors live in registers (uniform dynamic index)
-constexpr int kScrEpq0 = 0, kScrIdx = 36, kScrPca = 84, kScratchDwords = 84 + 32 * 2 * 9;
-// kScrPca: the PCA seeds (base, offset) and the pre-weighted pixel sums of every (partition, subset), 9 floats: they do not depend
-// on the precision, so the first partitioned precision files them and the other five read them back (147 KB per wave, written
-// once and read five times in coalesced 256-byte lines: about 0.1 TB/s at 8 Mblocks/s) instead of running three passes over
-// the pixels and eight power iterations with IEEE divisions again
-// Waves per SIMD the register allocator must leave room for.  4 (128 VGPRs, spills) instead of 3 (150-167, none) measured
-// +3.5 % in round 2 and +9 % with round 3's code (127.5 against 139.5 ms at 4096^2): gfx950 overlaps the plain f32
-// instructions of an EVEN number of resident waves (profiles/r02/valu_order.txt).
+// ---- per-partition "meta round" state: everything stays on the chip (LDS, [entry][lane], conflict free) ----
+//   EPQ : the quantised end points of every round of BOTH subsets (duplicate-round test, legality pass, commit).
+//         two-subset precisions (<= 11 bits): two words per round -- r | g << 11 | b[9:0] << 22 per end point -- plus bit 10 of
+//         the two blue values in a register (24 bits per subset); single-subset precisions (<= 16 bits): three words per
+//         round (6 x int16).  2 x 12 x 2 = 48 entries (36 for the single-subset search)
+//   ERR : 12 rounds x 2 subsets, binary32                                                        = 24 entries
+// 72 entries x 256 B = 18 KB per wave: two waves per SIMD (8 per CU, 144 of 160 KB).  Indexes are not kept at all: the
+// winner's are selected again, once, from its end points after the search (same deterministic scan), and the PCA seeds are
+// computed per precision.  Round 3 kept the subset-0 history, the indexes of every round and the seeds in a 169 KB per wave
+// HBM work buffer and 24 errors + spills in 256 B of private scratch: 104 GB of HBM traffic per 4096^2 image (FETCH_SIZE /
+// WRITE_SIZE, profiles/r04) against 151 MB of algorithmic bytes.
+constexpr int kEpqBase = 0, kEpqDwords = 48, kErrBase = 48, kMetaDwords = 72;
+// Waves per SIMD the register allocator may assume.  The LDS footprint allows two; with 256 registers nothing spills and the
+// pixels' weighted linear values stay in registers.  Measured with round 3's code: 2 waves 7.17, 3 waves 7.25, 4 waves
+// (128 registers, 256 B of scratch) 7.70 Mblocks/s on noise -- the fourth wave bought 7 % and cost the HBM traffic above.
 #ifndef CVTT_BC6H_WAVES
-#define CVTT_BC6H_WAVES 4
+#define CVTT_BC6H_WAVES 2
 #endif
 
 // ceil(n / 31) for 0 <= n < 2^23: one v_mul_hi_u32.  2216757579 = (2^36 + 8213) / 31 (NOT ceil(2^36 / 31) = 2216757315):
@@ -175,26 +173,39 @@ __device__ __forceinline__ float twosCLHalfToFloat(int v16)
 }
 
 // ReconstructHDR{Signed,Unsigned}Uninverted for one channel, IndexSelectorHDR.h:34-66
-template <bool SIGNED>
-__device__ __forceinline__ int reconstructChannel(int e0, int e1, int weight)
+// (64 - w) * e0 + w * e1 = 64 * e0 + w * (e1 - e0): one 24-bit multiply-add per interpolant instead of two 32-bit
+// multiplications (quarter rate on gfx950) -- |e| < 2^16, w <= 64, so every term fits 24 bits
+// reconstructBase: 64 * e0 + 32, with the difference e1 - e0 computed once per round and channel
+__device__ __forceinline__ u32 mulU24(u32 a, u32 b)
+{
+    u32 r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// DYN: the weight is a run-time value (forced v_mad_i32_i24); otherwise a literal the compiler may fold
+template <bool SIGNED, bool DYN = true>
+__device__ __forceinline__ int reconstructFrom(int base, int diff, int weight)
 {
     if (SIGNED)
     {
-        int p = (64 - weight) * e0 + weight * e1; // |e| < 2^15: fits easily
-        p = (p + 32) >> 6;
+        int p = (DYN ? madI24(weight, diff, base) : mad24(weight, diff, base)) >> 6;
         p = p > 32767 ? 32767 : (p < -32768 ? -32768 : p);
         const bool neg = p < 0;
         const int a = neg ? -p : p;
-        int scaled = (int)((((u32)a & 0xffffu) * 31u) >> 5); // UnscaleHDRValueSigned, BC67.cpp:766-782
+        int scaled = (int)(__umul24((u32)a & 0xffffu, 31u) >> 5); // UnscaleHDRValueSigned, BC67.cpp:766-782
         scaled = scaled > 32767 ? 32767 : scaled;
         return (int)(short)(unsigned short)((u32)scaled | (neg ? 0x8000u : 0u));
     }
     else
     {
-        u32 p = (u32)(64 - weight) * (u32)e0 + (u32)weight * (u32)e1; // e < 2^16, weight <= 64
-        p = (p + 32u) >> 6;
-        return (int)((((p & 0xffffu) * 31u) >> 6)); // UnscaleHDRValueUnsigned
+        const u32 p = (u32)(DYN ? madI24(weight, diff, base) : mad24(weight, diff, base)) >> 6; // e < 2^16, weight <= 64: 0 <= 64 e0 + w (e1 - e0) + 32 < 2^22 + 32
+        return (int)(mulU24(p & 0xffffu, 31u) >> 6);   // UnscaleHDRValueUnsigned
     }
+}
+template <bool SIGNED>
+__device__ __forceinline__ int reconstructChannel(int e0, int e1, int weight)
+{
+    return reconstructFrom<SIGNED, false>(e0 * 64 + 32, e1 - e0, weight);
 }
 
 struct FetchHDR
@@ -218,13 +229,12 @@ __device__ __forceinline__ u32 groupBits(u64 ballot, int lane) { return (u32)(ba
 
 template <bool SIGNED, bool FAST>
 __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
-                                                         const CvttBc6hArgs A, const CvttDeviceTables *__restrict__ T,
-                                                         u32 *__restrict__ scratch)
+                                                         const CvttBc6hArgs A, const CvttDeviceTables *__restrict__ T)
 {
     __shared__ u32 meta[kMetaDwords][64];
-    float errR[24]; // error of every (round, subset) of the current partition; indexed by wave-uniform loop counters
     const int lane = threadIdx.x;
-    u32 *const scr = scratch + (size_t)blockIdx.x * (kScratchDwords * 64) + lane; // entry e at scr[e * 64]
+    // error of round m of subset s of the current partition (indexed by wave-uniform loop counters)
+    auto errAt = [&](int m, int s) -> float & { return reinterpret_cast<float &>(meta[kErrBase + m * 2 + s][lane]); };
     const u32 blockIndex = blockIdx.x * 64u + (u32)lane;
     const bool valid = blockIndex < A.numBlocks;
 
@@ -281,6 +291,20 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
         return f;
     };
 
+    // slow indexing: the weighted linear value of every pixel channel (floatPixelsLinearWeighted, BC67.cpp:2711), what the
+    // interpolant scan compares with; 48 of the 256 registers two waves per SIMD leave a lane
+    float lw[FAST ? 1 : 16][3];
+    if (!FAST)
+    {
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+        {
+            lw[px][0] = pixelToFloat((int)(short)(pk01[px] & 0xffffu)) * A.w[0];
+            lw[px][1] = pixelToFloat((int)(short)(pk01[px] >> 16)) * A.w[1];
+            lw[px][2] = pixelToFloat((int)(short)(pk2[px] & 0xffffu)) * A.w[2];
+        }
+    }
+
     int numTweakRounds = A.seedPoints < 1 ? 1 : (A.seedPoints > 4 ? 4 : A.seedPoints);
     int numRefineRounds = A.refineRounds < 1 ? 1 : (A.refineRounds > 3 ? 3 : A.refineRounds);
 
@@ -288,7 +312,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
     float bestError = FLT_MAX;
     int bestMode = 0, bestPartition = 0;
     u32 bestEP[6] = {0, 0, 0, 0, 0, 0}; // [subset][3 dwords: (e0r|e0g<<16),(e0b|e1r<<16),(e1g|e1b<<16)]
-    u32 bestIdxLo = 0, bestIdxHi = 0;
+    u32 bestSwap = 0; // bit s: the winning round of subset s exchanged its end points (anchor index in the upper half)
 
     // A mode of the current precision as one wave-uniform word (a scalar register): mode | transformed << 4 | the bits a
     // delta loses per channel (16 - bPrec) << 8, 16, 24.  Read from the table once per precision: a table lookup inside a
@@ -316,22 +340,13 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
         return ok;
     };
 
-    // PCA seeds of a subset and the sums of its pre-weighted pixels; slot >= 0: filed for the later precisions (kScrPca)
-    auto pcaSeeds = [&](u32 subsetMask, Unfinished &u, float (&sums)[3], int slot) {
+    // PCA seeds of a subset and the sums of its pre-weighted pixels (the reference precomputes them for every partition,
+    // BC67.cpp:2738-2774; per precision here: 64 x 9 floats per block have no place on the chip, and the six passes cost
+    // 4 % of the kernel where a 147 KB per wave work buffer cost 14 GB of HBM traffic per 4096^2 image)
+    auto pcaSeeds = [&](u32 subsetMask, Unfinished &u, float (&sums)[3]) {
         Moments<3> m;
         pcaMomentsT<3>(F, subsetMask, m, sums);
         pcaFinishT<3>(F, subsetMask, A.w, m, u);
-        if (slot >= 0)
-        {
-            u32 *dst = scr + (size_t)(kScrPca + slot * 9) * 64;
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++)
-            {
-                dst[ch * 64] = __float_as_uint(u.base[ch]);
-                dst[(3 + ch) * 64] = __float_as_uint(u.offset[ch]);
-                dst[(6 + ch) * 64] = __float_as_uint(sums[ch]);
-            }
-        }
     };
 
     // the single-subset (4-bit indexes) and the partitioned (3-bit) search are two instantiations of the same body, so
@@ -345,6 +360,50 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
         const float maxValue = (float)(indexRange - 1);
         const int weightRcp = partitioned ? 4681 : 2185; // g_weightReciprocals[8], [16]
         const float rcpMaxIndex = T->rcpMaxIndex[indexBits];
+
+        // ---- the quantised end points of a round as kept in LDS (layout at the top of the file) ----
+        // wc: the two-subset form's two spare bits (bit 10 of the blue values), kept in a register per subset
+        auto packEPQ = [&](const int (&q)[2][3], u32 &wa, u32 &wb, u32 &wc) {
+            if (partitioned)
+            {
+                wa = ((u32)q[0][0] & 0x7ffu) | (((u32)q[0][1] & 0x7ffu) << 11) | (((u32)q[0][2] & 0x3ffu) << 22);
+                wb = ((u32)q[1][0] & 0x7ffu) | (((u32)q[1][1] & 0x7ffu) << 11) | (((u32)q[1][2] & 0x3ffu) << 22);
+                wc = (((u32)q[0][2] >> 10) & 1u) | ((((u32)q[1][2] >> 10) & 1u) << 1);
+            }
+            else
+            {
+                wa = ((u32)q[0][0] & 0xffffu) | ((u32)q[0][1] << 16);
+                wb = ((u32)q[0][2] & 0xffffu) | ((u32)q[1][0] << 16);
+                wc = ((u32)q[1][1] & 0xffffu) | ((u32)q[1][2] << 16);
+            }
+        };
+        auto unpackEPQ = [&](u32 wa, u32 wb, u32 wc, int (&e)[2][3]) {
+            if (partitioned)
+            {
+                const u32 v[2][3] = {{wa & 0x7ffu, (wa >> 11) & 0x7ffu, (wa >> 22) | ((wc & 1u) << 10)},
+                                     {wb & 0x7ffu, (wb >> 11) & 0x7ffu, (wb >> 22) | ((wc & 2u) << 9)}};
+#pragma unroll
+                for (int epi = 0; epi < 2; epi++)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                        e[epi][ch] = SIGNED ? ((int)(v[epi][ch] << 21) >> 21) : (int)v[epi][ch];
+            }
+            else
+            {
+                e[0][0] = (int)(short)(wa & 0xffffu); e[0][1] = (int)(short)(wa >> 16); e[0][2] = (int)(short)(wb & 0xffffu);
+                e[1][0] = (int)(short)(wb >> 16); e[1][1] = (int)(short)(wc & 0xffffu); e[1][2] = (int)(short)(wc >> 16);
+            }
+        };
+        constexpr int epqStride = partitioned ? 2 : 3;
+        // LDS entry of word 0 of round `m` of subset `s`
+        auto epqEntry = [&](int s, int m) -> int { return kEpqBase + (s * 12 + m) * epqStride; };
+        // the stored words of a round (xb: the subset's spare-bit register)
+        auto loadEPQ = [&](int s, int m, u32 xb, int (&e)[2][3]) {
+            const int at = epqEntry(s, m);
+            const u32 wa = meta[at][lane], wb = meta[at + 1][lane];
+            const u32 wc = partitioned ? ((xb >> (2 * m)) & 3u) : meta[at + 2][lane];
+            unpackEPQ(wa, wb, wc, e);
+        };
 
         for (int aPrec = 16; aPrec >= 0; aPrec--)
         {
@@ -380,7 +439,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                 const bool lazy = !eagerNow;
                 if (partitioned && aPrec >= 8) { if (lazy) { PROF_COUNT(13, 1) } else { PROF_COUNT(11, 1) } }
                 u32 cand0 = 0;   // lazy: rounds of subset 0 whose own delta fits a mode in THIS lane
-                u32 invBits = 0; // lazy: bit subset * 12 + round = the round swapped its end points (anchor index in the upper half)
+                u32 invBits = 0; // bit subset * 12 + round = the round swapped its end points (anchor index in the upper half)
+                u32 xbits0 = 0, xbits1 = 0; // the spare bits of the packed end points (two per round)
                 u32 roundValid0 = 0xfffu, roundValid1 = 0xfffu; // per group (identical in its 8 lanes)
                 // Rounds of subset 0 whose quantised end points fit the delta coding of a mode of this precision in at
                 // least one lane of the wave.  A block can only be committed with such a round (the legality test of
@@ -395,41 +455,18 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                 {
                     const u32 subsetMask = partitioned ? (subset ? partitionMask : (~partitionMask & 0xffffu)) : 0xffffu;
                     if (subset == 1 && usable0 == 0)
-                    {
-                        if (aPrec == 11)
-                        {
-                            // nobody needs subset 1 here, but the later precisions need its seeds
-                            Unfinished u1;
-                            float v1[3];
-                            pcaSeeds(subsetMask, u1, v1, p * 2 + 1);
-                        }
                         break;
-                    }
                     const int fixupIndex = (subset == 0) ? 0 : (int)T->anchor2[p];
                     const int count = __popc(subsetMask);
                     const float wRcp = T->rcpTable[count];
                     const float wCount = (float)count;
 
-                    // seeds of this subset (the reference precomputes them for every partition,
-                    // BC67.cpp:2738-2774; recomputing them per precision keeps them out of memory)
                     Unfinished ufep;
                     // the refiner's sums of the pre-weighted member pixels (EndpointRefiner.h:78-92) do not depend on the indexes:
                     // the PCA's first pass forms the same sums in the same order, so a round takes them from here instead of
                     // adding them up pixel by pixel
                     float vsSubset[3];
-                    if (partitioned && aPrec != 11)
-                    {
-                        const u32 *src = scr + (size_t)(kScrPca + (p * 2 + subset) * 9) * 64;
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++)
-                        {
-                            ufep.base[ch] = __uint_as_float(src[ch * 64]);
-                            ufep.offset[ch] = __uint_as_float(src[(3 + ch) * 64]);
-                            vsSubset[ch] = __uint_as_float(src[(6 + ch) * 64]);
-                        }
-                    }
-                    else
-                        pcaSeeds(subsetMask, ufep, vsSubset, partitioned ? p * 2 + subset : -1);
+                    pcaSeeds(subsetMask, ufep, vsSubset);
 
                     PROF_MARK(0)
                     for (int tweak = 0; tweak < 4; tweak++)
@@ -449,9 +486,11 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 if (subset == 0) roundValid0 &= ~(1u << metaRound); else roundValid1 &= ~(1u << metaRound);
                                 // never written by the reference: the canonical build's zero-initialised automatics
                                 // (fresh for every partition, BC67.cpp:2797-2801), which later rounds compare against
-                                meta[kEpqBase + metaRound * 3][lane] = 0;
-                                meta[kEpqBase + metaRound * 3 + 1][lane] = 0;
-                                meta[kEpqBase + metaRound * 3 + 2][lane] = 0;
+                                // (the spare bits of such a round stay zero in xbits0 / xbits1)
+                                meta[epqEntry(subset, metaRound)][lane] = 0;
+                                meta[epqEntry(subset, metaRound) + 1][lane] = 0;
+                                if (!partitioned)
+                                    meta[epqEntry(subset, metaRound) + 2][lane] = 0;
                                 continue;
                             }
 
@@ -549,19 +588,54 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             }
                             else
                             {
+                                // An interpolant lies between the two finished end points (the interpolation, the
+                                // unscaling and the conversion are monotone), so when no lane's end point has a zero exponent
+                                // field no interpolant has one and the halving of TwosCLHalfToFloat is skipped (unsigned format)
+                                bool interpFixup = true;
+                                if (!SIGNED)
+                                {
+                                    int lowest = fin[0][0] < fin[1][0] ? fin[0][0] : fin[1][0];
 #pragma unroll
-                                for (int i = 0; i < indexRange; i++)
+                                    for (int ch = 1; ch < 3; ch++)
+                                    {
+                                        lowest = fin[0][ch] < lowest ? fin[0][ch] : lowest;
+                                        lowest = fin[1][ch] < lowest ? fin[1][ch] : lowest;
+                                    }
+                                    interpFixup = __ballot(lowest < 0x400) != 0;
+                                }
+                                if (interpFixup)
+                                {
+#pragma unroll
+                                    for (int i = 0; i < indexRange; i++)
                                     {
                                         const int weight = mad24(weightRcp, i, 256) >> 9;
 #pragma unroll
                                         for (int ch = 0; ch < 3; ch++)
                                             iw[i][ch] = twosCLHalfToFloat<SIGNED>(reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight)) * A.w[ch];
                                     }
+                                }
+                                else
+                                {
+#pragma unroll
+                                    for (int i = 0; i < indexRange; i++)
+                                    {
+                                        const int weight = mad24(weightRcp, i, 256) >> 9;
+#pragma unroll
+                                        for (int ch = 0; ch < 3; ch++)
+                                            iw[i][ch] = __half2float(__ushort_as_half((unsigned short)reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight))) * A.w[ch];
+                                    }
+                                }
+                            }
+                            int recBase[3], recDiff[3];
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++)
+                            {
+                                recBase[ch] = unq[0][ch] * 64 + 32;
+                                recDiff[ch] = unq[1][ch] - unq[0][ch];
                             }
                             // raw (un-inverted) index of the pixel packed in (a, b); SelectIndexHDRSlow keeps the FIRST minimum
-                            // lf: the pixel's three half values as floats (slow indexing only; the caller converts them once
-                            // and uses them for the error as well)
-                            auto rawIndexOf = [&](u32 a, u32 b, const float (&lf)[3]) -> int {
+                            // lwp: the pixel's weighted linear values (slow indexing only)
+                            auto rawIndexOf = [&](u32 a, u32 b, const float (&lwp)[3]) -> int {
                                 if (FAST)
                                 {
                                     const int c0 = (int)(short)(a & 0xffffu), c1 = (int)(short)(a >> 16), c2 = (int)(short)(b & 0xffffu);
@@ -570,9 +644,9 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     dist = dist + ((float)c2 - origin[2]) * axis[2];
                                     return (int)clampRound(dist, maxValue);
                                 }
-                                const float l0 = lf[0] * A.w[0];
-                                const float l1 = lf[1] * A.w[1];
-                                const float l2 = lf[2] * A.w[2];
+                                const float l0 = lwp[0];
+                                const float l1 = lwp[1];
+                                const float l2 = lwp[2];
                                 float be = 0.0f;
                                 int bi = 0;
 #pragma unroll
@@ -590,9 +664,11 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                         {
                                             // be = sseMin(be, e) with the index taken along on the same comparison (the errors
                                             // are sums of squares: no NaN, no -0, so equal values are equal bits)
+                                            // (the minimum as v_min_f32, the comparison only for the index: the select form made
+                                            // every step wait for the previous one's compare -> select, with a hazard nop between)
                                             const bool lt = e < be;
                                             bi = lt ? i : bi;
-                                            be = lt ? e : be;
+                                            be = __builtin_fminf(be, e);
                                         }
                                     }
                                 return bi;
@@ -610,9 +686,9 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             float fixLf[3] = {0.0f, 0.0f, 0.0f};
                             if (!FAST)
                             {
-                                fixLf[0] = pixelToFloat((int)(short)(fa & 0xffffu));
-                                fixLf[1] = pixelToFloat((int)(short)(fa >> 16));
-                                fixLf[2] = pixelToFloat((int)(short)(fb & 0xffffu));
+                                fixLf[0] = pixelToFloat((int)(short)(fa & 0xffffu)) * A.w[0];
+                                fixLf[1] = pixelToFloat((int)(short)(fa >> 16)) * A.w[1];
+                                fixLf[2] = pixelToFloat((int)(short)(fb & 0xffffu)) * A.w[2];
                             }
                             const int fixRaw = rawIndexOf(fetchPixel(fa), fetchPixel(fb), fixLf);
                             PROF_MARK(2)
@@ -627,9 +703,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     q[1][ch] = t;
                                 }
                             }
-                            const u32 qa = ((u32)q[0][0] & 0xffffu) | ((u32)q[0][1] << 16);
-                            const u32 qb = ((u32)q[0][2] & 0xffffu) | ((u32)q[1][0] << 16);
-                            const u32 qc = ((u32)q[1][1] & 0xffffu) | ((u32)q[1][2] << 16);
+                            u32 qa, qb, qc;
+                            packEPQ(q, qa, qb, qc);
                             bool needError = true; // wave-uniform
                             if (subset == 0)
                             {
@@ -645,20 +720,25 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     cand0 |= 1u << metaRound;
                             }
                             if (lazy)
-                            {
                                 needError = false;
-                                if (invert)
-                                    invBits |= 1u << (subset * 12 + metaRound);
-                            }
+                            if (invert)
+                                invBits |= 1u << (subset * 12 + metaRound);
                             // ---- duplicate-round test against every earlier meta round of this subset (group-wide) ----
                             // Only a group whose eight lanes ALL repeat an earlier round skips the round, so the first of the three
                             // words is compared alone, and the other two only if some group matches in it everywhere.
+                            const int epq0 = epqEntry(subset, 0), epqNow = epqEntry(subset, metaRound);
+                            const u32 xbPrev = subset == 0 ? xbits0 : xbits1;
                             bool anySame = false;
                             for (int prev = 0; prev < metaRound; prev++)
-                                anySame = anySame || (meta[kEpqBase + prev * 3][lane] == qa);
-                            meta[kEpqBase + metaRound * 3][lane] = qa;
-                            meta[kEpqBase + metaRound * 3 + 1][lane] = qb;
-                            meta[kEpqBase + metaRound * 3 + 2][lane] = qc;
+                                anySame = anySame || (meta[epq0 + prev * epqStride][lane] == qa);
+                            meta[epqNow][lane] = qa;
+                            meta[epqNow + 1][lane] = qb;
+                            if (partitioned)
+                            {
+                                if (subset == 0) xbits0 |= qc << (2 * metaRound); else xbits1 |= qc << (2 * metaRound);
+                            }
+                            else
+                                meta[epqNow + 2][lane] = qc;
                             bool groupAllSame = false;
                             if (metaRound > 0)
                             {
@@ -670,8 +750,10 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 {
                                     anySame = false;
                                     for (int prev = 0; prev < metaRound; prev++)
-                                        anySame = anySame || (meta[kEpqBase + prev * 3][lane] == qa && meta[kEpqBase + prev * 3 + 1][lane] == qb &&
-                                                              meta[kEpqBase + prev * 3 + 2][lane] == qc);
+                                    {
+                                        const u32 pc = partitioned ? ((xbPrev >> (2 * prev)) & 3u) : meta[epq0 + prev * epqStride + 2][lane];
+                                        anySame = anySame || (meta[epq0 + prev * epqStride][lane] == qa && meta[epq0 + prev * epqStride + 1][lane] == qb && pc == qc);
+                                    }
                                     groupAllSame = groupBits(__ballot(anySame), lane) == 0xffu;
                                 }
                             }
@@ -684,34 +766,29 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             else if (!needError && refinePass == numRefineRounds - 1)
                             {
                                 // nobody can use this round and no refine pass follows it
-                                errR[metaRound * 2 + subset] = FLT_MAX;
+                                errAt(metaRound, subset) = FLT_MAX;
                             }
                             else
                             {
-                                // ---- error, indexes and refiner sums in pixel order (BC67.cpp:2879-2909) ----
+                                // ---- error and refiner sums in pixel order (BC67.cpp:2879-2909); the indexes themselves are not kept ----
                                 float subsetError = needError ? 0.0f : FLT_MAX;
-                                u32 idxLo = 0, idxHi = 0;
 #pragma unroll
                                 for (int px = 0; px < 16; px++)
                                     if ((sm >> px) & 1u)
                                     {
                                         const u32 a = fetchPixel(pk01[px]), b = fetchPixel(pk2[px]);
                                         float lf[3] = {0.0f, 0.0f, 0.0f};
-                                        if (!FAST)
+                                        if (!FAST && needError)
                                         {
                                             lf[0] = pixelToFloat((int)(short)(a & 0xffffu));
                                             lf[1] = pixelToFloat((int)(short)(a >> 16));
                                             lf[2] = pixelToFloat((int)(short)(b & 0xffffu));
                                         }
                                         // (the anchor's scan has been done: its index decided the inversion)
-                                        const int raw = (px == fixupIndex) ? fixRaw : rawIndexOf(a, b, lf);
+                                        const int raw = (px == fixupIndex) ? fixRaw : rawIndexOf(a, b, lw[FAST ? 0 : px]);
                                         const int index = invert ? (indexRange - 1) - raw : raw;
-                                        if (px < 8)
-                                            idxLo |= (u32)index << (4 * px);
-                                        else
-                                            idxHi |= (u32)index << (4 * (px - 8));
 
-                                        const int weight = mad24(weightRcp, raw, 256) >> 9;
+                                        const int weight = (int)((mulU24((u32)raw, (u32)weightRcp) + 256u) >> 9);
                                         const int orig[3] = {(int)(short)(a & 0xffffu), (int)(short)(a >> 16), (int)(short)(b & 0xffffu)};
                                         if (needError)
                                         {
@@ -719,7 +796,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 #pragma unroll
                                         for (int ch = 0; ch < 3; ch++)
                                         {
-                                            const int rec = reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight);
+                                            const int rec = reconstructFrom<SIGNED>(recBase[ch], recDiff[ch], weight);
                                             float sq;
                                             if (FAST)
                                             {
@@ -758,22 +835,10 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     for (int ch = 0; ch < 3; ch++)
                                         vs[ch] = vsSubset[ch];
                                 }
-                                if (needError)
-                                {
-                                    scr[(kScrIdx + (subset * 12 + metaRound) * 2) * 64] = idxLo;
-                                    scr[(kScrIdx + (subset * 12 + metaRound) * 2 + 1) * 64] = idxHi;
-                                }
-                                errR[metaRound * 2 + subset] = subsetError;
+                                errAt(metaRound, subset) = subsetError;
                             }
                             PROF_MARK(4)
                         }
-                    }
-                    if (partitioned && subset == 0 && usable0 != 0)
-                    {
-                        // subset 1 reuses the LDS history; the legality pass reads subset 0's from scratch
-#pragma unroll 4
-                        for (int e = 0; e < 36; e++)
-                            scr[(kScrEpq0 + e) * 64] = meta[kEpqBase + e][lane];
                     }
                 }
 
@@ -790,10 +855,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                         const bool act = c0 != 0;
                         const int m0 = act ? __builtin_ctz(c0) : 0;
                         c0 &= c0 - 1u;
-                        const u32 a0 = scr[(kScrEpq0 + m0 * 3) * 64], b0 = scr[(kScrEpq0 + m0 * 3 + 1) * 64], cc0 = scr[(kScrEpq0 + m0 * 3 + 2) * 64];
                         int e0[2][3];
-                        e0[0][0] = (int)(short)(a0 & 0xffffu); e0[0][1] = (int)(short)(a0 >> 16); e0[0][2] = (int)(short)(b0 & 0xffffu);
-                        e0[1][0] = (int)(short)(b0 >> 16); e0[1][1] = (int)(short)(cc0 & 0xffffu); e0[1][2] = (int)(short)(cc0 >> 16);
+                        loadEPQ(0, m0, xbits0, e0); // (m0 differs from lane to lane: the entry index is per lane, the bank is the lane's)
                         const bool own0 = ownDeltaFits(e0, modeW0, aPrec);
                         const bool own1 = numModesHere > 1 && ownDeltaFits(e0, modeW1, aPrec);
                         const bool own2 = numModesHere > 2 && ownDeltaFits(e0, modeW2, aPrec);
@@ -803,9 +866,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             continue;
                         for (int m1 = 0; m1 < 12; m1++)
                         {
-                            const u32 a1 = meta[kEpqBase + m1 * 3][lane], b1 = meta[kEpqBase + m1 * 3 + 1][lane], c1 = meta[kEpqBase + m1 * 3 + 2][lane];
-                            const int x[2][3] = {{(int)(short)(a1 & 0xffffu), (int)(short)(a1 >> 16), (int)(short)(b1 & 0xffffu)},
-                                                 {(int)(short)(b1 >> 16), (int)(short)(c1 & 0xffffu), (int)(short)(c1 >> 16)}};
+                            int x[2][3];
+                            loadEPQ(1, m1, xbits1, x);
                             const bool in = act && ((roundValid1 >> m1) & 1u);
                             bool ok0 = in && own0, ok1 = in && own1, ok2 = in && own2;
                             const int mask = (1 << aPrec) - 1;
@@ -855,23 +917,12 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                         const int bit = __builtin_ctz(todo);
                         const int rs = bit >= 12 ? 1 : 0, rm = bit - 12 * rs;
                         const u32 rmask = opaqueUniform(rs ? partitionMask : (~partitionMask & 0xffffu));
-                        u32 ra, rb, rc;
-                        if (rs == 0)
-                        {
-                            ra = scr[(kScrEpq0 + rm * 3) * 64];
-                            rb = scr[(kScrEpq0 + rm * 3 + 1) * 64];
-                            rc = scr[(kScrEpq0 + rm * 3 + 2) * 64];
-                        }
-                        else
-                        {
-                            ra = meta[kEpqBase + rm * 3][lane];
-                            rb = meta[kEpqBase + rm * 3 + 1][lane];
-                            rc = meta[kEpqBase + rm * 3 + 2][lane];
-                        }
                         // the end points as the round had them before it swapped them (the scan's first-minimum rule sees the order)
                         const bool was = ((invBits >> bit) & 1u) != 0;
-                        const int s0[3] = {(int)(short)(ra & 0xffffu), (int)(short)(ra >> 16), (int)(short)(rb & 0xffffu)};
-                        const int s1[3] = {(int)(short)(rb >> 16), (int)(short)(rc & 0xffffu), (int)(short)(rc >> 16)};
+                        int rq[2][3];
+                        loadEPQ(rs, rm, rs ? xbits1 : xbits0, rq);
+                        const int (&s0)[3] = rq[0];
+                        const int (&s1)[3] = rq[1];
                         int unq[2][3], fin[2][3];
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++)
@@ -912,7 +963,6 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             }
                         }
                         float subsetError = 0.0f;
-                        u32 idxLo = 0, idxHi = 0;
 #pragma unroll 1
                         for (int px = 0; px < 16; px++)
                         {
@@ -955,15 +1005,10 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     e = e + d * d;
                                     const bool lt = (i == 0) || (e < be);
                                     raw = lt ? i : raw;
-                                    be = lt ? e : be;
+                                    be = (i == 0) ? e : __builtin_fminf(be, e);
                                 }
                             }
-                            const int index = was ? (indexRange - 1) - raw : raw;
-                            if (px < 8)
-                                idxLo |= (u32)index << (4 * px);
-                            else
-                                idxHi |= (u32)index << (4 * (px - 8));
-                            const int weight = mad24(weightRcp, raw, 256) >> 9;
+                            const int weight = (int)((mulU24((u32)raw, (u32)weightRcp) + 256u) >> 9);
                             const int orig[3] = {(int)(short)(a & 0xffffu), (int)(short)(a >> 16), (int)(short)(b & 0xffffu)};
                             float err = 0.0f;
 #pragma unroll
@@ -986,9 +1031,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             }
                             subsetError = subsetError + err;
                         }
-                        scr[(kScrIdx + (rs * 12 + rm) * 2) * 64] = idxLo;
-                        scr[(kScrIdx + (rs * 12 + rm) * 2 + 1) * 64] = idxHi;
-                        errR[rm * 2 + rs] = subsetError;
+                        errAt(rm, rs) = subsetError;
                     }
                 }
 
@@ -1003,7 +1046,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                     minErr1 = FLT_MAX;
                     for (int m = 0; m < 12; m++)
                     {
-                        const float e = errR[m * 2 + 1];
+                        const float e = errAt(m, 1);
                         if (((roundValid1 >> m) & 1u) && e < minErr1)
                             minErr1 = e;
                     }
@@ -1011,7 +1054,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                 for (int meta0 = 0; meta0 < 12; meta0++)
                 {
                     const bool valid0 = ((roundValid0 >> meta0) & 1u) != 0;
-                    const float err0 = errR[meta0 * 2];
+                    const float err0 = errAt(meta0, 0);
                     const bool canBeat = valid0 && ((partitioned ? err0 + minErr1 : err0) < bestError);
                     if (__ballot(canBeat) == 0)
                         continue;
@@ -1019,21 +1062,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                     int e0[2][3];
                     bool legal0[3] = {true, true, true};
                     {
-                        u32 a0, b0, c0;
-                        if (partitioned)
-                        {
-                            a0 = scr[(kScrEpq0 + meta0 * 3) * 64];
-                            b0 = scr[(kScrEpq0 + meta0 * 3 + 1) * 64];
-                            c0 = scr[(kScrEpq0 + meta0 * 3 + 2) * 64];
-                        }
-                        else
-                        {
-                            a0 = meta[kEpqBase + meta0 * 3][lane];
-                            b0 = meta[kEpqBase + meta0 * 3 + 1][lane];
-                            c0 = meta[kEpqBase + meta0 * 3 + 2][lane];
-                        }
-                        e0[0][0] = (int)(short)(a0 & 0xffffu); e0[0][1] = (int)(short)(a0 >> 16); e0[0][2] = (int)(short)(b0 & 0xffffu);
-                        e0[1][0] = (int)(short)(b0 >> 16); e0[1][1] = (int)(short)(c0 & 0xffffu); e0[1][2] = (int)(short)(c0 >> 16);
+                        loadEPQ(0, meta0, xbits0, e0);
                         legal0[0] = ownDeltaFits(e0, modeW0, aPrec);
                         if (numModesHere > 1)
                             legal0[1] = ownDeltaFits(e0, modeW1, aPrec);
@@ -1048,7 +1077,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                         const bool roundsOk = valid0 && (!partitioned || ((roundValid1 >> meta1) & 1u));
                         float combined = err0;
                         if (partitioned)
-                            combined = combined + errR[meta1 * 2 + 1];
+                            combined = combined + errAt(meta1, 1);
                         const bool errorBetter = roundsOk && (combined < bestError);
                         if (__ballot(errorBetter) == 0)
                             continue;
@@ -1058,12 +1087,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 
                         int e1[2][3] = {{0, 0, 0}, {0, 0, 0}};
                         if (partitioned)
-                        {
-                            const u32 a1 = meta[kEpqBase + meta1 * 3][lane], b1 = meta[kEpqBase + meta1 * 3 + 1][lane],
-                                      c1 = meta[kEpqBase + meta1 * 3 + 2][lane];
-                            e1[0][0] = (int)(short)(a1 & 0xffffu); e1[0][1] = (int)(short)(a1 >> 16); e1[0][2] = (int)(short)(b1 & 0xffffu);
-                            e1[1][0] = (int)(short)(b1 >> 16); e1[1][1] = (int)(short)(c1 & 0xffffu); e1[1][2] = (int)(short)(c1 >> 16);
-                        }
+                            loadEPQ(1, meta1, xbits1, e1);
 
                         for (int mi = 0; mi < numModesHere; mi++)
                         {
@@ -1111,14 +1135,6 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             const u32 gCommit = groupBits(__ballot(commit), lane);
                             if (__ballot(commit) != 0)
                             {
-                                // indexes: subset-0 pixels from round meta0, subset-1 pixels from meta1 (rare: a few commits per block)
-                                const u32 lo0 = scr[(kScrIdx + meta0 * 2) * 64], hi0 = scr[(kScrIdx + meta0 * 2 + 1) * 64];
-                                u32 lo1 = 0, hi1 = 0;
-                                if (partitioned)
-                                {
-                                    lo1 = scr[(kScrIdx + (12 + meta1) * 2) * 64];
-                                    hi1 = scr[(kScrIdx + (12 + meta1) * 2 + 1) * 64];
-                                }
                                 if (commit)
                                 {
                                     bestError = combined;
@@ -1133,8 +1149,9 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                         bestEP[4] = ((u32)enc[1][0][2] & 0xffffu) | ((u32)enc[1][1][0] << 16);
                                         bestEP[5] = ((u32)enc[1][1][1] & 0xffffu) | ((u32)enc[1][1][2] << 16);
                                     }
-                                    bestIdxLo = lo0 | lo1; // the two subsets' pixels are disjoint nibbles
-                                    bestIdxHi = hi0 | hi1;
+                                    // (the indexes of the two rounds are selected again after the search, from these end
+                                    // points in the order the rounds had them)
+                                    bestSwap = ((invBits >> meta0) & 1u) | (partitioned ? ((invBits >> (12 + meta1)) & 1u) << 1 : 0u);
                                     needsCommit = false;
                                 }
                             }
@@ -1154,6 +1171,122 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 
     PROF_MARK(5)
     PROF_FLUSH
+    // ---- the winner's indexes, selected again from its end points.  A round's indexes are a function of its quantised end
+    // points in the order it had them before the anchor swap, of the precision and of the pixels (QuantizeEndpoints* +
+    // SelectIndexHDR*, BC67.cpp:2503-2595, 2879-2893): the same operations on the same values here, once per block, instead of
+    // 48 words of index history per partition and precision in memory. ----
+    u32 bestIdxLo = 0, bestIdxHi = 0;
+    {
+        const bool partitionedB = T->bc6hModeInfo[bestMode][1] != 0;
+        const int aPrecB = (int)T->bc6hModeInfo[bestMode][3];
+        const bool transformedB = T->bc6hModeInfo[bestMode][2] != 0;
+        const u32 pmask = partitionedB ? T->partition2[bestPartition & 31] : 0u;
+        const int rangeB = partitionedB ? 8 : 16;
+        const int weightRcpB = partitionedB ? 4681 : 2185;
+        const float maxValueB = (float)(rangeB - 1);
+        const int enc[2][2][3] = {
+            {{(int)(short)(bestEP[0] & 0xffffu), (int)(short)(bestEP[0] >> 16), (int)(short)(bestEP[1] & 0xffffu)},
+             {(int)(short)(bestEP[1] >> 16), (int)(short)(bestEP[2] & 0xffffu), (int)(short)(bestEP[2] >> 16)}},
+            {{(int)(short)(bestEP[3] & 0xffffu), (int)(short)(bestEP[3] >> 16), (int)(short)(bestEP[4] & 0xffffu)},
+             {(int)(short)(bestEP[4] >> 16), (int)(short)(bestEP[5] & 0xffffu), (int)(short)(bestEP[5] >> 16)}}};
+        // the quantised end points: a transformed mode stores deltas whose sum with the base equals the end point in its low
+        // aPrec bits (the legality test, BC67.cpp:2597-2663), and an end point has no other bits (sign-extended when signed)
+        int unqB[2][2][3], finB[2][2][3];
+        const int maskB = (1 << aPrecB) - 1;
+#pragma unroll
+        for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+            {
+                int qv[2];
+#pragma unroll
+                for (int epi = 0; epi < 2; epi++)
+                {
+                    int v = enc[sb][epi][ch];
+                    if (transformedB && (sb != 0 || epi != 0))
+                    {
+                        v = (v + enc[0][0][ch]) & maskB;
+                        if (SIGNED)
+                            v = (int)((u32)v << (32 - aPrecB)) >> (32 - aPrecB);
+                    }
+                    qv[epi] = v;
+                }
+                const bool sw = ((bestSwap >> sb) & 1u) != 0; // back to the order the round selected its indexes in
+                const int q0 = sw ? qv[1] : qv[0], q1 = sw ? qv[0] : qv[1];
+                unqB[sb][0][ch] = SIGNED ? unquantizeSigned(q0, aPrecB, finB[sb][0][ch]) : unquantizeUnsigned(q0, aPrecB, finB[sb][0][ch]);
+                unqB[sb][1][ch] = SIGNED ? unquantizeSigned(q1, aPrecB, finB[sb][1][ch]) : unquantizeUnsigned(q1, aPrecB, finB[sb][1][ch]);
+            }
+        float originB[2][3], axisB[2][3];
+        if (FAST)
+        {
+#pragma unroll
+            for (int sb = 0; sb < 2; sb++)
+            {
+                float epDW[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    originB[sb][ch] = (float)finB[sb][0][ch];
+                    epDW[ch] = ((float)finB[sb][1][ch] - originB[sb][ch]) * A.w[ch];
+                }
+                float lenSq = epDW[0] * epDW[0];
+                lenSq = lenSq + epDW[1] * epDW[1];
+                lenSq = lenSq + epDW[2] * epDW[2];
+                lenSq = safeDenom(lenSq);
+                const float mvdls = maxValueB / lenSq;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                    axisB[sb][ch] = epDW[ch] * A.w[ch] * mvdls;
+            }
+        }
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+        {
+            const bool s1 = ((pmask >> px) & 1u) != 0;
+            const u32 a = fetchPixel(pk01[px]), b = fetchPixel(pk2[px]);
+            const int c[3] = {(int)(short)(a & 0xffffu), (int)(short)(a >> 16), (int)(short)(b & 0xffffu)};
+            int raw = 0;
+            if (FAST)
+            {
+                float dist = ((float)c[0] - (s1 ? originB[1][0] : originB[0][0])) * (s1 ? axisB[1][0] : axisB[0][0]);
+                dist = dist + ((float)c[1] - (s1 ? originB[1][1] : originB[0][1])) * (s1 ? axisB[1][1] : axisB[0][1]);
+                dist = dist + ((float)c[2] - (s1 ? originB[1][2] : originB[0][2])) * (s1 ? axisB[1][2] : axisB[0][2]);
+                raw = (int)clampRound(dist, maxValueB);
+            }
+            else
+            {
+                int e0[3], e1[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    e0[ch] = s1 ? unqB[1][0][ch] : unqB[0][0][ch];
+                    e1[ch] = s1 ? unqB[1][1][ch] : unqB[0][1][ch];
+                }
+                const float l0 = lw[FAST ? 0 : px][0], l1 = lw[FAST ? 0 : px][1], l2 = lw[FAST ? 0 : px][2];
+                float be = 0.0f;
+#pragma unroll 1
+                for (int i = 0; i < 16; i++)
+                {
+                    const int weight = mad24(weightRcpB, i, 256) >> 9;
+                    float d = l0 - twosCLHalfToFloat<SIGNED>(reconstructChannel<SIGNED>(e0[0], e1[0], weight)) * A.w[0];
+                    float e = d * d;
+                    d = l1 - twosCLHalfToFloat<SIGNED>(reconstructChannel<SIGNED>(e0[1], e1[1], weight)) * A.w[1];
+                    e = e + d * d;
+                    d = l2 - twosCLHalfToFloat<SIGNED>(reconstructChannel<SIGNED>(e0[2], e1[2], weight)) * A.w[2];
+                    e = e + d * d;
+                    const bool lt = (i == 0) || (i < rangeB && e < be);
+                    raw = lt ? i : raw;
+                    be = lt ? e : be;
+                }
+            }
+            const bool sw = ((bestSwap >> (s1 ? 1 : 0)) & 1u) != 0;
+            const u32 index = (u32)(sw ? (rangeB - 1) - raw : raw);
+            if (px < 8)
+                bestIdxLo |= index << (4 * px);
+            else
+                bestIdxHi |= index << (4 * (px - 8));
+        }
+    }
     // ---- header scatter + indexes (BC67.cpp:2992-3050, BC6H_IO: table from tools/gen_bc6h_layout.py) ----
     if (valid)
     {
@@ -1217,19 +1350,14 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
     }
 }
 
-extern "C" size_t cvttmi_bc6h_scratch_bytes(uint32_t numBlocks)
-{
-    return (size_t)((numBlocks + 63u) / 64u) * kScratchDwords * 64 * sizeof(u32);
-}
-
 extern "C" hipError_t cvttmi_launch_bc6h(const void *d_blocks, void *d_out, const CvttBc6hArgs *args,
-                                         const CvttDeviceTables *d_tables, int isSigned, void *d_scratch, hipStream_t stream)
+                                         const CvttDeviceTables *d_tables, int isSigned, hipStream_t stream)
 {
     const uint32_t waves = (args->numBlocks + 63u) / 64u;
     if (waves == 0)
         return hipSuccess;
     const bool fast = (args->flags & CVTTMI_FLAG_BC6H_FAST_INDEXING) != 0;
-#define CVTT_LAUNCH(S, Fq) hipLaunchKernelGGL((cvttmi_bc6h_kernel<S, Fq>), dim3(waves), dim3(64), 0, stream, (const uint8_t *)d_blocks, (uint8_t *)d_out, *args, d_tables, (u32 *)d_scratch)
+#define CVTT_LAUNCH(S, Fq) hipLaunchKernelGGL((cvttmi_bc6h_kernel<S, Fq>), dim3(waves), dim3(64), 0, stream, (const uint8_t *)d_blocks, (uint8_t *)d_out, *args, d_tables)
     if (isSigned)
     {
         if (fast) CVTT_LAUNCH(true, true); else CVTT_LAUNCH(true, false);

@@ -46,8 +46,7 @@ extern "C" hipError_t cvttmi_launch_bc1(const void *d_blocks, void *d_out, const
                                         const CvttDeviceTables *d_tables, hipStream_t stream);
 
 extern "C" hipError_t cvttmi_launch_bc6h(const void *d_blocks, void *d_out, const CvttBc6hArgs *args,
-                                         const CvttDeviceTables *d_tables, int isSigned, void *d_scratch, hipStream_t stream);
-extern "C" size_t cvttmi_bc6h_scratch_bytes(uint32_t numBlocks);
+                                         const CvttDeviceTables *d_tables, int isSigned, hipStream_t stream);
 
 extern "C" hipError_t cvttmi_launch_etc2(const void *d_blocks, void *d_out, const CvttEtcArgs *args,
                                          const CvttDeviceTables *d_tables, int mode, hipStream_t stream);
@@ -97,13 +96,12 @@ struct cvttmi_context
     hipEvent_t evLast;
     hipStream_t lastStream;
     bool lastValid;
-    void *dScratch;       // kernel work space (BC6H endpoint history), grown on demand
-    size_t dScratchBytes;
-    float *dPtTrial;      // BC7_RespectPunchThrough with more than 6 refine rounds: the trial-error table of a launch's waves
+    float *dPtTrial;      // BC7_RespectPunchThrough with more than 2 refine rounds (kMaxPTRefine of bc7_kernel.hip): the trial-error table of a launch's waves
     size_t dPtTrialBytes;
+    size_t ptTableBytes;  // cap of that table per launch (256 MB; CVTTMI_BC7_PT_TABLE_KB, read when the context is created)
     bool exhaustive; // search every candidate even when it provably cannot win
     // BC7: blocks with many live mode-7 partitions are finished by a second launch (bc7_kernel.hip, HARD).
-    // One set of buffers per context, like dScratch: launches of one context are expected on one stream at a time.
+    // One set of buffers per context: launches of one context are expected on one stream at a time.
     static const uint32_t kHardSlots = 8192;
     uint32_t *dHardCount;
     CvttBc7HardRec *dHardRec;
@@ -325,7 +323,8 @@ namespace
         {
             // more distinct streams than entries: the first entry's launch is waited for and the entry taken over
             use = &ctx->planUse[slot][0];
-            (void)hipEventSynchronize(use->ev);
+            if (hipEventSynchronize(use->ev) != hipSuccess)
+                (void)hipDeviceSynchronize(); // the entry's launch cannot be waited for by its event: wait for everything
         }
         if (!use->ev && hipEventCreateWithFlags(&use->ev, hipEventDisableTiming) != hipSuccess)
         {
@@ -390,30 +389,35 @@ namespace
         }
         return attr.type == hipMemoryTypeHost;
     }
-    // ... the WHOLE range [p, p + bytes): one allocation that covers it (hipMemGetAddressRange), else -- registered memory
-    // the runtime gives no range for -- both ends and a probe every 64 KiB in between (a buffer registered in parts with
-    // pageable holes smaller than that is not something a caller gets by accident)
+    // ... the WHOLE range [p, p + bytes): walked allocation by allocation.  Every piece must be page-locked memory for which
+    // the runtime reports the covering range (hipMemGetAddressRange on its device alias); the walk continues at the end of
+    // that range.  A byte the runtime gives no range for ends the walk with "not pinned", and the caller's buffer goes
+    // through the staged copies instead of being read in place by the kernel (a pageable hole inside a buffer registered
+    // in parts would otherwise be a GPU page fault).  One or two runtime calls per registration, whatever the size.
     bool isPinnedHostRange(const void *p, size_t bytes)
     {
-        if (bytes == 0 || !isPinnedHost(p))
+        if (bytes == 0)
             return false;
         const uint8_t *b = static_cast<const uint8_t *>(p);
-        hipDeviceptr_t base = NULL;
-        size_t size = 0;
-        void *dev = NULL;
-        if (hipHostGetDevicePointer(&dev, const_cast<void *>(p), 0) == hipSuccess && hipMemGetAddressRange(&base, &size, dev) == hipSuccess)
+        size_t off = 0;
+        for (int pieces = 0; off < bytes; pieces++)
         {
+            if (pieces > 4096 || !isPinnedHost(b + off))
+                return false;
+            hipDeviceptr_t base = NULL;
+            size_t size = 0;
+            void *dev = NULL;
+            if (hipHostGetDevicePointer(&dev, const_cast<uint8_t *>(b + off), 0) != hipSuccess || hipMemGetAddressRange(&base, &size, dev) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                return false;
+            }
             const uint8_t *lo = static_cast<const uint8_t *>(static_cast<void *>(base));
             const uint8_t *d = static_cast<const uint8_t *>(dev);
-            if (d >= lo && d + bytes <= lo + size)
-                return true;
-        }
-        (void)hipGetLastError();
-        if (!isPinnedHost(b + bytes - 1))
-            return false;
-        for (size_t off = 65536; off < bytes; off += 65536)
-            if (!isPinnedHost(b + off))
+            if (d < lo || d >= lo + size)
                 return false;
+            off += (size_t)(lo + size - d);
+        }
         return true;
     }
 
@@ -713,8 +717,6 @@ extern "C"
         ctx->evLast = ctx->evStart = ctx->evStop = NULL;
         ctx->lastStream = NULL;
         ctx->lastValid = false;
-        ctx->dScratch = NULL;
-        ctx->dScratchBytes = 0;
         ctx->dPtTrial = NULL;
         ctx->dPtTrialBytes = 0;
         ctx->timing = false;
@@ -725,6 +727,7 @@ extern "C"
         ctx->dHardRec = NULL;
         ctx->dHardCand = NULL;
         ctx->lastHardCap = 0;
+        ctx->ptTableBytes = getenv("CVTTMI_BC7_PT_TABLE_KB") ? (size_t)atol(getenv("CVTTMI_BC7_PT_TABLE_KB")) << 10 : (size_t)256 << 20;
         ctx->hardMin = getenv("CVTTMI_BC7_HARD_MIN") ? atoi(getenv("CVTTMI_BC7_HARD_MIN")) : 8;
         ctx->hardDiv = getenv("CVTTMI_BC7_HARD_DIV") ? atoi(getenv("CVTTMI_BC7_HARD_DIV")) : 128;
         if (ctx->hardDiv < 1)
@@ -767,7 +770,6 @@ extern "C"
         if (ctx->dPlans) (void)hipFree(ctx->dPlans);
         if (ctx->pinnedPlans) (void)hipHostFree(ctx->pinnedPlans);
         freePipe(ctx);
-        if (ctx->dScratch) (void)hipFree(ctx->dScratch);
         if (ctx->dPtTrial) (void)hipFree(ctx->dPtTrial);
         if (ctx->dHardCount) (void)hipFree(ctx->dHardCount);
         if (ctx->dHardRec) (void)hipFree(ctx->dHardRec);
@@ -1103,7 +1105,7 @@ extern "C"
         if ((options->flags & CVTTMI_FLAG_BC7_RESPECT_PUNCHTHROUGH) && options->refineRoundsBC7 > 2) // kMaxPTRefine of bc7_kernel.hip
         {
             const size_t perWave = (size_t)32 * 16 * sizeof(float) * (size_t)options->refineRoundsBC7;
-            size_t wavesPerLaunch = ((size_t)256 << 20) / perWave;
+            size_t wavesPerLaunch = ctx->ptTableBytes / perWave; // 256 MB; developer knob CVTTMI_BC7_PT_TABLE_KB (tests: several launches)
             wavesPerLaunch = wavesPerLaunch < 1 ? 1 : wavesPerLaunch;
             const size_t wavesNeeded = (numBlocks + 15) / 16;
             wavesPerLaunch = wavesPerLaunch > wavesNeeded ? wavesNeeded : wavesPerLaunch;
@@ -1137,7 +1139,13 @@ extern "C"
             args.numBlocks = static_cast<uint32_t>(n);
             e = cvttmi_launch_bc7(static_cast<const uint8_t *>(d_blocks) + first * 64, static_cast<uint8_t *>(d_out) + first * 16, &args, ctx->dTables, dPlan, stream);
             if (e != hipSuccess)
+            {
+                // launches queued before this one still read the plan slot, the trial table and the hand-over list: nothing
+                // may rewrite those before they have finished
+                if (first != 0)
+                    (void)hipStreamSynchronize(stream);
                 return fail(ctx, CVTTMI_E_HIP, "bc7 kernel launch", e);
+            }
         }
         if (args.hardCap || args.ptTrial)
             markLaunch(ctx, stream);
@@ -1324,32 +1332,14 @@ extern "C"
             return fail(ctx, CVTTMI_E_NO_DEVICE, "hipSetDevice", e);
         hipStream_t stream = static_cast<hipStream_t>(hipStream);
         std::lock_guard<std::recursive_mutex> lock(ctx->mu);
-        orderAfterPrevious(ctx, stream); // the endpoint-history scratch exists once per context
+        // (the search keeps its whole state on the chip: no work buffer, nothing shared between calls or streams)
         CvttBc6hArgs args;
         fillWeightArgs(options, args.w, args.wSq, args.rcpW);
         args.flags = options->flags;
         args.refineRounds = options->refineRoundsBC6H;
         args.seedPoints = options->seedPoints;
-        // the endpoint-history scratch is sized for one launch (21.5 KB per wave of 64 blocks); large batches go in chunks of
-        // 2^20 blocks (352 MB of scratch, allocated on first use) on the same stream.  A chunk should be many waves per SIMD:
-        // launches are stream-ordered, so every chunk ends with a tail in which the SIMDs run empty -- 2^18-block chunks
-        // (4 096 waves = one generation at 4 waves per SIMD) measured 4.31 Mblocks/s on 4096^2, 2^20-block chunks 4.95.
-        static const int bc6hChunkLog2 = getenv("CVTTMI_BC6H_CHUNK_LOG2") ? atoi(getenv("CVTTMI_BC6H_CHUNK_LOG2")) : 20;
-        const size_t kChunk = (size_t)1 << (bc6hChunkLog2 < 12 ? 12 : bc6hChunkLog2 > 24 ? 24 : bc6hChunkLog2);
-        const size_t need = cvttmi_bc6h_scratch_bytes(static_cast<uint32_t>(numBlocks < kChunk ? numBlocks : kChunk));
-        if (ctx->dScratchBytes < need)
-        {
-            if (ctx->dScratch)
-            {
-                hipDeviceSynchronize();
-                hipFree(ctx->dScratch);
-                ctx->dScratch = NULL;
-                ctx->dScratchBytes = 0;
-            }
-            if ((e = hipMalloc(&ctx->dScratch, need)) != hipSuccess)
-                return fail(ctx, CVTTMI_E_HIP, "hipMalloc(scratch)", e);
-            ctx->dScratchBytes = need;
-        }
+        // one launch per 2^28 blocks (the grid is blocks / 64 workgroups)
+        const size_t kChunk = (size_t)1 << 28;
         if (ctx->timing)
             hipEventRecord(ctx->evStart, stream);
         for (size_t first = 0; first < numBlocks; first += kChunk)
@@ -1357,11 +1347,10 @@ extern "C"
             const size_t n = (numBlocks - first) < kChunk ? (numBlocks - first) : kChunk;
             args.numBlocks = static_cast<uint32_t>(n);
             e = cvttmi_launch_bc6h(static_cast<const uint8_t *>(d_blocks) + first * 128, static_cast<uint8_t *>(d_out) + first * 16,
-                                   &args, ctx->dTables, isSigned, ctx->dScratch, stream);
+                                   &args, ctx->dTables, isSigned, stream);
             if (e != hipSuccess)
                 return fail(ctx, CVTTMI_E_HIP, "bc6h kernel launch", e);
         }
-        markLaunch(ctx, stream);
         if (ctx->timing)
         {
             hipEventRecord(ctx->evStop, stream);

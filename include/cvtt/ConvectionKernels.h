@@ -129,11 +129,9 @@ namespace cvtt
         void ConfigureBC7EncodingPlanFromQuality(BC7EncodingPlan &encodingPlan, int quality);
         bool ConfigureBC7EncodingPlanFromFineTuningParams(BC7EncodingPlan &encodingPlan, const BC7FineTuningParams &params);
 
-        // Deviation from the reference (documented): the reference derives the two chroma axes of the planar
-        // search from the weights of the Options given HERE (ETC.cpp:3117-3145) and keeps them in the data block; this
-        // library derives them from the Options of every Encode call (the GPU keeps no per-caller block).  The output is
-        // bit-identical whenever the red/green/blue weights at allocation and at encoding are equal -- the only use
-        // the reference's own caller makes of it (etc2packer.cpp:215-281).
+        // As in the reference (ETC.cpp:3117-3145) the two chroma axes of the T / H sector split belong to the Options given
+        // HERE: the block AllocETC2Data returns keeps them, and EncodeETC2 / EncodeETC2RGBA / EncodeETC2PunchthroughAlpha use
+        // them together with the error weights of the Options of the Encode call (cvttmi_encode_etc2_with_data).
         ETC2CompressionData *AllocETC2Data(allocFunc_t allocFunc, void *context, const Options &options);
         void ReleaseETC2Data(ETC2CompressionData *compressionData, freeFunc_t freeFunc);
         ETC1CompressionData *AllocETC1Data(allocFunc_t allocFunc, void *context);

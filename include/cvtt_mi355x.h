@@ -143,7 +143,7 @@ int cvttmi_host_unregister(cvttmi_context *ctx, void *ptr);
  * Streams: a context owns ONE set of device work space (BC7 hand-over list, punch-through trial table and plan ring,
  * BC6H endpoint history and PCA seeds: 169 KB per 64 blocks of a launch, i.e. 2.8 GB of HBM for launches of 2^20 blocks,
  * allocated on the first BC6H call; CVTTMI_BC6H_CHUNK_LOG2 in the environment bounds the launch size).  The calls that use it (EncodeBC7 from half a million blocks or with BC7_RespectPunchThrough and
- * more than 6 refine rounds, EncodeBC6H) are ordered by the library itself: such a call on another stream than the
+ * more than 2 refine rounds, EncodeBC6H) are ordered by the library itself: such a call on another stream than the
  * previous one first makes its stream wait (hipStreamWaitEvent) for that call's launches; a plan slot is rewritten only
  * after every launch that read it, on whatever stream, has finished.  Calls that use no shared work space (BC1-BC5, ETC,
  * EAC, decode, tiling) are simply queued on the stream given.  A mutex serialises the host side of EVERY call on a

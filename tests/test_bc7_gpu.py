@@ -142,10 +142,9 @@ def test_device_tensor_path_and_ragged_sizes(gpu_ctx, oracle_lib):
 
 
 def test_respect_punchthrough_many_refine_rounds(gpu_ctx, oracle_lib):
-    """BC7_RespectPunchThrough with more refine rounds than the LDS trial table holds (6): the reference clamps
-    refineRoundsBC7 only from below (BC67.cpp:1044-1045), so 7 and 9 rounds must work too -- the table moves to HBM and a
-    large call goes in several launches (the second shape: enough blocks for two launches at 9 rounds is too slow for a
-    test, so the chunking is exercised through the table size knob of the shim's arithmetic: 512 blocks = 32 waves)"""
+    """BC7_RespectPunchThrough with more refine rounds than the LDS trial table holds (2, kMaxPTRefine): the reference clamps
+    refineRoundsBC7 only from below (BC67.cpp:1044-1045), so 7, 9 and 12 rounds must work too -- the table moves to HBM.  (One
+    launch here; test_respect_punchthrough_chunked_launches splits such a call.)"""
     api = _api()
     rcp = oracle_lib.probe_rcp()
     gpu_ctx.set_rcp_table(rcp)
@@ -163,6 +162,31 @@ def test_respect_punchthrough_many_refine_rounds(gpu_ctx, oracle_lib):
     opt = api.Options(flags=api.Flags.Default | PTF)
     exp = oracle_lib.encode_bc7(blocks, np.frombuffer(opt.tobytes(), np.uint8).copy(), np.frombuffer(plan.tobytes(), np.uint8).copy(), rcp, threads=8)
     assert _diff(gpu_ctx.encode_bc7(blocks, opt, plan), exp).size == 0
+
+
+def test_respect_punchthrough_chunked_launches(oracle_lib, monkeypatch):
+    """The same path when the HBM trial table does not hold the whole call: the shim sizes its launches for 256 MB of table;
+    the developer knob CVTTMI_BC7_PT_TABLE_KB (read when a context is created) makes 504 blocks = 31.5 waves go in four
+    launches of 10 + 10 + 10 + 1.5 waves -- per-launch input / output offsets, a ragged last chunk that is not a multiple of
+    16 blocks, and the table reused from launch to launch."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    api = _api()
+    monkeypatch.setenv("CVTTMI_BC7_PT_TABLE_KB", "140")  # 7 rounds: 14 KB per wave -> 10 waves per launch
+    ctx = api.Context(0)
+    monkeypatch.delenv("CVTTMI_BC7_PT_TABLE_KB")
+    rcp = oracle_lib.probe_rcp()
+    ctx.set_rcp_table(rcp)
+    blocks = np.concatenate([content.mixed_ldr_blocks(4242, 40), content.mixed_ldr_blocks(9, 24)[::-1]])[:504]
+    plan = api.BC7EncodingPlan()
+    PTF = api.Flags.BC7_RespectPunchThrough
+    for opt in (api.Options(flags=api.Flags.Default | PTF, refineRoundsBC7=7), api.Options(flags=api.Flags.Better | PTF, refineRoundsBC7=3)):
+        exp = oracle_lib.encode_bc7(blocks, np.frombuffer(opt.tobytes(), np.uint8).copy(),
+                                    np.frombuffer(plan.tobytes(), np.uint8).copy(), rcp, threads=8)
+        out = ctx.encode_bc7(blocks, opt, plan)
+        bad = _diff(out, exp)
+        assert bad.size == 0, "flags %x refine %d blocks %s" % (opt.flags, opt.refineRoundsBC7, bad[:8])
 
 
 def test_respect_punchthrough(gpu_ctx, oracle_lib):

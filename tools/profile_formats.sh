@@ -8,16 +8,24 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG/fmt
 mkdir -p $OUT
 : > $OUT/fmt_bench.jsonl
+if [ -z "$PROFILE_SKIP_BENCH" ]; then
 for spec in "bc7 4096" "bc7o 4096" "bc7b 4096" "bc7photo 2048" "bc7grad 2048" "bc7two 2048" "bc1 4096" "bc1x 2048" "bc2 4096" "bc3 4096" "bc4 4096" "bc5 4096" "bc6hu 4096" "bc6hs 2048" "etc1 2048" "etc2 4096" "etc2rgba 4096" "etc2pt 2048" "eac 4096"; do
   set -- $spec
   python tools/fmt_bench.py $1 $2 3 >> $OUT/fmt_bench.jsonl 2>> $OUT/fmt_bench.err
 done
+fi
 cat $OUT/fmt_bench.jsonl
-for spec in "bc1 4096" "bc6hu 4096" "etc2rgba 4096" "bc7o 4096" "bc7photo 2048"; do
+# PROFILE_FORMATS="bc6hu:4096,bc7o:4096" restricts the counter passes
+IFS=',' read -ra SPECS <<< "${PROFILE_FORMATS:-bc1:4096,bc6hu:4096,etc2rgba:4096,bc7o:4096,bc7b:4096,bc7photo:2048}"
+for spec in "${SPECS[@]}"; do
+  spec=${spec/:/ }
   set -- $spec
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$1 -o $1 -- python tools/fmt_bench.py $1 $2 3 > $OUT/trace_$1.log 2>&1
   rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_$1 -o $1 -- python tools/fmt_bench.py $1 $2 1 > $OUT/pmc_$1.log 2>&1
   rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d $OUT/pmc2_$1 -o $1 -- python tools/fmt_bench.py $1 $2 1 > $OUT/pmc2_$1.log 2>&1
+  # HBM traffic: FETCH_SIZE and WRITE_SIZE in passes of their own (MI355X_MICROARCH.md, HBM / rocprofv3 section)
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmcf_$1 -o $1 -- python tools/fmt_bench.py $1 $2 1 > $OUT/pmcf_$1.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmcw_$1 -o $1 -- python tools/fmt_bench.py $1 $2 1 > $OUT/pmcw_$1.log 2>&1
   cat $OUT/trace_$1/*kernel_stats.csv | head -4
 done
 python tools/summarize_fmt_pmc.py $OUT > /dev/null

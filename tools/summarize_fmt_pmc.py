@@ -49,6 +49,24 @@ for d in sorted(glob.glob(os.path.join(out_dir, "pmc_*"))):
                 waves = last[kname]["grid"] / 64
                 last[kname]["mem"] = {k: round(v / waves, 1) for k, v in c2.items()}
                 last[kname]["mem_note"] = "per wave"
+    # third / fourth pass: HBM traffic (FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a
+    # wide coalesced stream -> doubled, as tools/summarize_pmc.py does for the headline)
+    tr = {}
+    for sub, cname in (("pmcf_", "FETCH_SIZE"), ("pmcw_", "WRITE_SIZE")):
+        f3 = glob.glob(os.path.join(out_dir, sub + fmt, "*counter_collection.csv"))
+        if not f3:
+            continue
+        d3 = {}
+        for r in csv.DictReader(open(f3[0])):
+            if "cvttmi" in r["Kernel_Name"] and r["Counter_Name"] == cname:
+                k3 = (r["Kernel_Name"].split("(")[0], r["Dispatch_Id"])
+                d3[k3] = d3.get(k3, 0.0) + float(r["Counter_Value"])
+        for (kname, _), v in d3.items():  # dispatches in order: the last one of each kernel stays
+            tr.setdefault(kname, {})[cname] = v
+    for kname, c3 in tr.items():
+        if kname in last and "FETCH_SIZE" in c3 and "WRITE_SIZE" in c3:
+            last[kname]["hbm"] = {"fetch_kib_raw": c3["FETCH_SIZE"], "write_kib_raw": c3["WRITE_SIZE"],
+                                  "bytes_corrected": (2 * c3["FETCH_SIZE"] + c3["WRITE_SIZE"]) * 1024}
     summary[fmt] = list(last.values())
     st = glob.glob(os.path.join(out_dir, "trace_" + fmt, "*kernel_stats.csv"))
     if st:
