@@ -228,14 +228,18 @@ __device__ __forceinline__ u32 groupBits(u64 ballot, int lane) { return (u32)(ba
 } // namespace
 
 template <bool SIGNED, bool FAST>
-__global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+#ifndef CVTT_BC6H_WG_WAVES
+#define CVTT_BC6H_WG_WAVES 1 // waves per workgroup (independent of each other: each has its own 18 KB of the LDS block)
+#endif
+__global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC6H_WG_WAVES - 1) / CVTT_BC6H_WG_WAVES) void cvttmi_bc6h_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
                                                          const CvttBc6hArgs A, const CvttDeviceTables *__restrict__ T)
 {
-    __shared__ u32 meta[kMetaDwords][64];
-    const int lane = threadIdx.x;
+    __shared__ u32 metaAll[CVTT_BC6H_WG_WAVES][kMetaDwords][64];
+    u32 (&meta)[kMetaDwords][64] = metaAll[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
     // error of round m of subset s of the current partition (indexed by wave-uniform loop counters)
     auto errAt = [&](int m, int s) -> float & { return reinterpret_cast<float &>(meta[kErrBase + m * 2 + s][lane]); };
-    const u32 blockIndex = blockIdx.x * 64u + (u32)lane;
+    const u32 blockIndex = blockIdx.x * (64u * CVTT_BC6H_WG_WAVES) + threadIdx.x;
     const bool valid = blockIndex < A.numBlocks;
 
     PROF_DECL
@@ -291,19 +295,33 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
         return f;
     };
 
-    // slow indexing: the weighted linear value of every pixel channel (floatPixelsLinearWeighted, BC67.cpp:2711), what the
-    // interpolant scan compares with; 48 of the 256 registers two waves per SIMD leave a lane
-    float lw[FAST ? 1 : 16][3];
-    if (!FAST)
-    {
-#pragma unroll
-        for (int px = 0; px < 16; px++)
+    // slow indexing: the linear value of every pixel channel (TwosCLHalfToFloat of the pixel, BC67.cpp:2711), converted once:
+    // the error takes it as it is, the interpolant scan its product with the channel weight (floatPixelsLinearWeighted; a
+    // plain multiplication per use).  48 of the 256 registers two waves per SIMD leave a lane.
+    // (filled between the single-subset search, whose sixteen-entry interpolant table needs the registers, and the
+    // partitioned one; the single-subset search converts per use)
+    float lf[FAST ? 1 : 16][3];
+    // the three linear values of a pixel converted on the spot, with ONE wave-uniform branch around the rare halvings
+    auto pixelLinear = [&](u32 a, u32 b, float (&o)[3]) {
+        const int v[3] = {(int)(short)(a & 0xffffu), (int)(short)(a >> 16), (int)(short)(b & 0xffffu)};
+        if (SIGNED)
         {
-            lw[px][0] = pixelToFloat((int)(short)(pk01[px] & 0xffffu)) * A.w[0];
-            lw[px][1] = pixelToFloat((int)(short)(pk01[px] >> 16)) * A.w[1];
-            lw[px][2] = pixelToFloat((int)(short)(pk2[px] & 0xffffu)) * A.w[2];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+                o[ch] = twosCLHalfToFloat<SIGNED>(v[ch]);
+            return;
         }
-    }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+            o[ch] = __half2float(__ushort_as_half((unsigned short)v[ch]));
+        if (pixelFixup)
+        {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+                o[ch] = (v[ch] & 0x7c00) ? o[ch] : o[ch] * 0.5f;
+        }
+    };
 
     int numTweakRounds = A.seedPoints < 1 ? 1 : (A.seedPoints > 4 ? 4 : A.seedPoints);
     int numRefineRounds = A.refineRounds < 1 ? 1 : (A.refineRounds > 3 ? 3 : A.refineRounds);
@@ -456,7 +474,25 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                     const u32 subsetMask = partitioned ? (subset ? partitionMask : (~partitionMask & 0xffffu)) : 0xffffu;
                     if (subset == 1 && usable0 == 0)
                         break;
-                    const int fixupIndex = (subset == 0) ? 0 : (int)T->anchor2[p];
+                    const int fixupIndex = __builtin_amdgcn_readfirstlane((subset == 0) ? 0 : (int)T->anchor2[p]);
+                    // the anchor pixel of the subset (its index decides the swap of a round's end points, BC67.cpp:2525-2547)
+                    u32 fa = 0, fb = 0;
+                    float fixLw[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int px = 0; px < 16; px++)
+                        if (px == fixupIndex)
+                        {
+                            fa = pk01[px];
+                            fb = pk2[px];
+                        }
+                    if (!FAST)
+                    {
+                        float fl[3];
+                        pixelLinear(fa, fb, fl);
+                        fixLw[0] = fl[0] * A.w[0];
+                        fixLw[1] = fl[1] * A.w[1];
+                        fixLw[2] = fl[2] * A.w[2];
+                    }
                     const int count = __popc(subsetMask);
                     const float wRcp = T->rcpTable[count];
                     const float wCount = (float)count;
@@ -565,6 +601,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             PROF_MARK(1)
                             // ---- index selection, one pixel at a time: IndexSelectorHDR.h:100-144 ----
                             const u32 sm = opaqueUniform(subsetMask);
+                            bool interpFixup = true; // may an interpolant of this round have a zero exponent field? (wave-uniform)
                             float iw[indexRange][3]; // slow: weighted linear colour of every interpolant
                             float origin[3], axis[3]; // fast: projection axis
                             if (FAST)
@@ -591,7 +628,6 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 // An interpolant lies between the two finished end points (the interpolation, the
                                 // unscaling and the conversion are monotone), so when no lane's end point has a zero exponent
                                 // field no interpolant has one and the halving of TwosCLHalfToFloat is skipped (unsigned format)
-                                bool interpFixup = true;
                                 if (!SIGNED)
                                 {
                                     int lowest = fin[0][0] < fin[1][0] ? fin[0][0] : fin[1][0];
@@ -674,23 +710,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 return bi;
                             };
 
-                            // anchor index decides the inversion (BC67.cpp:2525-2547)
-                            u32 fa = 0, fb = 0;
-#pragma unroll
-                            for (int px = 0; px < 16; px++)
-                                if (px == fixupIndex)
-                                {
-                                    fa = pk01[px];
-                                    fb = pk2[px];
-                                }
-                            float fixLf[3] = {0.0f, 0.0f, 0.0f};
-                            if (!FAST)
-                            {
-                                fixLf[0] = pixelToFloat((int)(short)(fa & 0xffffu)) * A.w[0];
-                                fixLf[1] = pixelToFloat((int)(short)(fa >> 16)) * A.w[1];
-                                fixLf[2] = pixelToFloat((int)(short)(fb & 0xffffu)) * A.w[2];
-                            }
-                            const int fixRaw = rawIndexOf(fetchPixel(fa), fetchPixel(fb), fixLf);
+                            const int fixRaw = rawIndexOf(fetchPixel(fa), fetchPixel(fb), fixLw);
                             PROF_MARK(2)
                             const bool invert = (indexRange / 2 - 1) < fixRaw;
                             if (invert)
@@ -777,15 +797,27 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     if ((sm >> px) & 1u)
                                     {
                                         const u32 a = fetchPixel(pk01[px]), b = fetchPixel(pk2[px]);
-                                        float lf[3] = {0.0f, 0.0f, 0.0f};
-                                        if (!FAST && needError)
+                                        float lfp[3] = {0.0f, 0.0f, 0.0f};
+                                        if (!FAST)
                                         {
-                                            lf[0] = pixelToFloat((int)(short)(a & 0xffffu));
-                                            lf[1] = pixelToFloat((int)(short)(a >> 16));
-                                            lf[2] = pixelToFloat((int)(short)(b & 0xffffu));
+                                            if (partitioned)
+                                            {
+                                                lfp[0] = lf[FAST ? 0 : px][0];
+                                                lfp[1] = lf[FAST ? 0 : px][1];
+                                                lfp[2] = lf[FAST ? 0 : px][2];
+                                            }
+                                            else
+                                                pixelLinear(a, b, lfp);
                                         }
                                         // (the anchor's scan has been done: its index decided the inversion)
-                                        const int raw = (px == fixupIndex) ? fixRaw : rawIndexOf(a, b, lw[FAST ? 0 : px]);
+                                        int raw;
+                                        if (px == fixupIndex)
+                                            raw = fixRaw;
+                                        else
+                                        {
+                                            const float lwp[3] = {lfp[0] * A.w[0], lfp[1] * A.w[1], lfp[2] * A.w[2]};
+                                            raw = rawIndexOf(a, b, lwp);
+                                        }
                                         const int index = invert ? (indexRange - 1) - raw : raw;
 
                                         const int weight = (int)((mulU24((u32)raw, (u32)weightRcp) + 256u) >> 9);
@@ -793,21 +825,36 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                         if (needError)
                                         {
                                         float err = 0.0f;
+                                        int rec[3];
+                                        float recF[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
                                         for (int ch = 0; ch < 3; ch++)
                                         {
-                                            const int rec = reconstructFrom<SIGNED>(recBase[ch], recDiff[ch], weight);
+                                            rec[ch] = reconstructFrom<SIGNED>(recBase[ch], recDiff[ch], weight);
+                                            if (!FAST)
+                                                recF[ch] = SIGNED ? twosCLHalfToFloat<SIGNED>(rec[ch]) : __half2float(__ushort_as_half((unsigned short)rec[ch]));
+                                        }
+                                        if (!FAST && !SIGNED && interpFixup)
+                                        {
+                                            asm volatile("" ::: "memory"); // one wave-uniform branch around the three rare halvings
+#pragma unroll
+                                            for (int ch = 0; ch < 3; ch++)
+                                                recF[ch] = (rec[ch] & 0x7c00) ? recF[ch] : recF[ch] * 0.5f;
+                                        }
+#pragma unroll
+                                        for (int ch = 0; ch < 3; ch++)
+                                        {
                                             float sq;
                                             if (FAST)
                                             {
                                                 // SqDiffSInt16, ParallelMath.h:996-1010
-                                                const int r16 = (int)(short)rec;
+                                                const int r16 = (int)(short)rec[ch];
                                                 const u32 du = (u32)((r16 > orig[ch] ? r16 : orig[ch]) - (r16 > orig[ch] ? orig[ch] : r16)) & 0xffffu;
                                                 sq = (float)(int)(du * du);
                                             }
                                             else
                                             {
-                                                const float d = twosCLHalfToFloat<SIGNED>(rec) - lf[ch];
+                                                const float d = recF[ch] - lfp[ch];
                                                 sq = d * d;
                                             }
                                             err = err + sq * A.wSq[ch]; // (Flags::Uniform: the weights are 1.0 and the product is exact, no second form needed)
@@ -1167,6 +1214,12 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
         }
     };
     searchAll(std::false_type{});
+    if (!FAST)
+    {
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+            pixelLinear(pk01[px], pk2[px], lf[px]);
+    }
     searchAll(std::true_type{});
 
     PROF_MARK(5)
@@ -1262,7 +1315,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                     e0[ch] = s1 ? unqB[1][0][ch] : unqB[0][0][ch];
                     e1[ch] = s1 ? unqB[1][1][ch] : unqB[0][1][ch];
                 }
-                const float l0 = lw[FAST ? 0 : px][0], l1 = lw[FAST ? 0 : px][1], l2 = lw[FAST ? 0 : px][2];
+                const float l0 = lf[FAST ? 0 : px][0] * A.w[0], l1 = lf[FAST ? 0 : px][1] * A.w[1], l2 = lf[FAST ? 0 : px][2] * A.w[2];
                 float be = 0.0f;
 #pragma unroll 1
                 for (int i = 0; i < 16; i++)
@@ -1357,7 +1410,7 @@ extern "C" hipError_t cvttmi_launch_bc6h(const void *d_blocks, void *d_out, cons
     if (waves == 0)
         return hipSuccess;
     const bool fast = (args->flags & CVTTMI_FLAG_BC6H_FAST_INDEXING) != 0;
-#define CVTT_LAUNCH(S, Fq) hipLaunchKernelGGL((cvttmi_bc6h_kernel<S, Fq>), dim3(waves), dim3(64), 0, stream, (const uint8_t *)d_blocks, (uint8_t *)d_out, *args, d_tables)
+#define CVTT_LAUNCH(S, Fq) hipLaunchKernelGGL((cvttmi_bc6h_kernel<S, Fq>), dim3((waves + CVTT_BC6H_WG_WAVES - 1) / CVTT_BC6H_WG_WAVES), dim3(64 * CVTT_BC6H_WG_WAVES), 0, stream, (const uint8_t *)d_blocks, (uint8_t *)d_out, *args, d_tables)
     if (isSigned)
     {
         if (fast) CVTT_LAUNCH(true, true); else CVTT_LAUNCH(true, false);
