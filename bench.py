@@ -106,6 +106,41 @@ def stand_in_encoder(blocks_u8):
     return ((b[:, 0:16] * 3 + b[:, 16:32] * 5 + b[:, 32:48] * 7 + b[:, 48:64] * 11) & 0xFF).to(dtype=__import__("torch").uint8)
 
 
+def preflight(torch, dist, dev, rank, world, backend):
+    """Before anything is timed: one 1 MiB grouped send/recv round to rank 0 -- the exchange pattern of the timed steps
+    (sharding.gather_to_root: batch_isend_irecv, every peer over its own link) -- with the payload checked, and an
+    all-reduce of the verdict.  A broken link, a rank on the wrong device or an IPC problem (HSA_ENABLE_IPC_MODE_LEGACY)
+    stops the run here with a message instead of a hang or a wrong hash twenty steps later."""
+    from convectionkernels_amd import sharding
+    n = 1 << 16  # 64 Ki blocks x 16 B = 1 MiB per rank
+    ranges = [(r * n, (r + 1) * n) for r in range(world)]
+    local = torch.full((n, 16), (rank * 29 + 7) & 0xFF, dtype=torch.uint8, device=dev)
+    full = torch.zeros((world * n, 16), dtype=torch.uint8, device=dev) if rank == 0 else None
+    ok = 1
+    t0 = time.perf_counter()
+    try:
+        sharding.gather_to_root(local, ranges, full, root=0)
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        if rank == 0:
+            want = torch.tensor([(r * 29 + 7) & 0xFF for r in range(world)], dtype=torch.uint8, device=dev)
+            ok = int(bool((full.view(world, -1) == want[:, None]).all()))
+    except Exception as e:  # noqa
+        sys.stderr.write("bench.py preflight: rank %d: %s exchange failed: %r\n" % (rank, backend, e))
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        if rank == 0:
+            sys.stderr.write("bench.py preflight: the 1 MiB %s gather to rank 0 over %d ranks failed or delivered wrong bytes; "
+                             "nothing was timed (check HSA_ENABLE_IPC_MODE_LEGACY=0, one GPU per rank, MASTER_ADDR=127.0.0.1)\n" % (backend, world))
+        dist.destroy_process_group()
+        sys.exit(3)
+    if rank == 0:
+        sys.stderr.write("bench.py preflight: %s gather of %d x 1 MiB to rank 0 ok (%.0f ms incl. communicator set-up)\n"
+                         % (backend, world - 1, (time.perf_counter() - t0) * 1e3))
+
+
 def run_sharded(args):
     import torch
     import torch.distributed as dist
@@ -133,6 +168,8 @@ def run_sharded(args):
             dist.init_process_group("nccl", device_id=dev)
     n_ranks = dist.get_world_size() if world > 1 else 1
     assert n_ranks == args.gpus
+    if n_ranks > 1:
+        preflight(torch, dist, dev, rank, n_ranks, "gloo" if args.dry_run else "RCCL")
 
     size = args.size or 16384
     seed = 5
@@ -642,7 +679,7 @@ def family_legs(torch, api, synth, ctx, dev, rcp, no_cpu, n=1 << 20, check=1 << 
     return res
 
 
-def bc6h_family_legs(torch, api, synth, ctx, dev, rcp, no_cpu, n=1 << 19, check=1 << 11):
+def bc6h_family_legs(torch, api, synth, ctx, dev, rcp, no_cpu, n=1 << 19, check=1 << 14):
     """EncodeBC6HU on three kinds of HDR content: the search skips what the delta coding of the end points rules out, so
     its rate depends on how close together a block's end points are (noise = BASELINE config 3: nearly everything is ruled
     out at the higher precisions; smooth content: nearly nothing is).  Each family is compared with the CPU path on its

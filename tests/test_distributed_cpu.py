@@ -118,3 +118,56 @@ def test_gather_to_root_inside_a_subgroup(tmp_path):
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
                            "--master-addr", "127.0.0.1", "--master-port", "29733", str(script)], env=env, timeout=600)
     assert open(tmp_path / "subgroup_ok").read() == "ok"
+
+
+EIGHT_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from convectionkernels_amd import sharding
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+assert world == 8
+def pattern(lo, hi, step):
+    # 16 bytes per block: a function of the GLOBAL block number and the step, so a misplaced, stale or missing shard shows
+    i = torch.arange(lo, hi, dtype=torch.int32)[:, None]
+    k = torch.arange(16, dtype=torch.int32)[None, :]
+    return (i * (2 * k + 3) + (i >> 9) + 17 * step + k).to(torch.uint8)
+# (block rows, blocks per row): the real table of BASELINE config 5 (16384^2 pixels = 4096 x 4096 blocks, 2 097 152 blocks =
+# 32 MiB of packed output per rank, 224 MiB into rank 0 per step) and ragged tables: fewer rows than ranks, rows that are
+# not a multiple of the group size, an empty shard
+for rows, per_row, steps in ((4096, 4096, 2), (37, 24, 3), (5, 12, 3), (3, 8, 2), (4093, 20, 2)):
+    ranges = sharding.shard_ranges(rows, per_row, world)
+    total = rows * per_row
+    assert ranges[0][0] == 0 and ranges[-1][1] == total and all(a %% 8 == 0 for a, _ in ranges)
+    lo, hi = ranges[rank]
+    full = [torch.zeros((total, 16), dtype=torch.uint8) for _ in range(2)] if rank == 0 else [None, None]
+    outs = [f[lo:hi] for f in full] if rank == 0 else [torch.zeros((hi - lo, 16), dtype=torch.uint8) for _ in range(2)]
+    seen = []
+    def encode_step(i, buf):
+        outs[buf].copy_(pattern(lo, hi, i))
+    def exchange(i, buf):
+        return sharding.gather_to_root(outs[buf], ranges, full[buf], root=0, async_op=True)
+    def after(i, buf):
+        if rank == 0:
+            seen.append((i, bool((full[buf] == pattern(0, total, i)).all())))
+    sharding.pipelined_steps(steps, encode_step, exchange, after_exchange=after)
+    if rank == 0:
+        assert seen == [(i, True) for i in range(steps)], (rows, per_row, seen)
+dist.barrier()
+if rank == 0:
+    open(os.path.join(os.environ["OUT_DIR"], "eight_ok"), "w").write("ok")
+dist.destroy_process_group()
+''' % (ROOT,)
+
+
+def test_eight_rank_gather_with_the_config5_shard_table(tmp_path):
+    """World size 8 (gloo): the exchange of `bench.py --gpus 8` with the real shard table of the 16384^2 image -- every rank
+    sends its 32 MiB of packed blocks to rank 0, two buffer sets, the gather of step i checked after step i + 1 was
+    queued -- and with ragged tables (fewer block rows than ranks, an empty shard, rows that are no multiple of 8 blocks)"""
+    env = dict(os.environ, OUT_DIR=str(tmp_path), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    script = tmp_path / "eight.py"
+    script.write_text(EIGHT_WORKER)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                           "--master-addr", "127.0.0.1", "--master-port", "29735", str(script)], env=env, timeout=900)
+    assert open(tmp_path / "eight_ok").read() == "ok"

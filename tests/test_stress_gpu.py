@@ -1,8 +1,9 @@
 """Reduced differential stress (the driver's `-m gpu` run repeats what tools/stress_parity.py shows in builder logs):
 every content family of synth.content_families through the HIP kernels and through the REAL reference (oracle/_ref, all
 usable host threads; the C restatement when the reference build did not travel), every block compared.
-8 families x 16 384 blocks x {default, Flags::Better, Flags::Ultra + BC7_RespectPunchThrough} for BC7, 4 096 blocks each for
-BC6HU / BC6HS / ETC2 RGBA.  These are the families on which the branch-and-bound prunes hardest (smooth, two-colour,
+8 families x 65 536 blocks with the default options and x 32 768 with Flags::Better and Flags::Ultra + BC7_RespectPunchThrough
+for BC7; 16 384 blocks each for BC6HU / BC6HS (wide-range noise, narrow-range blocks and the three families of
+synth.hdr_content_families) and for ETC2 RGBA.  These are the families on which the branch-and-bound prunes hardest (smooth, two-colour,
 photo-like) and least (noise)."""
 import os
 import time
@@ -14,8 +15,8 @@ from oracle import pyref
 
 pytestmark = pytest.mark.gpu
 
-N_BC7 = 16384
-N_OTHER = 4096
+N_BC7 = {"default": 65536, "better": 32768, "ultra_pt": 32768}
+N_OTHER = 16384
 
 
 def _threads():
@@ -66,7 +67,7 @@ def test_bc7_families_vs_reference(gpu_ctx, cpu_side, variant):
     pb = np.frombuffer(plan.tobytes(), np.uint8).copy()
     t0 = time.time()
     report = {}
-    for name, b in synth.content_families(N_BC7, seed=20260930 + len(variant)).items():
+    for name, b in synth.content_families(N_BC7[variant], seed=20260930 + len(variant)).items():
         got = gpu_ctx.encode_bc7(b, opt, plan)
         exp = bc7(b, ob, pb)
         report[name] = int((got != exp).any(axis=1).sum())
@@ -83,16 +84,21 @@ def test_bc6h_and_etc2_vs_reference(gpu_ctx, cpu_side):
     rng = np.random.Generator(np.random.PCG64(77))
     report = {}
     # HDR: wide-range noise and narrow-range blocks (close exponents), unsigned and signed
-    wide = rng.integers(0, 0x7C00, (N_OTHER // 2, 16, 4)).astype(np.uint16)
-    base = rng.integers(0x3000, 0x7000, (N_OTHER // 2, 1, 3))
-    narrow = np.zeros((N_OTHER // 2, 16, 4), np.uint16)
-    narrow[:, :, :3] = (base + rng.integers(-60, 61, (N_OTHER // 2, 16, 3))).astype(np.uint16)
-    hdr = np.concatenate([wide, narrow])
+    q = N_OTHER // 4
+    wide = rng.integers(0, 0x7C00, (q, 16, 4)).astype(np.uint16)
+    base = rng.integers(0x3000, 0x7000, (q, 1, 3))
+    narrow = np.zeros((q, 16, 4), np.uint16)
+    narrow[:, :, :3] = (base + rng.integers(-60, 61, (q, 16, 3))).astype(np.uint16)
+    fam_hdr = synth.hdr_content_families(q - q % 24, seed=4242)  # smooth ramps / narrow range: where the deltas do fit
+    third = (q - q % 24) // 3
+    mixed = np.concatenate([v[:third].view(np.uint16) for v in fam_hdr.values()])
+    hdr = np.concatenate([wide, narrow, mixed, mixed[::-1]])[:N_OTHER]
+    hdr = np.ascontiguousarray(hdr[:hdr.shape[0] // 8 * 8])
     hdr[:, :, 3] = 0x3C00
     for sg in (False, True):
         h = hdr.copy()
         if sg:
-            h[:, :, :3] |= (rng.integers(0, 2, (N_OTHER, 16, 3)) << 15).astype(np.uint16)
+            h[:, :, :3] |= (rng.integers(0, 2, (h.shape[0], 16, 3)) << 15).astype(np.uint16)
         b = h.view(np.int16)
         got = gpu_ctx.encode_bc6h(b, opt, signed=sg)
         exp = other("bc6hs" if sg else "bc6hu", b, ob)
