@@ -426,17 +426,81 @@ def read_sclk_mhz():
     return None
 
 
+VALU_PEAK = 256 * 4 * SHADER_CLOCK_HZ / VALU_CYCLES_PER_INST  # wave-instructions per second, whole chip
+
+
+def format_counters(src_sha):
+    """PMC figures per format from the newest committed profiles/rNN/formats_summary.json (tools/profile_formats.sh: SQ
+    counters, FETCH_SIZE and WRITE_SIZE in passes of their own, at the BASELINE config sizes), used only when that profile
+    was taken with the library that is loaded now (its build identity, api.library_source_sha256).  Returns
+    {fmt: {valu_wave_insts_per_block, hbm_bytes_per_block, avg_waves_per_simd, kernels}} or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "formats_summary.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        if d.get("source_sha256") != src_sha:
+            return {"stale": True, "source": os.path.relpath(files[-1], ROOT)}
+        blocks = {e["fmt"]: e["blocks"] for e in d.get("fmt_bench", [])}
+        out = {"source": os.path.relpath(files[-1], ROOT)}
+        for fmt, kernels in d.items():
+            if not isinstance(kernels, list) or not kernels or "derived" not in kernels[0] or fmt not in blocks:
+                continue
+            insts = sum(k["derived"]["valu_insts_per_wave"] * k["grid"] / 64.0 for k in kernels if "derived" in k)
+            hbm = [k["hbm"]["bytes_corrected"] for k in kernels if "hbm" in k]
+            dur = sum(k["dur_us"] for k in kernels)
+            out[fmt] = {"valu_wave_insts_per_block": insts / blocks[fmt],
+                        "hbm_bytes_per_block": (sum(hbm) / blocks[fmt]) if len(hbm) == len(kernels) else None,
+                        "avg_waves_per_simd": sum(k["derived"]["avg_waves_per_simd"] * k["dur_us"] for k in kernels if "derived" in k) / dur,
+                        "kernels": [k["kernel"] for k in kernels], "profiled_blocks": blocks[fmt]}
+        return out
+    except Exception:  # noqa
+        return None
+
+
+def roofline_block(fmt, nblk, k_ms, kernel, insts_per_block=None, hbm_bytes_per_block=None, waves_per_simd=None, source=None):
+    """The roofline of one kernel launch.  The search kernels are VALU-issue bound (72-144 algorithmic bytes per block against
+    thousands of instructions), so when the PMC profile of this very library is at hand `bound` is "valu": achieved =
+    wave-level VALU instructions per second (SQ_INSTS_VALU of the profile, per block, x the blocks of this launch / the kernel
+    time measured here with HIP events), peak = one wave64 VALU instruction per SIMD per 2 cycles (MI355X_MICROARCH.md).
+    The HBM view -- SURVEY 8(d)'s algorithmic bytes per block over the same time, against 8 TB/s, and `traffic`, the
+    FETCH_SIZE / WRITE_SIZE bytes of the profile over the same time -- is always there under `hbm`; without a matching
+    profile it is all there is, and `bound` says "hbm" with a note."""
+    t = k_ms * 1e-3
+    a = ALGO_BYTES[fmt] * nblk / t / 1e9
+    hbm = {"achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "bytes_per_block": ALGO_BYTES[fmt], "traffic": None}
+    if hbm_bytes_per_block is not None:
+        hbm["traffic"] = hbm_bytes_per_block * nblk / t / 1e9
+        hbm["traffic_bytes_per_launch"] = hbm_bytes_per_block * nblk
+        hbm["traffic_over_algorithmic"] = hbm_bytes_per_block / float(ALGO_BYTES[fmt])
+    if insts_per_block is None:
+        r = dict(hbm)
+        r.update({"bound": "hbm", "kernel": kernel, "kernel_ms": k_ms,
+                  "note": "no PMC profile of this library build: only the HBM view; the kernel is VALU-issue bound (DESIGN.md 4)"})
+        return r
+    rate = insts_per_block * nblk / t
+    r = {"bound": "valu", "achieved": rate, "peak": VALU_PEAK, "unit": "wave-instructions/s", "frac": rate / VALU_PEAK,
+         "traffic": hbm["traffic"], "kernel": kernel, "kernel_ms": k_ms, "valu_insts_per_block": insts_per_block,
+         "avg_waves_per_simd": waves_per_simd, "hbm": hbm, "counters_from": source,
+         "peak_source": "MI355X_MICROARCH.md: one wave64 VALU instruction per SIMD per 2 cycles, 1024 SIMDs at %.1f GHz" % (SHADER_CLOCK_HZ / 1e9)}
+    if hbm.get("traffic_over_algorithmic") is not None:
+        r["traffic_over_algorithmic"] = hbm["traffic_over_algorithmic"]
+    return r
+
+
 def profiled_counters(lib_sha):
     """PMC figures of the headline kernel from the newest committed rocprofv3 summary (profiles/rNN/summary.json, written by
     tools/profile_round.sh: separate --pmc passes, FETCH_SIZE corrected as the microarch guide prescribes) -- used only when
-    that profile was taken with the very kernel object that is loaded now (sha-256 of the library's .hip_fatbin)."""
+    that profile was taken with the library that is loaded now: its build identity (api.library_source_sha256, a hash of
+    the sources and flags that does not depend on the build directory)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "summary.json")))
     if not files:
         return None
     try:
         d = json.load(open(files[-1]))
-        if d.get("kernel_object_sha256") != lib_sha:
+        if d.get("source_sha256") != lib_sha:
             return {"stale": True, "source": os.path.relpath(files[-1], ROOT)}
         sq = d["pmc_sq"][0]  # the dominant kernel (tools/summarize_pmc.py sorts by total duration)
         return {"source": os.path.relpath(files[-1], ROOT),
@@ -512,32 +576,26 @@ def run_single(args):
             "search": "exhaustive (every candidate evaluated, as the reference does)" if args.exhaustive else
                       "exact branch-and-bound (candidates whose rigorous error lower bound exceeds the running best are skipped; output bit-identical)",
         },
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "kernel": "cvttmi_bc7_kernel", "kernel_ms": k_ms,
-            "note": "VALU-bound search: %d algorithmic bytes per block, so the HBM fraction is small by construction; the binding limit is "
-                    "`valu_issue`.  kernel_ms brackets the launches of one encode on its stream (search + hand-over launch + commit)" % ALGO_BYTES["bc7"],
-        },
+        "roofline": roofline_block("bc7", nblk, k_ms, "cvttmi_bc7_kernel"),
         "burst_value": mblocks,
     }
 
-    lib_sha = api.library_fatbin_sha256()
-    result["kernel_object_sha256"] = lib_sha
+    lib_sha = api.library_source_sha256()
+    result["library_source_sha256"] = lib_sha
+    result["kernel_object_sha256"] = api.library_fatbin_sha256()
     pmc = profiled_counters(lib_sha)
     if pmc and pmc.get("stale"):
-        result["profile_note"] = "%s was taken with a different kernel object: traffic / valu_issue omitted" % pmc["source"]
+        result["profile_note"] = "%s was taken with a library built from other sources or flags: traffic / valu_issue omitted" % pmc["source"]
     elif pmc and pmc["blocks"] == nblk and not args.exhaustive and not args.opaque:
-        result["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9
-        result["roofline"]["traffic_bytes_per_launch"] = pmc["hbm_bytes_per_launch"]
-        result["roofline"]["traffic_over_algorithmic"] = pmc["hbm_bytes_per_launch"] / float(ALGO_BYTES["bc7"] * nblk)
-        result["roofline"]["traffic_source"] = pmc["source"]
         waves = (nblk + 15) // 16
-        rate = waves * pmc["valu_insts_per_wave"] / (k_ms * 1e-3)
-        peak = 256 * 4 * SHADER_CLOCK_HZ / VALU_CYCLES_PER_INST
-        result["valu_issue"] = {"insts_per_wave": pmc["valu_insts_per_wave"], "achieved": rate, "unit": "wave-instructions/s",
-                                "peak": peak, "frac": rate / peak, "avg_waves_per_simd": pmc.get("avg_waves_per_simd"),
-                                "source": pmc["source"],
-                                "peak_source": "MI355X_MICROARCH.md: one wave64 VALU instruction per SIMD per 2 cycles at %.1f GHz" % (SHADER_CLOCK_HZ / 1e9)}
+        result["roofline"] = roofline_block("bc7", nblk, k_ms, "cvttmi_bc7_kernel", insts_per_block=pmc["valu_insts_per_wave"] * waves / float(nblk),
+                                            hbm_bytes_per_block=pmc["hbm_bytes_per_launch"] / float(nblk),
+                                            waves_per_simd=pmc.get("avg_waves_per_simd"), source=pmc["source"])
+        result["roofline"]["note"] = ("kernel_ms brackets the launches of one encode on its stream (search + hand-over launch + commit); "
+                                      "%d algorithmic bytes per block, so the HBM fraction (`hbm`) is small by construction" % ALGO_BYTES["bc7"])
+        result["valu_issue"] = {"insts_per_wave": pmc["valu_insts_per_wave"], "achieved": result["roofline"]["achieved"], "unit": "wave-instructions/s",
+                                "peak": VALU_PEAK, "frac": result["roofline"]["frac"], "avg_waves_per_simd": pmc.get("avg_waves_per_simd"),
+                                "source": pmc["source"]}
 
     if not args.no_extra and not args.exhaustive:
         # ---- sustained rate: >= 3 s of back-to-back encodes, shader clock sampled while they run
@@ -586,7 +644,11 @@ def run_single(args):
         hp = host_path_leg(torch, api, ctx, blocks, out_host, opt, plan)
         if hp:
             result["host_path"] = hp
-        result["configs"] = per_config_legs(torch, api, synth, ctx, dev, h, rcp, rcp_gold, same_lut, args)
+        fmtc = format_counters(lib_sha)
+        if fmtc and fmtc.get("stale"):
+            result["formats_profile_note"] = "%s was taken with a library built from other sources or flags: per-config counters omitted" % fmtc["source"]
+            fmtc = None
+        result["configs"] = per_config_legs(torch, api, synth, ctx, dev, h, rcp, rcp_gold, same_lut, args, fmtc)
         result["content_families"] = family_legs(torch, api, synth, ctx, dev, rcp, args.no_cpu)
         result["bc6h_content_families"] = bc6h_family_legs(torch, api, synth, ctx, dev, rcp, args.no_cpu)
         # the one-GPU rate on the workload the N > 1 runs shard (one 16384^2 image): the base of a strong-scaling curve
@@ -603,21 +665,27 @@ def run_single(args):
     return result
 
 
-def per_config_legs(torch, api, synth, ctx, dev, h, rcp, rcp_gold, same_lut, args):
+def per_config_legs(torch, api, synth, ctx, dev, h, rcp, rcp_gold, same_lut, args, fmtc=None):
     """One measurement per BASELINE config besides the headline: kernel time (events), the roofline figure with SURVEY 8(d)'s
     bytes per block, the SHA-256 of the whole output against the reference's (made with the golden RCPPS table) and the CPU
     reference on a bounded sample with this box's table."""
     legs = {}
 
-    def leg(name, fmt, blocks, encode, hash_key, opt, plan=None, reps=2, cpu=True):
+    def leg(name, fmt, blocks, encode, hash_key, opt, plan=None, reps=2, cpu=True, prof=None):
         d_in = torch.from_numpy(blocks).to(dev)
         n = blocks.shape[0]
         out = encode(d_in, None)
         ms_min, ms_mean = timed_encode(torch, lambda: encode(d_in, out), reps)
         host = out.cpu().numpy()
-        a = ALGO_BYTES[fmt] * n / (ms_min * 1e-3) / 1e9
-        e = {"mblocks_s": n / ms_min / 1e3, "gpixel_per_s": n * 16 / ms_min / 1e6, "kernel_ms": ms_min, "blocks": n,
-             "roofline": {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "bytes_per_block": ALGO_BYTES[fmt]}}
+        c = (fmtc or {}).get(prof) if prof else None
+        if c:
+            roof = roofline_block(fmt, n, ms_min, "+".join(c["kernels"]), insts_per_block=c["valu_wave_insts_per_block"],
+                                  hbm_bytes_per_block=c["hbm_bytes_per_block"], waves_per_simd=c["avg_waves_per_simd"], source=fmtc["source"])
+            if c["profiled_blocks"] != n:
+                roof["counters_note"] = "per-block counters of the same kernel on %d blocks of the same kind of content" % c["profiled_blocks"]
+        else:
+            roof = roofline_block(fmt, n, ms_min, fmt)
+        e = {"mblocks_s": n / ms_min / 1e3, "gpixel_per_s": n * 16 / ms_min / 1e6, "kernel_ms": ms_min, "blocks": n, "roofline": roof}
         if hash_key in h:
             if same_lut:
                 e["sha256_matches_reference"] = sha256(host) == h[hash_key]
@@ -635,16 +703,16 @@ def per_config_legs(torch, api, synth, ctx, dev, h, rcp, rcp_gold, same_lut, arg
 
     o, p = api.Options(), api.BC7EncodingPlan()
     ultra = api.Options(flags=api.Flags.Ultra)
-    leg("1_bc1_256", "bc1", synth.tile_blocks(synth.image_rgba8(1, 256, 256)), lambda t, out: ctx.encode_bc1(t, o, out=out), "config1_bc1_256_seed1", o, reps=5)
+    leg("1_bc1_256", "bc1", synth.tile_blocks(synth.image_rgba8(1, 256, 256)), lambda t, out: ctx.encode_bc1(t, o, out=out), "config1_bc1_256_seed1", o, reps=5, prof="bc1")
     leg("2b_bc7_4096_opaque", "bc7", synth.tile_blocks(synth.image_rgba8(2, 4096, 4096, opaque=True)),
-        lambda t, out: ctx.encode_bc7(t, o, p, out=out), "config2b_bc7_4096_seed2_opaque", o, p)
+        lambda t, out: ctx.encode_bc7(t, o, p, out=out), "config2b_bc7_4096_seed2_opaque", o, p, prof="bc7o")
     leg("3_bc6hu_4096", "bc6hu", synth.tile_blocks(synth.image_f16bits(3, 4096, 4096)), lambda t, out: ctx.encode_bc6h(t, o, signed=False, out=out),
-        "config3_bc6hu_4096_seed3", o, reps=1)
+        "config3_bc6hu_4096_seed3", o, reps=1, prof="bc6hu")
     leg("4_etc2rgba_4096", "etc2rgba", synth.tile_blocks(synth.image_rgba8(4, 4096, 4096)), lambda t, out: ctx.encode_etc2_rgba(t, o, out=out),
-        "config4_etc2rgba_4096_seed4", o)
+        "config4_etc2rgba_4096_seed4", o, prof="etc2rgba")
     big = synth.tile_blocks(synth.image_rgba8(5, 16384, 16384))
-    leg("5a_bc7_16384", "bc7", big, lambda t, out: ctx.encode_bc7(t, o, p, out=out), "config5_bc7_16384_seed5", o, p)
-    leg("5b_bc7_16384_ultra", "bc7", big, lambda t, out: ctx.encode_bc7(t, ultra, p, out=out), "config5b_bc7_16384_seed5_ultra", ultra, p, reps=1)
+    leg("5a_bc7_16384", "bc7", big, lambda t, out: ctx.encode_bc7(t, o, p, out=out), "config5_bc7_16384_seed5", o, p, prof="bc7")
+    leg("5b_bc7_16384_ultra", "bc7", big, lambda t, out: ctx.encode_bc7(t, ultra, p, out=out), "config5b_bc7_16384_seed5_ultra", ultra, p, reps=1, prof="bc7u")
     return legs
 
 
@@ -735,18 +803,27 @@ def dropin_8block_leg():
             ob = np.frombuffer(ref.default_options(), np.uint8).copy()
             pb = np.frombuffer(ref.default_plan(), np.uint8).copy()
             cpu = {}
-            for fmt, n in (("bc7", 1024), ("bc1", 4096)):
+            cpu16 = {}
+            for fmt, n in (("bc7", 1024), ("bc1", 4096), ("etc2rgba", 512)):
                 t0 = time.perf_counter()
                 ref.encode_mt(fmt, blocks[:n], ob, pb if fmt == "bc7" else None, threads=1, budget_s=30.0, chunk_blocks=64)
                 cpu[fmt] = (time.perf_counter() - t0) / (n / 8) * 1e6
+                # the caller's own threading model on the CPU: 16 workers, 8 blocks per call
+                nt = min(16, usable_cores())
+                t0 = time.perf_counter()
+                _, done, _ = ref.encode_mt(fmt, blocks[:n * 4], ob, pb if fmt == "bc7" else None, threads=nt, budget_s=30.0, chunk_blocks=8)
+                cpu16[fmt] = done / 8 / (time.perf_counter() - t0)
+            res["cpu_reference_calls_per_s_all_threads"] = cpu16
             res["cpu_reference_us_per_call_one_thread"] = cpu
             for fmt in cpu:
                 if fmt in res and "us_per_call_1_thread" in res[fmt]:
                     res[fmt]["slower_than_cpu_reference_per_call"] = res[fmt]["us_per_call_1_thread"] > cpu[fmt]
+                    res[fmt]["calls_16_threads_over_1_thread"] = res[fmt]["calls_per_s_16_threads"] / res[fmt]["calls_per_s_1_thread"]
+                    res[fmt]["calls_16_threads_over_cpu_reference_all_threads"] = res[fmt]["calls_per_s_16_threads"] / cpu16[fmt]
     except Exception as e:  # noqa
         res["cpu_error"] = repr(e)
-    res["note"] = ("8 blocks per call cannot fill a GPU (one wave of 65 536 resident): use the *Batch entry points; "
-                   "the 8-block calls exist so that an unmodified caller links and gets identical bytes")
+    res["note"] = ("8 blocks per call cannot fill a GPU: concurrent calls of one kind are coalesced into one launch (cxx_api.cpp), a "
+                   "single caller thread pays a PCIe round trip and a one-wave launch per call; throughput needs the *Batch entry points")
     return res
 
 

@@ -174,7 +174,7 @@ class CvttError(RuntimeError):
 
 
 _EXPORTS = (
-    "cvttmi_default_options", "cvttmi_default_bc7_plan", "cvttmi_create", "cvttmi_destroy",
+    "cvttmi_source_sha256", "cvttmi_default_options", "cvttmi_default_bc7_plan", "cvttmi_create", "cvttmi_destroy",
     "cvttmi_last_error", "cvttmi_set_rcp_table", "cvttmi_get_rcp_table",
     "cvttmi_encode_bc7_device", "cvttmi_encode_bc7", "cvttmi_timing_enable", "cvttmi_timing_read",
     "cvttmi_set_exhaustive", "cvttmi_encode_bc1_device", "cvttmi_encode_bc1",
@@ -210,6 +210,8 @@ def load_library():
     for name in _EXPORTS:
         if not hasattr(lib, name):
             raise CvttError("symbol %s missing from %s" % (name, path))
+    lib.cvttmi_source_sha256.restype = ctypes.c_char_p
+    lib.cvttmi_source_sha256.argtypes = []
     lib.cvttmi_last_error.restype = ctypes.c_char_p
     lib.cvttmi_last_error.argtypes = [ctypes.c_void_p]
     lib.cvttmi_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
@@ -269,6 +271,13 @@ def load_library():
     lib.cvttmi_timing_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
     _lib = lib
     return lib
+
+
+def library_source_sha256():
+    """Build identity compiled into the loaded library (csrc/Makefile: SHA-256 over the kernel and shim sources, the public
+    headers and the compiler flags).  The same for every build of the same tree, whatever the build directory; profiles/
+    summaries carry it and bench.py quotes their counters only when it matches."""
+    return load_library().cvttmi_source_sha256().decode()
 
 
 def library_fatbin_sha256(path=None):

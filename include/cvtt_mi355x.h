@@ -104,6 +104,10 @@ typedef struct cvttmi_bc7_fine_tuning
 typedef struct cvttmi_context cvttmi_context;
 
 /* Default-constructed PODs (cvtt::Options(), cvtt::BC7EncodingPlan()). */
+/* Build identity of this library: SHA-256 (hex) over its kernel / shim sources, public headers and compiler flags.  Not part
+ * of the reference's API: measurement tooling uses it to tie rocprofv3 summaries to the library they were taken with. */
+const char *cvttmi_source_sha256(void);
+
 void cvttmi_default_options(cvttmi_options *out);
 void cvttmi_default_bc7_plan(cvttmi_bc7_plan *out);
 void cvttmi_default_bc7_fine_tuning(cvttmi_bc7_fine_tuning *out);

@@ -137,17 +137,40 @@ int main(int argc, char **argv)
             printf("%02x", out[k][i]);
         printf("\n");
     }
-    // the reference's callers run one worker thread per group (etc2packer.cpp:215-281): every thread gets its own context
+    // the reference's callers run one worker thread per group (etc2packer.cpp:215-281).  Concurrent one-group calls are
+    // coalesced into shared launches (cxx_api.cpp): sixteen threads, each with its OWN input (the blocks rotated by the thread
+    // number) and one of four kinds of call -- two formats, two plans, two Options -- hammer the library together; every
+    // result must equal what the same call gives on its own afterwards.
     int bad = 0;
     {
-        static uint8_t tout[4][128];
-        std::thread th[4];
-        for (int i = 0; i < 4; i++)
-            th[i] = std::thread([&, i] { for (int rep = 0; rep < 3; rep++) cvtt::Kernels::EncodeBC7(tout[i], in, options, plan); });
-        for (int i = 0; i < 4; i++)
+        const int T = 16, REPS = 40;
+        static cvtt::PixelBlockU8 tin[T][cvtt::NumParallelBlocks];
+        static uint8_t tout[T][128], want[T][128];
+        cvtt::Options uni;
+        uni.flags |= cvtt::Flags::Uniform;
+        for (int i = 0; i < T; i++)
+            for (unsigned b = 0; b < 8; b++)
+                tin[i][b] = in[(b + i) % 8];
+        auto one = [&](int i, uint8_t *dst) {
+            switch (i % 4)
+            {
+            case 0: cvtt::Kernels::EncodeBC7(dst, tin[i], options, plan); break;
+            case 1: cvtt::Kernels::EncodeBC7(dst, tin[i], options, qplan); break;
+            case 2: cvtt::Kernels::EncodeBC7(dst, tin[i], uni, plan); break;
+            default: cvtt::Kernels::EncodeETC2RGBA(dst, tin[i], options, NULL); break;
+            }
+        };
+        std::thread th[T];
+        for (int i = 0; i < T; i++)
+            th[i] = std::thread([&, i] { for (int rep = 0; rep < REPS; rep++) one(i, tout[i]); });
+        for (int i = 0; i < T; i++)
             th[i].join();
-        for (int i = 0; i < 4; i++)
-            bad += memcmp(tout[i], out[0], 128) != 0;
+        for (int i = 0; i < T; i++)
+        {
+            one(i, want[i]);
+            bad += memcmp(tout[i], want[i], 128) != 0;
+        }
+        bad += memcmp(want[0], out[0], 128) != 0; // thread 0 has the unrotated blocks and the default call
     }
     printf("threads %d\n", bad);
     return 0;
@@ -198,7 +221,7 @@ def test_cxx_api_matches_oracle(tmp_path, oracle_lib, gpu_ctx):
     for k, w in enumerate(want):
         got = bytes.fromhex(lines[k])[:w.size]
         assert got == w.tobytes(), k
-    assert lines[11:13] == ["threads", "0"]  # four caller threads, a context each, same blocks as the main thread's
+    assert lines[11:13] == ["threads", "0"]  # sixteen caller threads, four kinds of call, coalesced launches
 
 
 def test_headline_kernel_needs_no_scratch():

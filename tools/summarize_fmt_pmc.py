@@ -71,5 +71,11 @@ for d in sorted(glob.glob(os.path.join(out_dir, "pmc_*"))):
     st = glob.glob(os.path.join(out_dir, "trace_" + fmt, "*kernel_stats.csv"))
     if st:
         summary[fmt + "_kernel_stats"] = [r for r in csv.DictReader(open(st[0])) if "cvttmi" in r["Name"]]
+try:  # which library these counters belong to (bench.py quotes them only for that one)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from convectionkernels_amd import api
+    summary["source_sha256"] = api.library_source_sha256()
+except Exception as ex:  # noqa
+    summary["source_sha256_error"] = str(ex)
 json.dump(summary, open(os.path.join(out_dir, "fmt_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:6000])

@@ -91,6 +91,7 @@ try:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from convectionkernels_amd import api
     summary["kernel_object_sha256"] = api.library_fatbin_sha256()
+    summary["source_sha256"] = api.library_source_sha256()
 except Exception as e:  # noqa
     summary["kernel_object_error"] = str(e)
 json.dump(summary, open(os.path.join(out_dir, "summary.json"), "w"), indent=1)
