@@ -93,7 +93,7 @@ def test_bc6h_and_etc2_vs_reference(gpu_ctx, cpu_side):
     third = (q - q % 24) // 3
     mixed = np.concatenate([v[:third].view(np.uint16) for v in fam_hdr.values()])
     hdr = np.concatenate([wide, narrow, mixed, mixed[::-1]])[:N_OTHER]
-    hdr = np.ascontiguousarray(hdr[:hdr.shape[0] // 8 * 8])
+    hdr = np.ascontiguousarray(hdr[:hdr.shape[0] // 64 * 64])  # whole 64-block chunks of the reference's worker threads
     hdr[:, :, 3] = 0x3C00
     for sg in (False, True):
         h = hdr.copy()
