@@ -2264,12 +2264,17 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
 // EAC 8-bit alpha: CompressETC2AlphaBlockInternal (ETC.cpp:1902-2085), QuantizeETC2Alpha 2366-2411.
 // KIND 0: 8-bit alpha of PixelBlockU8 (EncodeETC2Alpha / the alpha half of EncodeETC2RGBA);
 // KIND 1 / 2: unsigned / signed 11-bit EAC of PixelBlockScalarS16 (EncodeETC2Alpha11, CompressEACBlock ETC.cpp:2087-2114)
-template <int KIND>
+// SPREAD = false: one lane per block (the throughput form: a wave's 64 blocks share every table word).
+// SPREAD = true: sixteen lanes per block, lane t searches modifier table t, and a 16-lane minimum of (error, table) picks the
+// winner -- the reference walks the tables in ascending order and keeps the first minimum, i.e. the lowest table among equal
+// errors.  The same instructions per block, but a sixteenth of the latency: what a call with a handful of blocks (the
+// reference's 8-block convention, ConvectionKernels_API.cpp:246-256, 270-286) waits for (213 -> 25 us at 16 blocks).
+template <int KIND, bool SPREAD>
 __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
                                                              const CvttEtcArgs A, const CvttDeviceTables *__restrict__ T)
 {
     constexpr bool is11 = KIND != 0, isSigned = KIND == 2;
-    const u32 blockIndex = blockIdx.x * 64u + threadIdx.x;
+    const u32 blockIndex = SPREAD ? blockIdx.x * 4u + (threadIdx.x >> 4) : blockIdx.x * 64u + threadIdx.x;
     const bool valid = blockIndex < A.numBlocks;
     int pixel[16];
     if (!is11)
@@ -2323,16 +2328,21 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
     int bestTable = 0, bestBase = 0, bestMultiplier = 0;
     u32 bestIdxLo = 0, bestIdxHi = 0; // 3 bits per pixel
 
-    for (int tableIndex = 0; tableIndex < 16; tableIndex++)
+    for (int tableIter = 0; tableIter < (SPREAD ? 1 : 16); tableIter++)
     {
+        const int tableIndex = SPREAD ? (int)(threadIdx.x & 15u) : tableIter;
         const int pos[4] = {T->eacPositive[tableIndex][0], T->eacPositive[tableIndex][1], T->eacPositive[tableIndex][2], T->eacPositive[tableIndex][3]};
         // the table's row of the rounding table (13 entries of 2 bits) and its four positive modifiers as two wave-uniform
         // words: a pixel's lookups are bit-field extracts instead of a per-lane byte load and a select chain
         u32 roundBits = 0;
         for (int i = 0; i < 13; i++)
             roundBits |= (u32)T->eacRounding[tableIndex][i] << (2 * i);
-        roundBits = (u32)__builtin_amdgcn_readfirstlane((int)roundBits);
-        const u32 posWord = (u32)__builtin_amdgcn_readfirstlane(pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24));
+        u32 posWord = (u32)(pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24));
+        if (!SPREAD)
+        {
+            roundBits = (u32)__builtin_amdgcn_readfirstlane((int)roundBits);
+            posWord = (u32)__builtin_amdgcn_readfirstlane((int)posWord);
+        }
         for (int r = 0; r < 10; r++)
         {
             const int subrange = r % 3, mainRange = r / 3;
@@ -2413,6 +2423,21 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
             }
         }
     }
+    if (SPREAD)
+    {
+        // (error, table) as one word: the error of 16 pixels stays below 2^27 (16 x 2047^2)
+        u32 key = (bestTotalError << 4) | (u32)bestTable;
+#pragma unroll
+        for (int step = 1; step < 16; step <<= 1)
+        {
+            const u32 o = (u32)__shfl_xor((int)key, step);
+            key = o < key ? o : key;
+        }
+        const int src = (int)((threadIdx.x & ~15u) | (key & 15u));
+        bestTable = (int)(key & 15u);
+        bestBase = __shfl(bestBase, src);
+        bestMultiplier = __shfl(bestMultiplier, src);
+    }
     // the winner's indexes (the operations of the candidate loop, once)
     {
         const u32 magic = (u32)udivSmall20(bestMultiplier);
@@ -2437,7 +2462,7 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
         if (isSigned)
             bestBase ^= 0x80;
     }
-    if (valid)
+    if (valid && (!SPREAD || (threadIdx.x & 15u) == 0))
     {
         // 16 x 3-bit indexes, column-major pixel order, MSB first (ETC.cpp:2049-2084)
         u64 bits = 0;
@@ -2457,6 +2482,11 @@ __global__ __launch_bounds__(64) void cvttmi_eac_alpha_kernel(const uint8_t *__r
         *reinterpret_cast<uint2 *>(o) = v;
     }
 }
+
+// Launches of at most this many blocks use the sixteen-lanes-per-block form of the EAC search: the chip is not full there
+// (256 CUs x 4 SIMDs x 4 waves x 64 lanes = 262 144 blocks resident in the one-lane form), so latency is what counts.
+// CVTTMI_EAC_SPREAD_MAX in the environment overrides it (developer knob for A/B runs).
+static const uint32_t kEacSpreadMax = getenv("CVTTMI_EAC_SPREAD_MAX") ? (uint32_t)atol(getenv("CVTTMI_EAC_SPREAD_MAX")) : 65536u;
 
 extern "C" hipError_t cvttmi_launch_etc2(const void *d_blocks, void *d_out, const CvttEtcArgs *args,
                                          const CvttDeviceTables *d_tables, int mode, hipStream_t stream)
@@ -2495,8 +2525,12 @@ extern "C" hipError_t cvttmi_launch_etc2(const void *d_blocks, void *d_out, cons
     if (mode != 0)
     {
         a.outOffset = 0u;
-        hipLaunchKernelGGL(cvttmi_eac_alpha_kernel<0>, dim3((a.numBlocks + 63u) / 64u), dim3(64), 0, stream, (const uint8_t *)d_blocks,
-                           (uint8_t *)d_out, a, d_tables);
+        if (a.numBlocks <= kEacSpreadMax)
+            hipLaunchKernelGGL((cvttmi_eac_alpha_kernel<0, true>), dim3((a.numBlocks + 3u) / 4u), dim3(64), 0, stream, (const uint8_t *)d_blocks,
+                               (uint8_t *)d_out, a, d_tables);
+        else
+            hipLaunchKernelGGL((cvttmi_eac_alpha_kernel<0, false>), dim3((a.numBlocks + 63u) / 64u), dim3(64), 0, stream, (const uint8_t *)d_blocks,
+                               (uint8_t *)d_out, a, d_tables);
     }
     return hipGetLastError();
 }
@@ -2510,11 +2544,17 @@ extern "C" hipError_t cvttmi_launch_eac11(const void *d_blocksS16, void *d_out, 
     a.numBlocks = numBlocks;
     a.outStride = 8u;
     a.outOffset = 0u;
+    const bool spread = numBlocks <= kEacSpreadMax;
+    const dim3 grid(spread ? (numBlocks + 3u) / 4u : (numBlocks + 63u) / 64u);
     if (isSigned)
-        hipLaunchKernelGGL(cvttmi_eac_alpha_kernel<2>, dim3((numBlocks + 63u) / 64u), dim3(64), 0, stream, (const uint8_t *)d_blocksS16,
-                           (uint8_t *)d_out, a, d_tables);
+    {
+        if (spread) hipLaunchKernelGGL((cvttmi_eac_alpha_kernel<2, true>), grid, dim3(64), 0, stream, (const uint8_t *)d_blocksS16, (uint8_t *)d_out, a, d_tables);
+        else hipLaunchKernelGGL((cvttmi_eac_alpha_kernel<2, false>), grid, dim3(64), 0, stream, (const uint8_t *)d_blocksS16, (uint8_t *)d_out, a, d_tables);
+    }
     else
-        hipLaunchKernelGGL(cvttmi_eac_alpha_kernel<1>, dim3((numBlocks + 63u) / 64u), dim3(64), 0, stream, (const uint8_t *)d_blocksS16,
-                           (uint8_t *)d_out, a, d_tables);
+    {
+        if (spread) hipLaunchKernelGGL((cvttmi_eac_alpha_kernel<1, true>), grid, dim3(64), 0, stream, (const uint8_t *)d_blocksS16, (uint8_t *)d_out, a, d_tables);
+        else hipLaunchKernelGGL((cvttmi_eac_alpha_kernel<1, false>), grid, dim3(64), 0, stream, (const uint8_t *)d_blocksS16, (uint8_t *)d_out, a, d_tables);
+    }
     return hipGetLastError();
 }
