@@ -372,8 +372,15 @@ extern "C" int cvttmi_etc_prof_read(unsigned long long *out)
 #endif
 // ------------------------------------------------------------------------------------------
 // MODE 0: EncodeETC2 (RGB), 1: EncodeETC1, 2: EncodeETC2PunchthroughAlpha; FAKE: ETC_UseFakeBT709
+#ifndef CVTT_ETC2_WAVES
+#define CVTT_ETC2_WAVES 5
+#endif
+struct EtcGroupPixels { u32 w[8][16]; };
+struct EtcNoGroupPixels { u32 unused; };
 template <int MODE, bool FAKE>
-__global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+// (the punch-through instantiation keeps its group pixels apart -- 9.4 KB, 16 workgroups per CU -- so a tighter register budget
+// would only make it spill)
+__global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_etc2_color_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
                                                               const CvttEtcArgs A, const CvttDeviceTables *__restrict__ T)
 {
     // One wave = one workgroup = one block.  What a block needs from the other seven of its reference group (the maxima of
@@ -381,7 +388,11 @@ __global__ __launch_bounds__(64, 4) void cvttmi_etc2_color_kernel(const uint8_t 
     // works for group member l & 7 from the 512 bytes of the group's pixels.  No workgroup barrier, no waiting for the
     // slowest block of the group, and 9 KB of LDS per wave instead of 72 KB per eight.
     __shared__ EtcWaveShared shared1;
-    __shared__ u32 gpix[8][16];
+    // The group's pixels (512 B).  EncodeETC2 / EncodeETC1 need them for the sector split and the T modes only, which are over
+    // before the H mode and the cluster fit use the union `u`: there they live in it (8 940 B of LDS = 7 allocation granules =
+    // 18 workgroups per CU instead of 16).  The punch-through modes look at the group again after the cluster fit.
+    __shared__ typename std::conditional<MODE == 2, EtcGroupPixels, EtcNoGroupPixels>::type groupSeparate;
+    u32 (*const gpix)[16] = (MODE == 2) ? reinterpret_cast<u32 (*)[16]>(&groupSeparate) : reinterpret_cast<u32 (*)[16]>(&shared1.u);
 
     const int lane = threadIdx.x;
     const u32 blockIndex = blockIdx.x;
