@@ -311,8 +311,8 @@ def exported_symbols():
 class Context:
     """One encoder context on one HIP device (tables in HBM, staging and work buffers, rcp table).
 
-    Concurrency: a context owns ONE set of device work buffers (the BC7 hand-over list and punch-through table, the BC6H
-    scratch, the host-path staging ring).  The calls that use them are ordered by the library itself when they arrive on
+    Concurrency: a context owns ONE set of device work buffers (the BC7 hand-over list and punch-through table, the host-path
+    staging ring).  The calls that use them are ordered by the library itself when they arrive on
     different streams (cvtt_mi355x.h "Streams"; calls that use no shared work space are simply queued on their stream), the
     host side of every call on a context is serialised by a mutex in the library, and the host-pointer calls additionally by
     a lock here, so sharing a context between threads or streams is safe but not concurrent -- use one Context per worker

@@ -144,15 +144,15 @@ int cvttmi_host_unregister(cvttmi_context *ctx, void *ptr);
 
 /* ---- device-resident entry points: d_blocks / d_out are HBM pointers on the context's
  * device; the launch is asynchronous on `hipStream` (a hipStream_t, NULL = default).
- * Streams: a context owns ONE set of device work space (BC7 hand-over list, punch-through trial table and plan ring,
- * BC6H endpoint history and PCA seeds: 169 KB per 64 blocks of a launch, i.e. 2.8 GB of HBM for launches of 2^20 blocks,
- * allocated on the first BC6H call; CVTTMI_BC6H_CHUNK_LOG2 in the environment bounds the launch size).  The calls that use it (EncodeBC7 from half a million blocks or with BC7_RespectPunchThrough and
- * more than 2 refine rounds, EncodeBC6H) are ordered by the library itself: such a call on another stream than the
+ * Streams: a context owns ONE set of device work space (BC7 hand-over list, punch-through trial table and plan ring; up to 256 MB
+ * for the trial table, see below).  The calls that use it (EncodeBC7 from half a million blocks or with BC7_RespectPunchThrough and
+ * more than 2 refine rounds) are ordered by the library itself: such a call on another stream than the
  * previous one first makes its stream wait (hipStreamWaitEvent) for that call's launches; a plan slot is rewritten only
  * after every launch that read it, on whatever stream, has finished.  Calls that use no shared work space (BC1-BC5, ETC,
  * EAC, decode, tiling) are simply queued on the stream given.  A mutex serialises the host side of EVERY call on a
  * context, so any stream / thread mix is safe on one context; it is not concurrent: use one context per stream (or per
- * worker thread, the reference's caller model, etc2packer.cpp:215-281) to overlap independent jobs. ---- */
+ * worker thread, the reference's caller model, etc2packer.cpp:215-281) to overlap independent jobs.  (EncodeBC6H keeps its
+ * whole search state on the chip since round 4: no work buffer, no ordering between its calls.) ---- */
 
 /* replaces cvtt::Kernels::EncodeBC7 (ConvectionKernels_API.cpp:41-54): numBlocks * 64 B
  * of PixelBlockU8 in, numBlocks * 16 B out. */
