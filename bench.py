@@ -315,10 +315,16 @@ def run_sharded(args):
         if args.dry_run:
             result["dry_run"] = True
         else:
-            achieved = ALGO_BYTES["bc7"] * nloc / (k_ms * 1e-3) / 1e9
-            result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                  "traffic": None, "kernel": "cvttmi_bc7_kernel", "kernel_ms": k_ms,
-                                  "note": "rank 0's shard (%d blocks) per launch; VALU-bound search, see the N=1 line for the issue-rate figures and the PMC traffic" % nloc}
+            # rank 0's launch: the per-block counters of the headline profile (same kernel, same kind of content) when that
+            # profile belongs to the loaded library
+            pmc = profiled_counters(api.library_source_sha256())
+            if pmc and not pmc.get("stale"):
+                result["roofline"] = roofline_block("bc7", nloc, k_ms, "cvttmi_bc7_kernel", insts_per_block=pmc["valu_insts_per_wave"] / 16.0,
+                                                    hbm_bytes_per_block=pmc["hbm_bytes_per_launch"] / float(pmc["blocks"]),
+                                                    waves_per_simd=pmc.get("avg_waves_per_simd"), source=pmc["source"])
+            else:
+                result["roofline"] = roofline_block("bc7", nloc, k_ms, "cvttmi_bc7_kernel")
+            result["roofline"]["note"] = "rank 0's shard (%d blocks) per launch; per-block counters of the 4096^2 profile of the same kernel" % nloc
             result["rank0_search_mblocks_s"] = nloc / k_ms / 1e3
             if not args.no_cpu:
                 # the CPU path on a bounded sample of rank 0's shard (the golden RCPPS table is in use on every rank)
