@@ -72,3 +72,32 @@ def test_three_ranks_ragged_shards_dry_run():
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert r["n_gpus"] == 3 and r["config"]["blocks_per_rank"] == [21 * 64, 21 * 64, 22 * 64]
     assert r["output_check"]["matches_single_process"] is True
+
+
+def test_committed_profiles_belong_to_this_library_and_feed_the_rooflines():
+    """The counters bench.py quotes (VALU instructions per block, HBM bytes per launch) come from profiles/rNN/*.json and are
+    used only for the library they were taken with: the build identity compiled into the library (a hash of the kernel / shim
+    sources, public headers and compiler flags, csrc/Makefile) must equal the one the newest committed summaries carry --
+    otherwise the driver's bench line silently falls back to `bound: "hbm"` without traffic.  No GPU needed."""
+    import glob
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    from convectionkernels_amd import api
+    sha = api.library_source_sha256()
+    assert len(sha) == 64
+    head = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "summary.json")))[-1]))
+    assert head["source_sha256"] == sha, "re-run tools/profile_round.sh + tools/profile_formats.sh and copy the summaries into profiles/"
+    pmc = bench.profiled_counters(sha)
+    assert pmc and not pmc.get("stale") and pmc["blocks"] == 1 << 20
+    r = bench.roofline_block("bc7", pmc["blocks"], 1.55, "k", insts_per_block=pmc["valu_insts_per_wave"] / 16.0,
+                             hbm_bytes_per_block=pmc["hbm_bytes_per_launch"] / float(pmc["blocks"]))
+    assert r["bound"] == "valu" and 0.5 < r["frac"] < 0.8 and 0.99 < r["traffic_over_algorithmic"] < 1.1 and r["hbm"]["frac"] < 0.01
+    fmtc = bench.format_counters(sha)
+    assert fmtc and not fmtc.get("stale")
+    for fmt in ("bc7", "bc7o", "bc7u", "bc6hu", "etc2rgba", "bc1"):
+        c = fmtc[fmt]
+        assert c["valu_wave_insts_per_block"] > 100 and c["hbm_bytes_per_block"] > 64, (fmt, c)
+    # BC6H keeps its search state on the chip: traffic ~ algorithmic (round 3: 687 x)
+    assert fmtc["bc6hu"]["hbm_bytes_per_block"] < 1.1 * bench.ALGO_BYTES["bc6hu"]
+    assert bench.roofline_block("bc1", 4096, 0.04, "k")["bound"] == "hbm"  # no counters: the HBM view alone, with a note
