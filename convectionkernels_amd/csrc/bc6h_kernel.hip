@@ -228,6 +228,16 @@ __device__ __forceinline__ u32 groupBits(u64 ballot, int lane) { return (u32)(ba
 } // namespace
 
 template <bool SIGNED, bool FAST>
+// Developer variant for the mapping A/B VERDICT r3 asks for (make VARIANT=b6_gw EXTRA=-DCVTT_BC6H_GROUPWAVE=1; never the shipped
+// form): a wave is ONE reference group -- lane = candidate * 8 + block: eight partitions of each of the eight blocks are searched
+// side by side (partition 8 j + candidate in step j), the single-subset search runs redundantly in the eight candidate lanes.
+// The two group predicates stay the 8-lane ballot slices they are.  Per-lane partitions mean per-lane subset masks (every pixel
+// step is predicated per lane), and because the mode loop of the commit depends on the group mates' running best at that point of
+// the reference's candidate order (BC67.cpp:2936-2984), the eight candidates of a step still commit ONE AFTER THE OTHER, each
+// followed by a broadcast of the block's best to its eight lanes.  profiles/r04/ab_bc6h_mapping.txt has the measurement.
+#ifndef CVTT_BC6H_GROUPWAVE
+#define CVTT_BC6H_GROUPWAVE 0
+#endif
 #ifndef CVTT_BC6H_WG_WAVES
 #define CVTT_BC6H_WG_WAVES 1 // waves per workgroup (independent of each other: each has its own 18 KB of the LDS block)
 #endif
@@ -239,7 +249,9 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
     const int lane = threadIdx.x & 63;
     // error of round m of subset s of the current partition (indexed by wave-uniform loop counters)
     auto errAt = [&](int m, int s) -> float & { return reinterpret_cast<float &>(meta[kErrBase + m * 2 + s][lane]); };
-    const u32 blockIndex = blockIdx.x * (64u * CVTT_BC6H_WG_WAVES) + threadIdx.x;
+    constexpr bool GW = CVTT_BC6H_GROUPWAVE != 0;
+    static_assert(!GW || CVTT_BC6H_WG_WAVES == 1, "the group-wave variant is one wave per workgroup");
+    const u32 blockIndex = GW ? blockIdx.x * 8u + (threadIdx.x & 7u) : blockIdx.x * (64u * CVTT_BC6H_WG_WAVES) + threadIdx.x;
     const bool valid = blockIndex < A.numBlocks;
 
     PROF_DECL
@@ -451,8 +463,9 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
             // the eager search (content whose deltas do fit).
             bool eagerNow = !(partitioned && aPrec >= 8);
 
-            for (int p = 0; p < numPartitions; p++)
+            for (int pStep = 0; pStep < ((GW && partitioned) ? 4 : numPartitions); pStep++)
             {
+                const int p = (GW && partitioned) ? pStep * 8 + (lane >> 3) : pStep; // GW: a partition per candidate lane
                 const u32 partitionMask = partitioned ? T->partition2[p] : 0u;
                 const bool lazy = !eagerNow;
                 if (partitioned && aPrec >= 8) { if (lazy) { PROF_COUNT(13, 1) } else { PROF_COUNT(11, 1) } }
@@ -474,7 +487,7 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
                     const u32 subsetMask = partitioned ? (subset ? partitionMask : (~partitionMask & 0xffffu)) : 0xffffu;
                     if (subset == 1 && usable0 == 0)
                         break;
-                    const int fixupIndex = __builtin_amdgcn_readfirstlane((subset == 0) ? 0 : (int)T->anchor2[p]);
+                    const int fixupIndex = GW ? ((subset == 0) ? 0 : (int)T->anchor2[p]) : __builtin_amdgcn_readfirstlane((subset == 0) ? 0 : (int)T->anchor2[p]);
                     // the anchor pixel of the subset (its index decides the swap of a round's end points, BC67.cpp:2525-2547)
                     u32 fa = 0, fb = 0;
                     float fixLw[3] = {0.0f, 0.0f, 0.0f};
@@ -600,7 +613,7 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
 
                             PROF_MARK(1)
                             // ---- index selection, one pixel at a time: IndexSelectorHDR.h:100-144 ----
-                            const u32 sm = opaqueUniform(subsetMask);
+                            const u32 sm = GW ? subsetMask : opaqueUniform(subsetMask);
                             bool interpFixup = true; // may an interpolant of this round have a zero exponent field? (wave-uniform)
                             float iw[indexRange][3]; // slow: weighted linear colour of every interpolant
                             float origin[3], axis[3]; // fast: projection axis
@@ -963,7 +976,7 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
                     {
                         const int bit = __builtin_ctz(todo);
                         const int rs = bit >= 12 ? 1 : 0, rm = bit - 12 * rs;
-                        const u32 rmask = opaqueUniform(rs ? partitionMask : (~partitionMask & 0xffffu));
+                        const u32 rmask = GW ? (rs ? partitionMask : (~partitionMask & 0xffffu)) : opaqueUniform(rs ? partitionMask : (~partitionMask & 0xffffu));
                         // the end points as the round had them before it swapped them (the scan's first-minimum rule sees the order)
                         const bool was = ((invBits >> bit) & 1u) != 0;
                         int rq[2][3];
@@ -1098,9 +1111,12 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
                             minErr1 = e;
                     }
                 }
+                for (int cand = 0; cand < ((GW && partitioned) ? 8 : 1); cand++)
+                {
+                const bool act = !(GW && partitioned) || (lane >> 3) == cand; // GW: the candidates commit in the reference's order
                 for (int meta0 = 0; meta0 < 12; meta0++)
                 {
-                    const bool valid0 = ((roundValid0 >> meta0) & 1u) != 0;
+                    const bool valid0 = act && ((roundValid0 >> meta0) & 1u) != 0;
                     const float err0 = errAt(meta0, 0);
                     const bool canBeat = valid0 && ((partitioned ? err0 + minErr1 : err0) < bestError);
                     if (__ballot(canBeat) == 0)
@@ -1210,6 +1226,19 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
                         }
                     }
                 }
+                if (GW && partitioned)
+                {
+                    // the block's best after this candidate's partition, to all eight lanes of the block
+                    const int src = cand * 8 + (lane & 7);
+                    bestError = __shfl(bestError, src);
+                    bestMode = __shfl(bestMode, src);
+                    bestPartition = __shfl(bestPartition, src);
+                    bestSwap = (u32)__shfl((int)bestSwap, src);
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+                        bestEP[i] = (u32)__shfl((int)bestEP[i], src);
+                }
+                } // candidates
             }
         }
     };
@@ -1341,7 +1370,7 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
         }
     }
     // ---- header scatter + indexes (BC67.cpp:2992-3050, BC6H_IO: table from tools/gen_bc6h_layout.py) ----
-    if (valid)
+    if (valid && (!GW || (threadIdx.x >> 3) == 0))
     {
         const bool partitioned = T->bc6hModeInfo[bestMode][1] != 0;
         const int headerBits = partitioned ? 82 : 65;
@@ -1406,7 +1435,7 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
 extern "C" hipError_t cvttmi_launch_bc6h(const void *d_blocks, void *d_out, const CvttBc6hArgs *args,
                                          const CvttDeviceTables *d_tables, int isSigned, hipStream_t stream)
 {
-    const uint32_t waves = (args->numBlocks + 63u) / 64u;
+    const uint32_t waves = CVTT_BC6H_GROUPWAVE ? (args->numBlocks + 7u) / 8u : (args->numBlocks + 63u) / 64u;
     if (waves == 0)
         return hipSuccess;
     const bool fast = (args->flags & CVTTMI_FLAG_BC6H_FAST_INDEXING) != 0;
