@@ -310,3 +310,33 @@ def test_eac_magic_number_division_is_exact():
         p = n * np.uint64(m)
         assert int(p.max()) < (1 << 32)
         assert ((p >> np.uint64(20)) == n // np.uint64(d)).all(), d
+
+
+@pytest.mark.gpu
+def test_gpu_launch_shapes_agree(gpu_ctx, oracle_lib):
+    """The launch shape depends on the number of blocks -- the EAC search has a sixteen-lanes-per-block form for launches of
+    at most 65 536 blocks and a lane-per-block form above, and the colour kernel deals the groups to the eight XCDs in eighths
+    (ragged when the number of groups is no multiple of 8) -- the bytes must not: every size gives the prefix of one large
+    encode, and the small ones equal the oracle."""
+    import torch
+    from convectionkernels_amd import api
+    big = np.concatenate([content.config_blocks(4, 1024, 1024), content.mixed_ldr_blocks(5, 96), content.config_blocks(11, 64, 64)])
+    big = np.ascontiguousarray(big[: 65536 + 264])  # above the EAC threshold, 8 233 groups: no multiple of 8
+    t = torch.from_numpy(big).cuda()
+    opt = api.Options()
+    full_rgba = gpu_ctx.encode_etc2_rgba(t, opt).cpu().numpy()
+    full_rgb = gpu_ctx.encode_etc2(t, opt).cpu().numpy()
+    full_a = gpu_ctx.encode_etc2_alpha(t, opt).cpu().numpy()
+    for n in (8, 24, 72, 1032, 65536, 65544):
+        assert (gpu_ctx.encode_etc2_rgba(t[:n], opt).cpu().numpy() == full_rgba[:n]).all(), n
+        assert (gpu_ctx.encode_etc2(t[:n], opt).cpu().numpy() == full_rgb[:n]).all(), n
+        assert (gpu_ctx.encode_etc2_alpha(t[:n], opt).cpu().numpy() == full_a[:n]).all(), n
+    small = big[:1032]
+    assert (full_rgba[:1032] == oracle_lib.encode_etc2(small, pyref.make_options(), 1, threads=8)).all()
+    # the same for the 11-bit EAC of EncodeETC2Alpha11
+    r11 = content.mixed_r11_blocks(5, 8200)[: 65536 + 64]
+    if r11.shape[0] > 65536:
+        tr = torch.from_numpy(np.ascontiguousarray(r11)).cuda()
+        for sg in (False, True):
+            full = gpu_ctx.encode_etc2_alpha11(tr, signed=sg).cpu().numpy()
+            assert (gpu_ctx.encode_etc2_alpha11(tr[:4096], signed=sg).cpu().numpy() == full[:4096]).all()
