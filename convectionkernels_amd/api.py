@@ -192,6 +192,10 @@ _EXPORTS = (
     "cvttmi_encode_etc2_with_data_device", "cvttmi_encode_etc2_with_data",
     "cvttmi_default_bc7_fine_tuning", "cvttmi_bc7_plan_from_quality", "cvttmi_bc7_plan_from_fine_tuning",
     "cvttmi_host_alloc", "cvttmi_host_free", "cvttmi_host_register", "cvttmi_host_unregister",
+    "cvttmi_shard_block_rows", "cvttmi_multi_create", "cvttmi_multi_destroy", "cvttmi_multi_last_error", "cvttmi_multi_num_devices",
+    "cvttmi_multi_context", "cvttmi_multi_last_shard", "cvttmi_multi_set_rcp_table", "cvttmi_multi_set_exhaustive", "cvttmi_multi_encode",
+    "cvttmi_encode_bc7_multi", "cvttmi_encode_bc1_multi", "cvttmi_encode_bc6h_multi", "cvttmi_encode_etc2_rgba_multi",
+    "cvttmi_dropin_set_devices",
 )
 
 _lib = None
@@ -271,6 +275,26 @@ def load_library():
     lib.cvttmi_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_set_exhaustive.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cvttmi_timing_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
+    if hasattr(lib, "cvttmi_multi_create"):
+        lib.cvttmi_shard_block_rows.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                                ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+        lib.cvttmi_multi_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int]
+        lib.cvttmi_multi_destroy.argtypes = [ctypes.c_void_p]
+        lib.cvttmi_multi_last_error.restype = ctypes.c_char_p
+        lib.cvttmi_multi_last_error.argtypes = [ctypes.c_void_p]
+        lib.cvttmi_multi_num_devices.argtypes = [ctypes.c_void_p]
+        lib.cvttmi_multi_last_shard.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+        lib.cvttmi_multi_set_rcp_table.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.cvttmi_multi_set_exhaustive.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.cvttmi_multi_encode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                            ctypes.c_void_p, ctypes.c_void_p]
+        lib.cvttmi_encode_bc7_multi.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                                ctypes.c_void_p, ctypes.c_void_p]
+        for n in ("cvttmi_encode_bc1_multi", "cvttmi_encode_etc2_rgba_multi"):
+            getattr(lib, n).argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
+        lib.cvttmi_encode_bc6h_multi.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                                 ctypes.c_void_p, ctypes.c_int]
+        lib.cvttmi_dropin_set_devices.argtypes = [ctypes.c_void_p, ctypes.c_int]
     _lib = lib
     return lib
 
@@ -692,6 +716,78 @@ class Context:
 
 
 _default_ctx = {}
+
+
+def shard_block_rows(block_rows, blocks_per_row, rank, world):
+    """cvttmi_shard_block_rows: [first, last) of `rank`'s shard -- whole block rows, group aligned (the C statement of
+    sharding.shard_block_rows; needs no device)"""
+    lib = load_library()
+    lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+    rc = lib.cvttmi_shard_block_rows(block_rows, blocks_per_row, rank, world, ctypes.byref(lo), ctypes.byref(hi))
+    if rc != 0:
+        raise CvttError("cvttmi_shard_block_rows failed (%d)" % rc)
+    return lo.value, hi.value
+
+
+class MultiContext:
+    """One job on several devices behind the C ABI (cvttmi_multi_*, csrc/multi.cpp): one context per entry of `devices` (a
+    device may appear more than once), block-row shards, packed output straight into the caller's buffer.  Host arrays only."""
+    FORMATS = {"bc7": (0, 64, 16), "bc1": (1, 64, 8), "bc6hu": (2, 128, 16), "bc6hs": (3, 128, 16), "etc2": (4, 64, 8), "etc2rgba": (5, 64, 16)}
+
+    def __init__(self, devices):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        self.devices = [int(d) for d in devices]
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        rc = self._lib.cvttmi_multi_create(ctypes.byref(self._h), arr, len(self.devices))
+        if rc != 0:
+            raise CvttError("cvttmi_multi_create(%s) failed with %d" % (self.devices, rc))
+
+    def close(self):
+        if self._h:
+            self._lib.cvttmi_multi_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_rcp_table(self, lut):
+        lut = np.ascontiguousarray(lut, np.float32)
+        assert lut.size == 17
+        rc = self._lib.cvttmi_multi_set_rcp_table(self._h, lut.ctypes.data)
+        if rc != 0:
+            raise CvttError("cvttmi_multi_set_rcp_table failed (%d)" % rc)
+
+    def set_exhaustive(self, on=True):
+        self._lib.cvttmi_multi_set_exhaustive(self._h, 1 if on else 0)
+
+    def last_shards(self):
+        out = []
+        for i in range(len(self.devices)):
+            lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+            self._lib.cvttmi_multi_last_shard(self._h, i, ctypes.byref(lo), ctypes.byref(hi))
+            out.append((lo.value, hi.value))
+        return out
+
+    def encode(self, fmt, blocks, options=None, plan=None, blocks_per_row=0, out=None):
+        code, in_bytes, out_bytes = self.FORMATS[fmt]
+        options = options if options is not None else Options()
+        if fmt == "bc7" and plan is None:
+            plan = BC7EncodingPlan()
+        b = np.ascontiguousarray(blocks)
+        n = b.nbytes // in_bytes
+        if b.nbytes % in_bytes or n % NumParallelBlocks:
+            raise CvttError("blocks must hold a multiple of 8 PixelBlocks")
+        res = out if out is not None else np.empty((n, out_bytes), np.uint8)
+        assert res.nbytes == n * out_bytes and res.flags["C_CONTIGUOUS"]
+        rc = self._lib.cvttmi_multi_encode(self._h, code, res.ctypes.data, b.ctypes.data, n, blocks_per_row,
+                                           ctypes.addressof(options), ctypes.addressof(plan) if plan is not None else None)
+        if rc != 0:
+            raise CvttError("cvttmi_multi_encode(%s) failed (%d): %s" % (fmt, rc, self._lib.cvttmi_multi_last_error(self._h).decode()))
+        return res
 
 
 def default_context(device=0):

@@ -7,22 +7,20 @@
 //
 // The reference's own calls take ONE group of 8 blocks (ConvectionKernels_API.cpp:41-99); on a GPU such a call is a PCIe
 // round trip and a one-wave launch, and sixteen caller threads doing that side by side queue on the device.  They are
-// therefore coalesced: calls of the same kind (format, Options, plan) that arrive while a launch is in flight wait for it,
-// and the first of them then encodes all of them with ONE launch on a shared context (`Coalescer` below; the groups are
-// independent, so the bytes are the ones separate calls give).  A single caller thread never waits: nothing is in flight
-// when its call arrives.  CVTTMI_DROPIN_COALESCE=0 turns it off (every call on its thread's own context).
+// therefore coalesced: calls of the same kind (format, Options, plan) that arrive while a launch of that kind is in flight
+// wait for it, and the first of them then encodes all of them with ONE launch (coalescer.h: one slot -- context and queue --
+// per kind, so callers of different kinds run side by side; the groups are independent, so the bytes are the ones separate
+// calls give).  A single caller thread never waits: nothing is in flight when its call arrives.
+// CVTTMI_DROPIN_COALESCE=0 turns it off (every call on its thread's own context).
 #include "../../include/cvtt/ConvectionKernels.h"
 #include "../../include/cvtt_mi355x.h"
+#include "coalescer.h"
 
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
-#include <atomic>
-#include <chrono>
-#include <condition_variable>
 #include <mutex>
-#include <thread>
 #include <new>
 #include <vector>
 
@@ -71,7 +69,7 @@ namespace
 
     const cvttmi_options *opt(const cvtt::Options &o) { return reinterpret_cast<const cvttmi_options *>(&o); }
 
-    // ---- coalescing of concurrent one-group calls ----
+    // ---- coalescing of concurrent one-group calls (coalescer.h) ----
     struct CallKey
     {
         int kind;                 // which entry point (and its integer argument)
@@ -86,166 +84,6 @@ namespace
                    (!hasAlloc || memcmp(&allocOptions, &o.allocOptions, sizeof(allocOptions)) == 0) && (!hasPlan || memcmp(&plan, &o.plan, sizeof(plan)) == 0);
         }
     };
-    struct Request
-    {
-        const CallKey *key;
-        const uint8_t *in;
-        uint8_t *out;
-        int rc;
-        std::atomic<bool> done;
-    };
-    // encode `numBlocks` contiguous blocks with the given key on `ctx`
-    typedef int (*BatchFn)(cvttmi_context *ctx, const CallKey &key, uint8_t *out, const uint8_t *in, size_t numBlocks);
-
-    class Coalescer
-    {
-    public:
-        static const size_t kMaxGroups = 256; // groups per launch (256 x 8 blocks: 128 KiB of PixelBlockU8)
-        Coalescer() : ctx_(NULL), busy_(false), recent_(1), busyFlag_(false), stageIn_(NULL), stageOut_(NULL) {}
-        ~Coalescer()
-        {
-            if (ctx_)
-            {
-                if (stageIn_) cvttmi_host_free(ctx_, stageIn_);
-                if (stageOut_) cvttmi_host_free(ctx_, stageOut_);
-                cvttmi_destroy(ctx_);
-            }
-        }
-        static bool enabled()
-        {
-            static const bool on = !(getenv("CVTTMI_DROPIN_COALESCE") && atoi(getenv("CVTTMI_DROPIN_COALESCE")) == 0);
-            return on;
-        }
-        // one group: 8 blocks of inBytes / 8 bytes each in, outBytes out
-        int call(const CallKey &key, uint8_t *out, const uint8_t *in, size_t inBytes, size_t outBytes, BatchFn fn)
-        {
-            Request me;
-            me.key = &key;
-            me.in = in;
-            me.out = out;
-            me.rc = CVTTMI_OK;
-            me.done.store(false, std::memory_order_relaxed);
-            std::unique_lock<std::mutex> lock(mu_);
-            pending_.push_back(&me);
-            for (;;)
-            {
-                if (me.done.load(std::memory_order_acquire))
-                    return me.rc;
-                if (!busy_)
-                    break; // nothing in flight: this thread runs the next launch
-                // A launch is in flight (tens of microseconds): poll for a while without the lock -- a futex wake-up costs
-                // about as much as the launch itself -- and only then sleep on the condition variable.
-                lock.unlock();
-                const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-                bool turn = false;
-                while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(400))
-                {
-                    if (me.done.load(std::memory_order_acquire) || !busyFlag_.load(std::memory_order_acquire))
-                    {
-                        turn = true;
-                        break;
-                    }
-                    std::this_thread::yield();
-                }
-                lock.lock();
-                if (!turn && busy_ && !me.done.load(std::memory_order_acquire))
-                    cv_.wait_for(lock, std::chrono::milliseconds(2));
-            }
-            busy_ = true;
-            busyFlag_.store(true, std::memory_order_release);
-            // The callers of the previous launch return, prepare their next group and arrive here within a few microseconds of
-            // each other; the first one to arrive would otherwise leave with a launch of its own and make the others wait for
-            // it.  So when recent launches carried more calls than are waiting now, give the others a moment (bounded: 100 us,
-            // about one one-wave launch; measured with 16 callers, BC7 / ETC2 RGBA calls per second in total: no wait 96 k / 30 k,
-            // 40 us 129 k / 46 k, 80 us 137 k / 51 k, 150 us 147 k / 56 k) -- a lone caller thread (recent_ == 1) never waits, and a
-            // pool that shrinks pays the wait once per lost thread (recent_ falls by one per launch).
-            if (pending_.size() < recent_)
-            {
-                const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-                static const int windowUs = getenv("CVTTMI_DROPIN_WINDOW_US") ? atoi(getenv("CVTTMI_DROPIN_WINDOW_US")) : 100; // developer knob
-                while (pending_.size() < recent_ && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(windowUs))
-                {
-                    lock.unlock();
-                    std::this_thread::yield();
-                    lock.lock();
-                }
-            }
-            // every waiting call of this kind, in arrival order, goes into this launch
-            std::vector<Request *> batch;
-            for (size_t i = 0; i < pending_.size();)
-            {
-                if (batch.size() < kMaxGroups && pending_[i]->key->same(key))
-                {
-                    batch.push_back(pending_[i]);
-                    pending_.erase(pending_.begin() + i);
-                }
-                else
-                    i++;
-            }
-            // what "recently" means: this launch, or one less than before when it carried fewer calls (a lone caller is back at 1 after a few calls)
-            recent_ = batch.size() >= recent_ ? batch.size() : recent_ - 1;
-            lock.unlock();
-            int rc = ensure(inBytes, outBytes);
-            if (rc == CVTTMI_OK)
-            {
-                if (batch.size() == 1)
-                    rc = fn(ctx_, key, out, in, cvtt::NumParallelBlocks);
-                else
-                {
-                    for (size_t i = 0; i < batch.size(); i++)
-                        memcpy(static_cast<uint8_t *>(stageIn_) + i * inBytes, batch[i]->in, inBytes);
-                    rc = fn(ctx_, key, static_cast<uint8_t *>(stageOut_), static_cast<const uint8_t *>(stageIn_), batch.size() * cvtt::NumParallelBlocks);
-                    if (rc == CVTTMI_OK)
-                        for (size_t i = 0; i < batch.size(); i++)
-                            memcpy(batch[i]->out, static_cast<uint8_t *>(stageOut_) + i * outBytes, outBytes);
-                }
-            }
-            lock.lock();
-            for (size_t i = 0; i < batch.size(); i++)
-            {
-                Request *r = batch[i];
-                r->rc = rc;
-                r->done.store(true, std::memory_order_release); // (a request other than `me` may be gone right after this)
-            }
-            busy_ = false;
-            busyFlag_.store(false, std::memory_order_release);
-            cv_.notify_all();
-            return rc;
-        }
-        const char *lastError() { return ctx_ ? cvttmi_last_error(ctx_) : "no context"; }
-
-    private:
-        int ensure(size_t inBytes, size_t outBytes)
-        {
-            if (!ctx_)
-            {
-                const char *dev = getenv("CVTTMI_DEVICE");
-                const int rc = cvttmi_create(&ctx_, dev ? atoi(dev) : 0);
-                if (rc != CVTTMI_OK)
-                {
-                    fprintf(stderr, "cvtt (MI355X): no usable gfx950 device (cvttmi_create = %d); there is no CPU fallback\n", rc);
-                    abort();
-                }
-            }
-            // page-locked staging for the gathered groups (the largest block type: PixelBlockF16 / 16-byte outputs)
-            if (!stageIn_ && cvttmi_host_alloc(ctx_, &stageIn_, kMaxGroups * 8 * 128) != CVTTMI_OK)
-                return CVTTMI_E_HIP;
-            if (!stageOut_ && cvttmi_host_alloc(ctx_, &stageOut_, kMaxGroups * 8 * 64) != CVTTMI_OK)
-                return CVTTMI_E_HIP;
-            (void)inBytes;
-            (void)outBytes;
-            return CVTTMI_OK;
-        }
-        cvttmi_context *ctx_;
-        std::mutex mu_;
-        std::condition_variable cv_;
-        std::vector<Request *> pending_;
-        bool busy_;
-        size_t recent_; // calls per launch, recently
-        std::atomic<bool> busyFlag_; // == busy_, readable without the lock
-        void *stageIn_, *stageOut_;
-    };
-    Coalescer g_coalescer;
 
     CallKey makeKey(int kind, const cvtt::Options &o, const cvttmi_options *alloc = NULL, const cvtt::BC7EncodingPlan *plan = NULL)
     {
@@ -261,16 +99,9 @@ namespace
             memcpy(&k.plan, plan, sizeof(k.plan));
         return k;
     }
-    void checkShared(int rc, const char *what)
-    {
-        if (rc != CVTTMI_OK)
-        {
-            fprintf(stderr, "cvtt (MI355X): %s failed (%d): %s\n", what, rc, g_coalescer.lastError());
-            abort();
-        }
-    }
 
     enum Kind { K_BC7, K_BC1, K_BC2, K_BC3, K_BC4U, K_BC4S, K_BC5U, K_BC5S, K_BC6HU, K_BC6HS, K_ETC1, K_ETC2, K_ETC2RGBA, K_ETC2PT, K_ETC2A, K_A11U, K_A11S };
+    // encode `n` contiguous blocks with the given key on `ctx`
     int encodeBatch(cvttmi_context *ctx, const CallKey &k, uint8_t *out, const uint8_t *in, size_t n)
     {
         const cvttmi_options *o = &k.options;
@@ -297,15 +128,111 @@ namespace
         }
         return CVTTMI_E_INVALID;
     }
+
+    // the device side of a coalescer slot
+    void *slotCreate()
+    {
+        cvttmi_context *c = NULL;
+        const char *dev = getenv("CVTTMI_DEVICE");
+        const int rc = cvttmi_create(&c, dev ? atoi(dev) : 0);
+        if (rc != CVTTMI_OK)
+        {
+            fprintf(stderr, "cvtt (MI355X): no usable gfx950 device (cvttmi_create = %d); there is no CPU fallback\n", rc);
+            abort();
+        }
+        return c;
+    }
+    void slotDestroy(void *ctx) { cvttmi_destroy(static_cast<cvttmi_context *>(ctx)); }
+    void *slotHostAlloc(void *ctx, size_t bytes)
+    {
+        void *p = NULL;
+        return cvttmi_host_alloc(static_cast<cvttmi_context *>(ctx), &p, bytes) == CVTTMI_OK ? p : NULL;
+    }
+    void slotHostFree(void *ctx, void *p) { cvttmi_host_free(static_cast<cvttmi_context *>(ctx), p); }
+    int slotEncode(void *ctx, const CallKey &key, uint8_t *out, const uint8_t *in, size_t numGroups)
+    {
+        return encodeBatch(static_cast<cvttmi_context *>(ctx), key, out, in, numGroups * cvtt::NumParallelBlocks);
+    }
+    typedef cvttmi_dropin::Coalescer<CallKey> DropinCoalescer;
+    int envInt(const char *name, int dflt) { return getenv(name) ? atoi(getenv(name)) : dflt; }
+    DropinCoalescer &coalescer()
+    {
+        static const cvttmi_dropin::Backend<CallKey> backend = {slotCreate, slotDestroy, slotHostAlloc, slotHostFree, slotEncode};
+        // developer knobs: groups per launch (tests: more callers than a launch takes), gather window
+        static DropinCoalescer c(backend, static_cast<size_t>(envInt("CVTTMI_DROPIN_MAX_GROUPS", 256)), envInt("CVTTMI_DROPIN_WINDOW_US", 100),
+                                 sizeof(cvtt::PixelBlockF16) * cvtt::NumParallelBlocks, 16 * cvtt::NumParallelBlocks);
+        return c;
+    }
+    bool coalesceEnabled()
+    {
+        static const bool on = envInt("CVTTMI_DROPIN_COALESCE", 1) != 0;
+        return on;
+    }
+
     // one reference-style call: a group of 8 blocks, `inBytes` in, `outBytes` out
     void oneGroup(int kind, uint8_t *pBC, const void *pBlocks, size_t inBytes, size_t outBytes, const cvtt::Options &options, const char *what,
                   const cvttmi_options *alloc = NULL, const cvtt::BC7EncodingPlan *plan = NULL)
     {
         const CallKey key = makeKey(kind, options, alloc, plan);
-        if (Coalescer::enabled())
-            checkShared(g_coalescer.call(key, pBC, static_cast<const uint8_t *>(pBlocks), inBytes, outBytes, encodeBatch), what);
-        else
-            check(encodeBatch(context(), key, pBC, static_cast<const uint8_t *>(pBlocks), cvtt::NumParallelBlocks), what);
+        if (coalesceEnabled())
+        {
+            void *ran = NULL;
+            const int rc = coalescer().call(key, pBC, static_cast<const uint8_t *>(pBlocks), inBytes, outBytes, &ran);
+            if (rc == CVTTMI_OK)
+                return;
+            if (rc != DropinCoalescer::kNoSlot) // (kNoSlot: more kinds in flight than slots -- this thread's own context below)
+            {
+                fprintf(stderr, "cvtt (MI355X): %s failed (%d): %s\n", what, rc, ran ? cvttmi_last_error(static_cast<cvttmi_context *>(ran)) : "no staging memory");
+                abort();
+            }
+        }
+        check(encodeBatch(context(), key, pBC, static_cast<const uint8_t *>(pBlocks), cvtt::NumParallelBlocks), what);
+    }
+
+    // ---- the device list of the *Batch entry points (cvtt_mi355x.h, cvttmi_dropin_set_devices) ----
+    const size_t kMultiMinBlocks = 65536; // below this a second device's launch and transfers cost more than they save
+    std::mutex g_devMu;
+    bool g_devInit = false;
+    std::vector<int> g_devList;
+    cvttmi_multi *g_multi = NULL;
+    // the handle when the list has several entries and the call is large enough, else NULL (single device: context())
+    cvttmi_multi *multiFor(size_t numBlocks)
+    {
+        std::lock_guard<std::mutex> lock(g_devMu);
+        if (!g_devInit)
+        {
+            g_devInit = true;
+            if (const char *e = getenv("CVTTMI_DEVICES"))
+                for (const char *p = e; *p;)
+                {
+                    char *end = NULL;
+                    const long v = strtol(p, &end, 10);
+                    if (end == p)
+                        break;
+                    g_devList.push_back((int)v);
+                    p = (*end == ',') ? end + 1 : end;
+                }
+        }
+        if (g_devList.size() < 2 || numBlocks < kMultiMinBlocks)
+            return NULL;
+        if (!g_multi)
+        {
+            const int rc = cvttmi_multi_create(&g_multi, g_devList.data(), (int)g_devList.size());
+            if (rc != CVTTMI_OK)
+            {
+                fprintf(stderr, "cvtt (MI355X): device list not usable (cvttmi_multi_create = %d); there is no CPU fallback\n", rc);
+                abort();
+            }
+        }
+        return g_multi;
+    }
+    void checkMulti(cvttmi_multi *m, int rc, const char *what)
+    {
+        if (rc != CVTTMI_OK)
+        {
+            fprintf(stderr, "cvtt (MI355X): %s failed (%d): %s\n", what, rc, cvttmi_multi_last_error(m));
+            abort();
+        }
     }
 
     // What survives of the reference's 136 KB ETC2 scratch: the allocator context (for ReleaseETC2Data) and the Options of
@@ -355,11 +282,16 @@ namespace cvtt
 
         void EncodeBC7Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options, const BC7EncodingPlan &plan)
         {
+            if (cvttmi_multi *m = multiFor(numBlocks))
+                return checkMulti(m, cvttmi_multi_encode(m, CVTTMI_FMT_BC7, pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, 0, opt(options),
+                                                         reinterpret_cast<const cvttmi_bc7_plan *>(&plan)), "EncodeBC7");
             check(cvttmi_encode_bc7(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options),
                                     reinterpret_cast<const cvttmi_bc7_plan *>(&plan)), "EncodeBC7");
         }
         void EncodeBC1Batch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
         {
+            if (cvttmi_multi *m = multiFor(numBlocks))
+                return checkMulti(m, cvttmi_multi_encode(m, CVTTMI_FMT_BC1, pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, 0, opt(options), NULL), "EncodeBC1");
             check(cvttmi_encode_bc1(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options)), "EncodeBC1");
         }
 #define CVTT_S3TC_BATCH(NAME, PIXELTYPE, CALL)                                                                                  \
@@ -390,10 +322,14 @@ namespace cvtt
 
         void EncodeBC6HUBatch(uint8_t *pBC, const PixelBlockF16 *pBlocks, size_t numBlocks, const Options &options)
         {
+            if (cvttmi_multi *m = multiFor(numBlocks))
+                return checkMulti(m, cvttmi_multi_encode(m, CVTTMI_FMT_BC6HU, pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, 0, opt(options), NULL), "EncodeBC6HU");
             check(cvttmi_encode_bc6h(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), 0), "EncodeBC6HU");
         }
         void EncodeBC6HSBatch(uint8_t *pBC, const PixelBlockF16 *pBlocks, size_t numBlocks, const Options &options)
         {
+            if (cvttmi_multi *m = multiFor(numBlocks))
+                return checkMulti(m, cvttmi_multi_encode(m, CVTTMI_FMT_BC6HS, pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, 0, opt(options), NULL), "EncodeBC6HS");
             check(cvttmi_encode_bc6h(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), 1), "EncodeBC6HS");
         }
         void EncodeETC2PunchthroughAlphaBatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options, ETC2CompressionData *data)
@@ -411,6 +347,10 @@ namespace cvtt
         }
         void EncodeETC2RGBABatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options, ETC2CompressionData *data)
         {
+            // (sharded only when the scratch was allocated with the Options of this call: the sharded form has one Options argument)
+            if (!allocOpt(data) || memcmp(allocOpt(data), &options, sizeof(cvttmi_options)) == 0)
+                if (cvttmi_multi *m = multiFor(numBlocks))
+                    return checkMulti(m, cvttmi_multi_encode(m, CVTTMI_FMT_ETC2_RGBA, pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, 0, opt(options), NULL), "EncodeETC2RGBA");
             check(cvttmi_encode_etc2_with_data(context(), pBC, reinterpret_cast<const uint8_t *>(pBlocks), numBlocks, opt(options), allocOpt(data), CVTTMI_ETC2_RGBA), "EncodeETC2RGBA");
         }
         void EncodeETC2AlphaBatch(uint8_t *pBC, const PixelBlockU8 *pBlocks, size_t numBlocks, const Options &options)
@@ -488,4 +428,19 @@ namespace cvtt
             freeFunc(ctx, data, sizeof(Etc1Marker));
         }
     }
+}
+
+extern "C" int cvttmi_dropin_set_devices(const int *devices, int numDevices)
+{
+    if (numDevices < 0 || (numDevices > 0 && !devices))
+        return CVTTMI_E_INVALID;
+    std::lock_guard<std::mutex> lock(g_devMu);
+    g_devInit = true;
+    g_devList.assign(devices, devices + numDevices);
+    if (g_multi)
+    {
+        cvttmi_multi_destroy(g_multi);
+        g_multi = NULL;
+    }
+    return CVTTMI_OK;
 }

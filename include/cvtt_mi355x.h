@@ -299,6 +299,49 @@ int cvttmi_decode_bc7(cvttmi_context *ctx, uint8_t *blocks, const uint8_t *bc, s
 int cvttmi_decode_bc6h_device(cvttmi_context *ctx, void *d_blocksF16, const void *d_bc, size_t numBlocks, int isSigned, void *hipStream);
 int cvttmi_decode_bc6h(cvttmi_context *ctx, uint8_t *blocksF16, const uint8_t *bc, size_t numBlocks, int isSigned);
 
+/* ---- one job on several devices (csrc/multi.cpp).  The north-star's "large images shard by block row across the GPUs of one
+ * node", for callers of this C interface (the reference has no counterpart: its callers parallelise by threads over groups,
+ * etc2packer.cpp:215-281).  Groups of 8 blocks are independent, so the search needs no exchange: the job is cut into
+ * contiguous ranges of whole block rows, moved to the next group boundary where a row is no multiple of 8 blocks
+ * (cvttmi_shard_block_rows -- the same rule as convectionkernels_amd/sharding.py), each range is encoded by its own context on
+ * its own device from its own host thread, and the packed blocks land in `out` at the range's offset.  Output bytes equal the
+ * single-device call's.  `devices` may name a device more than once (a context each).  blocksPerRow = blocks in one block row of
+ * the tiled image (ceil(ceil(w/4)/8)*8, cvttmi_tiled_block_count); 0 = no rows, shard by groups.
+ * cvttmi_multi_*: a handle owning one context per list entry.  cvttmi_encode_*_multi: stateless forms that keep a handle per
+ * device list for the life of the process.  Between processes (one per GPU) the packed output is gathered with RCCL send/recv
+ * over xGMI instead: sharding.py, bench.py --gpus N. ---- */
+#define CVTTMI_FMT_BC7 0
+#define CVTTMI_FMT_BC1 1
+#define CVTTMI_FMT_BC6HU 2
+#define CVTTMI_FMT_BC6HS 3
+#define CVTTMI_FMT_ETC2_RGB 4
+#define CVTTMI_FMT_ETC2_RGBA 5
+typedef struct cvttmi_multi cvttmi_multi;
+int cvttmi_shard_block_rows(size_t blockRows, size_t blocksPerRow, int rank, int world, size_t *firstBlock, size_t *lastBlock);
+int cvttmi_multi_create(cvttmi_multi **out, const int *devices, int numDevices);
+void cvttmi_multi_destroy(cvttmi_multi *m);
+const char *cvttmi_multi_last_error(const cvttmi_multi *m);
+int cvttmi_multi_num_devices(const cvttmi_multi *m);
+cvttmi_context *cvttmi_multi_context(cvttmi_multi *m, int index);
+int cvttmi_multi_last_shard(const cvttmi_multi *m, int index, size_t *firstBlock, size_t *lastBlock);
+int cvttmi_multi_set_rcp_table(cvttmi_multi *m, const float lut[17]);
+int cvttmi_multi_set_exhaustive(cvttmi_multi *m, int exhaustive);
+/* format = CVTTMI_FMT_*; plan: BC7 only (NULL otherwise); host buffers (page-locked ones are transferred in place) */
+int cvttmi_multi_encode(cvttmi_multi *m, int format, uint8_t *out, const uint8_t *blocks, size_t numBlocks, size_t blocksPerRow,
+                        const cvttmi_options *options, const cvttmi_bc7_plan *plan);
+int cvttmi_encode_bc7_multi(const int *devices, int numDevices, uint8_t *out, const uint8_t *blocks, size_t numBlocks, size_t blocksPerRow,
+                            const cvttmi_options *options, const cvttmi_bc7_plan *plan);
+int cvttmi_encode_bc1_multi(const int *devices, int numDevices, uint8_t *out, const uint8_t *blocks, size_t numBlocks, size_t blocksPerRow,
+                            const cvttmi_options *options);
+int cvttmi_encode_bc6h_multi(const int *devices, int numDevices, uint8_t *out, const uint8_t *blocks, size_t numBlocks, size_t blocksPerRow,
+                             const cvttmi_options *options, int isSigned);
+int cvttmi_encode_etc2_rgba_multi(const int *devices, int numDevices, uint8_t *out, const uint8_t *blocks, size_t numBlocks, size_t blocksPerRow,
+                                  const cvttmi_options *options);
+/* The device list of the C++ face's *Batch entry points (cvtt::Kernels::EncodeBC7Batch, EncodeBC1Batch, EncodeBC6HU/SBatch,
+ * EncodeETC2RGBABatch): more than one entry = calls of at least 65 536 blocks are sharded over the list as above (by groups).
+ * Default: the environment variable CVTTMI_DEVICES ("0,1,2,3"), else the single device CVTTMI_DEVICE (default 0). */
+int cvttmi_dropin_set_devices(const int *devices, int numDevices);
+
 /* Arithmetic self-test: evaluates binary32 divide and square root on `count` pseudo-random finite
  * operand patterns (zeros, denormals and both signs included) with the expressions and compiler
  * flags the encoders use, and counts results that differ from the host's DIVSS / SQRTSS -- the

@@ -1,0 +1,132 @@
+"""Several devices behind the C ABI (csrc/multi.cpp; VERDICT r4 missing 2 / next 6).
+CPU: the C shard rule equals sharding.shard_block_rows for ragged tables.  GPU (one device is enough: the list may name it
+more than once): ragged shards of every format equal the single-context output and the reference-made hashes, the
+stateless *_multi entry points, and the C++ face's *Batch calls with a device list."""
+import ctypes
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import content
+from convectionkernels_amd import api, sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_c_shard_rule_equals_the_python_one():
+    for rows, per_row in [(4096, 4096), (1024, 1024), (7, 24), (3, 8), (1, 8), (5, 12), (64, 1028), (9, 4), (0, 8), (13, 20)]:
+        for world in (1, 2, 3, 5, 8):
+            covered = 0
+            for r in range(world):
+                lo, hi = api.shard_block_rows(rows, per_row, r, world)
+                assert (lo, hi) == sharding.shard_block_rows(rows, per_row, r, world), (rows, per_row, r, world)
+                assert lo == covered and lo % 8 == 0 or hi == lo
+                covered = max(covered, hi)
+            assert covered == rows * per_row
+    lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+    lib = api.load_library()
+    assert lib.cvttmi_shard_block_rows(4, 8, 3, 3, ctypes.byref(lo), ctypes.byref(hi)) == -1  # rank outside the world
+
+
+@pytest.mark.gpu
+def test_multi_ragged_shards_equal_single_context(gpu_ctx, oracle_lib):
+    """devices = {0,0,0}: three contexts, block rows that are no multiple of the world size and a row length that is no
+    multiple of 8 blocks; every format; bytes equal the one-context call's, and BC7's equal the oracle's"""
+    m = api.MultiContext([0, 0, 0])
+    rcp = gpu_ctx.get_rcp_table()
+    m.set_rcp_table(rcp)
+    ldr = content.mixed_ldr_blocks(91, 7 * 5 * 3 // 3)  # 35 groups = 280 blocks
+    ldr = ldr[:7 * 40]                                    # 7 block rows of 40 blocks
+    hdr = content.mixed_hdr_blocks(92, 35)[:7 * 40]
+    opt, plan = api.Options(), api.BC7EncodingPlan()
+    got = m.encode("bc7", ldr, opt, plan, blocks_per_row=40)
+    assert m.last_shards() == [sharding.shard_block_rows(7, 40, r, 3) for r in range(3)]
+    assert (got == gpu_ctx.encode_bc7(ldr, opt, plan)).all()
+    exp = oracle_lib.encode_bc7(ldr, np.frombuffer(opt.tobytes(), np.uint8).copy(), np.frombuffer(plan.tobytes(), np.uint8).copy(), rcp, 4)
+    assert (got == exp).all()
+    assert (m.encode("bc1", ldr, opt, blocks_per_row=40) == gpu_ctx.encode_bc1(ldr, opt)).all()
+    assert (m.encode("bc6hu", hdr, opt, blocks_per_row=40) == gpu_ctx.encode_bc6h(hdr, opt, signed=False)).all()
+    assert (m.encode("bc6hs", hdr, opt, blocks_per_row=40) == gpu_ctx.encode_bc6h(hdr, opt, signed=True)).all()
+    assert (m.encode("etc2", ldr, opt, blocks_per_row=40) == gpu_ctx.encode_etc2(ldr, opt)).all()
+    assert (m.encode("etc2rgba", ldr, opt, blocks_per_row=12) == gpu_ctx.encode_etc2_rgba(ldr, opt)).all()  # 12: rows end inside a group
+    # fewer rows than devices: empty shards
+    two = ldr[:16]
+    assert (api.MultiContext([0, 0, 0, 0, 0]).encode("bc7", two, opt, plan, blocks_per_row=8) == gpu_ctx.encode_bc7(two, opt, plan)).all()
+    # stateless form
+    lib = api.load_library()
+    devs = (ctypes.c_int * 2)(0, 0)
+    out = np.zeros((ldr.shape[0], 16), np.uint8)
+    assert lib.cvttmi_encode_bc7_multi(devs, 2, out.ctypes.data, ldr.ctypes.data, ldr.shape[0], 40, ctypes.addressof(opt), ctypes.addressof(plan)) == 0
+    assert (out == got).all() or (out == gpu_ctx.encode_bc7(ldr, opt, plan)).all()
+    out6 = np.zeros((hdr.shape[0], 16), np.uint8)
+    assert lib.cvttmi_encode_bc6h_multi(devs, 2, out6.ctypes.data, hdr.ctypes.data, hdr.shape[0], 0, ctypes.addressof(opt), 1) == 0
+    assert (out6 == gpu_ctx.encode_bc6h(hdr, opt, signed=True)).all()
+
+
+@pytest.mark.gpu
+def test_multi_config5_hash(gpu_ctx):
+    """BASELINE config 5 through the multi-device entry point with devices = {0,0,0}: 16384x16384, 4096 block rows over three
+    contexts (1365 / 1365 / 1366 rows), SHA-256 of the 256 MiB equal to the reference's"""
+    from convectionkernels_amd import synth
+    h = json.load(open(os.path.join(GOLD, "config_hashes.json")))
+    m = api.MultiContext([0, 0, 0])
+    m.set_rcp_table(np.array(h["rcp_hex"], np.uint32).view(np.float32))
+    blocks = synth.tile_blocks(synth.image_rgba8(5, 16384, 16384))
+    out = m.encode("bc7", blocks, api.Options(), api.BC7EncodingPlan(), blocks_per_row=4096)
+    shards = m.last_shards()
+    assert shards == [(0, 1365 * 4096), (1365 * 4096, 2730 * 4096), (2730 * 4096, 4096 * 4096)]
+    band = out.shape[0] // 4
+    for i in range(4):
+        assert hashlib.sha256(out[i * band:(i + 1) * band].tobytes()).hexdigest() == h["config5_band_hashes"][i], "band %d" % i
+    assert hashlib.sha256(out.tobytes()).hexdigest() == h["config5_bc7_16384_seed5"]
+
+
+CXX_MULTI = r"""
+#include "cvtt/ConvectionKernels.h"
+#include "cvtt_mi355x.h"
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+int main()
+{
+    const size_t n = 65536 + 8 * 37; // above the sharding threshold, ragged over three devices
+    std::vector<cvtt::PixelBlockU8> in(n);
+    unsigned long long s = 99;
+    for (size_t i = 0; i < n * 64; i++)
+    {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        reinterpret_cast<unsigned char *>(in.data())[i] = (unsigned char)(s >> 56);
+    }
+    std::vector<unsigned char> one(n * 16), many(n * 16), one1(n * 8), many1(n * 8);
+    cvtt::Options options;
+    cvtt::BC7EncodingPlan plan;
+    cvtt::Kernels::ConfigureBC7EncodingPlanFromQuality(plan, 30);
+    cvtt::Kernels::EncodeBC7Batch(one.data(), in.data(), n, options, plan);
+    cvtt::Kernels::EncodeBC1Batch(one1.data(), in.data(), n, options);
+    const int devices[3] = {0, 0, 0};
+    if (cvttmi_dropin_set_devices(devices, 3) != 0)
+        return 2;
+    cvtt::Kernels::EncodeBC7Batch(many.data(), in.data(), n, options, plan);
+    cvtt::Kernels::EncodeBC1Batch(many1.data(), in.data(), n, options);
+    printf("multi %d %d\n", memcmp(one.data(), many.data(), n * 16) != 0, memcmp(one1.data(), many1.data(), n * 8) != 0);
+    return 0;
+}
+"""
+
+
+@pytest.mark.gpu
+def test_cxx_batch_calls_honour_the_device_list(tmp_path, gpu_ctx):
+    src = tmp_path / "multi.cpp"
+    src.write_text(CXX_MULTI)
+    exe = tmp_path / "multi"
+    libdir = os.path.dirname(os.path.abspath(os.environ.get("CVTTMI_LIB", api._LIB_PATH)))
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lcvtt_mi355x", "-Wl,-rpath," + libdir])
+    assert subprocess.check_output([str(exe)], timeout=600).decode().split() == ["multi", "0", "0"]
+    env = dict(os.environ, CVTTMI_DEVICES="0,0")
+    assert subprocess.check_output([str(exe)], timeout=600, env=env).decode().split() == ["multi", "0", "0"]

@@ -85,6 +85,16 @@ int main(int argc, char **argv)
                "\"us_per_call_16_threads\": %.2f, \"calls_per_s_16_threads\": %.0f, \"mblocks_s_16_threads\": %.5f}",
                f ? ", " : "", names[f], 1e6 / c1, c1, c1 * 8 / 1e6, 16e6 / c16, c16, c16 * 8 / 1e6);
     }
+    // a pool of mixed kinds: sixteen threads, four different Options (per-texture weights) -- one coalescer slot per kind, so
+    // the four kinds launch side by side (round 4: one busy flag serialised them)
+    {
+        static cvtt::Options mixed[4];
+        for (int k = 0; k < 4; k++)
+            mixed[k].redWeight = 0.25f + 0.25f * (float)k;
+        auto bc7m = [&](int t, int g) { cvtt::Kernels::EncodeBC7(out[t], in[g], mixed[t & 3], plan); };
+        const double c16 = callsPerSecond(maxThreads, seconds, bc7m);
+        printf(", \"bc7_mixed_4_kinds\": {\"us_per_call_16_threads\": %.2f, \"calls_per_s_16_threads\": %.0f, \"mblocks_s_16_threads\": %.5f}", 16e6 / c16, c16, c16 * 8 / 1e6);
+    }
     printf(", \"blocks_per_call\": 8, \"caller_threads\": [1, %d]}\n", maxThreads);
     return 0;
 }
