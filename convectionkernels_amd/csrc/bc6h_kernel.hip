@@ -238,6 +238,20 @@ template <bool SIGNED, bool FAST>
 #ifndef CVTT_BC6H_GROUPWAVE
 #define CVTT_BC6H_GROUPWAVE 0
 #endif
+// Lowest two-subset precision that is searched lazily (chains without errors, then only the rounds of pairs that can be
+// committed are evaluated).  8: where a round fits its own delta with probability 2^-8 or less on content without structure.
+// 7 (the 7-bit mode, 6-bit deltas: one round in nine fits its own delta) was built and measured in round 5 with the per-lane
+// replay below: 157.3 ms against 156.2 ms for config 3 (profiles/r05/ab_bc6h.txt) -- a lane that has one legal pair has many
+// (neighbouring refine rounds quantise to neighbouring end points), so the wave's busiest lane replays about ten rounds per
+// partition and the pair search + replay cost what the skipped errors saved.  6 is never lazy: its mode stores no deltas.
+#ifndef CVTT_BC6H_LAZY_MIN
+#define CVTT_BC6H_LAZY_MIN 8
+#endif
+// a partition whose per-lane replay needs more than this many rounds (both subsets, the wave's busiest lane each) switches the rest
+// of the precision to the eager search: content whose deltas do fit
+#ifndef CVTT_BC6H_LAZY_SWITCH
+#define CVTT_BC6H_LAZY_SWITCH 6
+#endif
 #ifndef CVTT_BC6H_WG_WAVES
 #define CVTT_BC6H_WG_WAVES 1 // waves per workgroup (independent of each other: each has its own 18 KB of the LDS block)
 #endif
@@ -461,7 +475,14 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
             // again, with errors (the replay below: code of its own, so that the chains' registers and branches do not know
             // about it).  The first partition of a precision that needs a replay switches the rest of the precision back to
             // the eager search (content whose deltas do fit).
-            bool eagerNow = !(partitioned && aPrec >= 8);
+            bool eagerNow = !(partitioned && aPrec >= CVTT_BC6H_LAZY_MIN);
+            // A precision with ONE mode (7, 9, 10 bits) has no coupling between the lanes of a group in its commit loop: a lane
+            // commits a pair iff the pair beats its best and is legal, whatever its group mates do (the mode loop of
+            // BC67.cpp:2936-2984 has a single iteration).  So each lane needs the errors of the rounds of ITS legal pairs only,
+            // and the replay below evaluates a different round in every lane.  With three modes (8, 11 bits) a lane that is
+            // better but illegal keeps the mode loop of its group going, so every lane needs the errors of every round in the
+            // wave's set: there the replay stays wave-uniform.
+            const bool perLaneReplay = !GW && numModesHere == 1;
 
             for (int pStep = 0; pStep < ((GW && partitioned) ? 4 : numPartitions); pStep++)
             {
@@ -957,28 +978,13 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
                             }
                         }
                     }
-                    u32 replayRounds = 0; // wave-uniform: bit subset * 12 + round
-                    if (__ballot(need0 != 0) != 0)
-                    {
-#pragma unroll
-                        for (int m = 0; m < 12; m++)
-                        {
-                            if (__ballot((need0 >> m) & 1u) != 0) replayRounds |= 1u << m;
-                            if (__ballot((need1 >> m) & 1u) != 0) replayRounds |= 1u << (12 + m);
-                        }
-                        eagerNow = true;
-                        PROF_COUNT(10, 1)
-                    }
-                    if (replayRounds == 0)
-                        continue; // nobody can commit anything with this partition at this precision
                     // ---- replay: the rounds of the set again, from their quantised end points, this time with errors ----
-                    for (u32 todo = replayRounds; todo != 0; todo &= todo - 1u)
-                    {
-                        const int bit = __builtin_ctz(todo);
-                        const int rs = bit >= 12 ? 1 : 0, rm = bit - 12 * rs;
+                    // `rm`: the round of subset `rs` (wave-uniform) this lane evaluates -- the same in every lane (three-mode
+                    // precisions) or each lane's own (single-mode precisions); `act`: the lane has one
+                    auto replayRound = [&](int rs, int rm, bool act) {
                         const u32 rmask = GW ? (rs ? partitionMask : (~partitionMask & 0xffffu)) : opaqueUniform(rs ? partitionMask : (~partitionMask & 0xffffu));
                         // the end points as the round had them before it swapped them (the scan's first-minimum rule sees the order)
-                        const bool was = ((invBits >> bit) & 1u) != 0;
+                        const bool was = ((invBits >> (rs * 12 + rm)) & 1u) != 0;
                         int rq[2][3];
                         loadEPQ(rs, rm, rs ? xbits1 : xbits0, rq);
                         const int (&s0)[3] = rq[0];
@@ -1091,7 +1097,48 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
                             }
                             subsetError = subsetError + err;
                         }
-                        errAt(rm, rs) = subsetError;
+                        if (act)
+                            errAt(rm, rs) = subsetError;
+                    };
+                    if (__ballot(need0 != 0) == 0)
+                        continue; // nobody can commit anything with this partition at this precision
+                    PROF_COUNT(10, 1)
+                    if (perLaneReplay)
+                    {
+                        // every lane its own rounds: as many passes as the wave's busiest lane has rounds to evaluate
+                        int passes = 0;
+#pragma unroll 1
+                        for (int rs = 0; rs < 2; rs++)
+                        {
+                            u32 todo = rs ? need1 : need0;
+                            while (__ballot(todo != 0) != 0)
+                            {
+                                const bool act = todo != 0;
+                                const int rm = act ? __builtin_ctz(todo) : 0;
+                                todo &= todo - 1u;
+                                replayRound(rs, rm, act);
+                                passes++;
+                            }
+                        }
+                        if (passes > CVTT_BC6H_LAZY_SWITCH)
+                            eagerNow = true;
+                    }
+                    else
+                    {
+                        u32 replayRounds = 0; // wave-uniform: bit subset * 12 + round
+#pragma unroll
+                        for (int m = 0; m < 12; m++)
+                        {
+                            if (__ballot((need0 >> m) & 1u) != 0) replayRounds |= 1u << m;
+                            if (__ballot((need1 >> m) & 1u) != 0) replayRounds |= 1u << (12 + m);
+                        }
+                        eagerNow = true;
+                        for (u32 todo = replayRounds; todo != 0; todo &= todo - 1u)
+                        {
+                            const int bit = __builtin_ctz(todo);
+                            const int rs = bit >= 12 ? 1 : 0;
+                            replayRound(rs, bit - 12 * rs, true);
+                        }
                     }
                 }
 

@@ -31,6 +31,10 @@ struct CvttDeviceTables
     int16_t thDistance[8];
     uint8_t eacPositive[16][4];
     uint8_t eacRounding[16][13];
+    // the same two tables as words: the four positive modifiers of a table as bytes, its row of the rounding table as 13
+    // two-bit fields (the EAC search inside the ETC2 RGBA colour kernel: a candidate's table is a per-lane value)
+    uint32_t eacPosWord[16];
+    uint32_t eacRoundBits[16];
     uint8_t clusterCount[8];
     uint16_t clusterStart[8];
     int16_t clusterOffsets[632];

@@ -375,35 +375,56 @@ extern "C" int cvttmi_etc_prof_read(unsigned long long *out)
 #ifndef CVTT_ETC2_WAVES
 #define CVTT_ETC2_WAVES 5
 #endif
+// Waves (= blocks) per workgroup.  The waves of a workgroup never wait for each other during the search; they only share the
+// output: each files its 8 / 16 bytes in LDS and the one that finishes last stores the workgroup's blocks with ONE coalesced
+// instruction (2 x 16 B = a full 32-byte sector for EncodeETC2RGBA).  Isolated 16-byte stores, one per wave, were written to
+// HBM as 32-byte sectors: WRITE_SIZE 37 MB for the 16 MB of a 4096^2 image (profiles/r05).  Two waves keep the LDS at 14
+// allocation granules per workgroup = 18 waves per CU as before; four would be 16.
+#ifndef CVTT_ETC2_WG_WAVES
+#define CVTT_ETC2_WG_WAVES 1
+#endif
 struct EtcGroupPixels { u32 w[8][16]; };
 struct EtcNoGroupPixels { u32 unused; };
 template <int MODE, bool FAKE>
 // (the punch-through instantiation keeps its group pixels apart -- 9.4 KB, 16 workgroups per CU -- so a tighter register budget
 // would only make it spill)
-__global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_etc2_color_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(64 * CVTT_ETC2_WG_WAVES, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_etc2_color_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
                                                               const CvttEtcArgs A, const CvttDeviceTables *__restrict__ T)
 {
     // One wave = one workgroup = one block.  What a block needs from the other seven of its reference group (the maxima of
     // the unique-colour counts and of the line-pixel counts, the two punch-through predicates) it computes itself: lane l
     // works for group member l & 7 from the 512 bytes of the group's pixels.  No workgroup barrier, no waiting for the
     // slowest block of the group, and 9 KB of LDS per wave instead of 72 KB per eight.
-    __shared__ EtcWaveShared shared1;
+    constexpr int WGW = CVTT_ETC2_WG_WAVES;
+    __shared__ EtcWaveShared sharedAll[WGW];
+    __shared__ u32 outStage[WGW][4];
+    __shared__ u32 outCount;
+    const int waveInWg = (int)(threadIdx.x >> 6);
+    EtcWaveShared &shared1 = sharedAll[waveInWg];
     // The group's pixels (512 B).  EncodeETC2 / EncodeETC1 need them for the sector split and the T modes only, which are over
     // before the H mode and the cluster fit use the union `u`: there they live in it (8 940 B of LDS = 7 allocation granules =
     // 18 workgroups per CU instead of 16).  The punch-through modes look at the group again after the cluster fit.
-    __shared__ typename std::conditional<MODE == 2, EtcGroupPixels, EtcNoGroupPixels>::type groupSeparate;
-    u32 (*const gpix)[16] = (MODE == 2) ? reinterpret_cast<u32 (*)[16]>(&groupSeparate) : reinterpret_cast<u32 (*)[16]>(&shared1.u);
+    __shared__ typename std::conditional<MODE == 2, EtcGroupPixels, EtcNoGroupPixels>::type groupSeparateAll[WGW];
+    u32 (*const gpix)[16] = (MODE == 2) ? reinterpret_cast<u32 (*)[16]>(&groupSeparateAll[waveInWg]) : reinterpret_cast<u32 (*)[16]>(&shared1.u);
 
-    const int lane = threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63u);
     // The eight waves of a reference group read the same 512 bytes.  Workgroup b runs on XCD b % 8 (observed, for speed only;
     // nothing depends on it), each XCD with an L2 of its own: with block = workgroup number the group's pixels were fetched from
     // HBM eight times (851 MB per 4096^2 image against 75 MB of algorithmic bytes).  So XCD x takes the x-th eighth of the
     // groups, and the waves of a group are the workgroups b, b + 8, ... b + 56 of one XCD, dispatched within a few microseconds
     // of each other.
     const u32 xcdChunk = ((A.numBlocks / 8u + 7u) / 8u) * 8u; // blocks per XCD: whole groups
-    const u32 blockIndex = (blockIdx.x & 7u) * xcdChunk + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= xcdChunk || blockIndex >= A.numBlocks)
+    const u32 wgFirst = (blockIdx.x >> 3) * (u32)WGW;           // first block of this workgroup inside its XCD's chunk
+    const u32 blockIndex = (blockIdx.x & 7u) * xcdChunk + wgFirst + (u32)waveInWg;
+    // (numBlocks and the chunk are multiples of 8 and WGW divides 8: the blocks of a workgroup exist together or not at all)
+    if (wgFirst >= xcdChunk || (blockIdx.x & 7u) * xcdChunk + wgFirst >= A.numBlocks)
         return;
+    if (WGW > 1)
+    {
+        if (threadIdx.x == 0)
+            outCount = 0;
+        __syncthreads(); // the only workgroup barrier: both waves have just started
+    }
     const int own = (int)(blockIndex & 7u), jb = lane & 7;
     EtcWaveShared &S = shared1;
     const EtcErr E = {(A.flags & CVTTMI_FLAG_UNIFORM) != 0, A.rw, A.gw, A.bw, FAKE};
@@ -433,9 +454,11 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
     // ---- load: pixel px by lane px.  Punch-through: pixels whose alpha is below the threshold are transparent and
     // count as black from here on (ETC.cpp:1670-1720) ----
     bool pxTransparent = false;
+    u32 alphaLane = 0; // EncodeETC2RGBA: the alpha of pixel `lane`
     if (lane < 16)
     {
         const u32 pk = reinterpret_cast<const u32 *>(blocks + (size_t)blockIndex * 64u)[lane];
+        alphaLane = pk >> 24;
         int r = (int)(pk & 0xffu), g = (int)((pk >> 8) & 0xffu), b = (int)((pk >> 16) & 0xffu);
         pxTransparent = PUNCH && (pk >> 24) < A.alphaThreshold;
         if (pxTransparent)
@@ -451,6 +474,113 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
         S.pw[lane][2] = pxTransparent ? 0.0f : pw3[2];
     }
     const u32 transMask = PUNCH ? ((u32)__ballot(pxTransparent) & 0xffffu) : 0u;
+
+    // ---- EncodeETC2RGBA (outStride 16): the EAC alpha half of the block, here, from the pixels this wave has just loaded ----
+    // CompressETC2AlphaBlockInternal, ETC.cpp:1902-2085 -- the search of cvttmi_eac_alpha_kernel<0> below with the 320
+    // (table, range, multiplier) candidates dealt to the lanes: candidate c = table * 20 + r * 2 + mo is the reference's loop
+    // order, lane l takes c = l, l + 64, ... in ascending order with the reference's strict '<', and the wave-wide minimum of
+    // (error << 9 | c) is the first minimum of that order.  The sixteen alpha values are wave-uniform (scalar registers), so a
+    // candidate costs what it costs in the one-lane-per-block kernel, the same instruction count per block without a second
+    // pass over the PixelBlocks -- and the block goes out as ONE 16-byte store (round 4: two kernels, both reading the 64 MB of
+    // a 4096^2 image, 8-byte stores into 16-byte slots: 2.36 x the algorithmic HBM traffic).
+    u32 alphaW0 = 0, alphaW1 = 0; // wave-uniform
+    if (MODE == 0 && A.outStride == 16u)
+    {
+        int al[16];
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+            al[px] = __builtin_amdgcn_readlane((int)alphaLane, px);
+        int minAlpha = 255, maxAlpha = 0;
+#pragma unroll
+        for (int px = 0; px < 16; px++)
+        {
+            minAlpha = al[px] < minAlpha ? al[px] : minAlpha;
+            maxAlpha = al[px] > maxAlpha ? al[px] : maxAlpha;
+        }
+        const int alphaSpan = maxAlpha - minAlpha, midTimes2 = maxAlpha + minAlpha;
+        u32 bestKey = 0xffffffffu;
+        int bestBase = 0, bestMultiplier = 0;
+#pragma unroll 1
+        for (int c = lane; c < 320; c += 64)
+        {
+            const int tableIndex = (int)(((u32)c * 3277u) >> 16); // c / 20 for c < 320
+            const int rem = c - tableIndex * 20;
+            const int r = rem >> 1, mo = rem & 1;
+            const u32 posWord = T->eacPosWord[tableIndex], roundBits = T->eacRoundBits[tableIndex];
+            const int mainRange = (int)(((u32)r * 11u) >> 5); // r / 3 for r < 10
+            const int subrange = r - mainRange * 3;
+            const int maxOffset = (int)((posWord >> (8 * (3 - mainRange - (subrange & 1)))) & 0xffu);
+            const int minOffset = -(int)((posWord >> (8 * (3 - mainRange - ((subrange >> 1) & 1)))) & 0xffu) - 1;
+            int minMultiplier = udivSmall(alphaSpan, maxOffset - minOffset);
+            minMultiplier = minMultiplier > 14 ? 14 : minMultiplier;
+            minMultiplier = minMultiplier < 1 ? 1 : minMultiplier;
+            const int multiplier = minMultiplier + mo;
+            int base2 = midTimes2 - multiplier * maxOffset - multiplier * minOffset;
+            base2 = base2 < 0 ? 0 : (base2 > 510 ? 510 : base2);
+            const int baseAlpha = (base2 + 1) >> 1;
+            const u32 magic = (u32)udivSmall20(multiplier);
+            u32 totalError = 0;
+#pragma unroll
+            for (int px = 0; px < 16; px++)
+            {
+                const int a = al[px];
+                const int refl2 = (a - baseAlpha) * 2 + multiplier;
+                const int absv = refl2 < 0 ? -refl2 : refl2;
+                int li = (int)(__umul24((u32)(absv >> 1), magic) >> 20);
+                li = li >= 13 ? 12 : li;
+                const int index = (int)((roundBits >> (2 * li)) & 3u);
+                const int pOff = (int)((posWord >> (8 * index)) & 0xffu);
+                const int sign = refl2 < 0 ? -1 : 0;
+                int q = baseAlpha + (pOff ^ sign) * multiplier;
+                q = q < 0 ? 0 : (q > 255 ? 255 : q);
+                const int dq = q - a;
+                totalError += (u32)(dq * dq);
+            }
+            const u32 key = (totalError << 9) | (u32)c; // 16 x 255^2 < 2^20
+            if (key < bestKey)
+            {
+                bestKey = key;
+                bestBase = baseAlpha;
+                bestMultiplier = multiplier;
+            }
+        }
+        u32 key = bestKey;
+#pragma unroll
+        for (int step = 1; step < 64; step <<= 1)
+        {
+            const u32 o = (u32)__shfl_xor((int)key, step);
+            key = o < key ? o : key;
+        }
+        const int bestC = (int)(key & 511u);
+        const int bestTable = (int)(((u32)bestC * 3277u) >> 16);
+        bestBase = __shfl(bestBase, bestC & 63);
+        bestMultiplier = __shfl(bestMultiplier, bestC & 63);
+        // the winner's indexes: lane px < 16 its pixel's code, at the place the column-major emission order gives it
+        // (16 x 3 bits, MSB first, ETC.cpp:2049-2084: the s-th code emitted is the pixel ((s & 3) << 2) | (s >> 2))
+        u32 bitsLo = 0, bitsHi = 0; // bits 0..31 / 32..47 of the 48-bit field
+        {
+            const u32 magic = (u32)udivSmall20(bestMultiplier);
+            const int refl2 = ((int)alphaLane - bestBase) * 2 + bestMultiplier;
+            const int absv = refl2 < 0 ? -refl2 : refl2;
+            int li = (int)(__umul24((u32)(absv >> 1), magic) >> 20);
+            li = li >= 13 ? 12 : li;
+            const int index = (int)((T->eacRoundBits[bestTable] >> (2 * li)) & 3u);
+            const u64 code = (u64)(u32)(index + 4 - ((refl2 < 0 ? -1 : 0) & 4));
+            const int s = ((lane & 3) << 2) | ((lane >> 2) & 3);
+            const u64 placed = lane < 16 ? code << (3 * (15 - s)) : 0ull;
+            bitsLo = (u32)placed;
+            bitsHi = (u32)(placed >> 32);
+#pragma unroll
+            for (int step = 1; step < 16; step <<= 1)
+            {
+                bitsLo |= (u32)__shfl_xor((int)bitsLo, step);
+                bitsHi |= (u32)__shfl_xor((int)bitsHi, step);
+            }
+        }
+        const u32 w0 = ((u32)bestBase & 0xffu) | ((u32)(((bestMultiplier << 4) | bestTable) & 0xff) << 8) | (((bitsHi >> 8) & 0xffu) << 16) | ((bitsHi & 0xffu) << 24);
+        alphaW0 = (u32)__builtin_amdgcn_readfirstlane((int)w0);
+        alphaW1 = (u32)__builtin_amdgcn_readfirstlane((int)bswap32(bitsLo));
+    }
     // the group's pixels: 128 words, two per lane
     {
         const u32 *gsrc = reinterpret_cast<const u32 *>(blocks + (size_t)(blockIndex & ~7u) * 64u);
@@ -936,7 +1066,7 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
                     auto tPixels = [&](auto uniTag) {
                         constexpr bool UNI = decltype(uniTag)::value;
                         const EtcErr EE = {UNI, E.rw, E.gw, E.bw, E.fake};
-                        EtcWaveShared &S = shared1; // (static storage: named again here, a generic lambda does not capture the outer reference)
+                        EtcWaveShared &S = sharedAll[waveInWg]; // (static storage: named again here, a generic lambda does not capture the outer reference)
 #pragma unroll 4
                         for (int px = 0; px < 16; px++)
                         {
@@ -1205,7 +1335,7 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
                     auto hPixels = [&](auto uniTag) {
                         constexpr bool UNI = decltype(uniTag)::value;
                         const EtcErr EE = {UNI, E.rw, E.gw, E.bw, E.fake};
-                        EtcWaveShared &S = shared1;
+                        EtcWaveShared &S = sharedAll[waveInWg];
 #pragma unroll 4
                         for (int px = 0; px < 16; px++)
                         {
@@ -2270,12 +2400,60 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
     }
 
     DBG_TAP(4);
+    const bool whole = MODE == 0 && A.outStride == 16u; // [EAC alpha | colour]: the kernel owns the whole 16-byte block
+    if (WGW == 1)
+    {
+        if (lane == 0)
+        {
+            if (whole)
+            {
+                uint4 o;
+                o.x = alphaW0;
+                o.y = alphaW1;
+                o.z = bswap32(outHi);
+                o.w = bswap32(outLo);
+                *reinterpret_cast<uint4 *>(out + (size_t)blockIndex * 16u) = o;
+            }
+            else
+            {
+                uint2 o;
+                o.x = bswap32(outHi);
+                o.y = bswap32(outLo);
+                *reinterpret_cast<uint2 *>(out + (size_t)blockIndex * A.outStride + A.outOffset) = o;
+            }
+        }
+        return;
+    }
+    // the workgroup's blocks are consecutive: the wave that finishes last stores them all with one instruction
+    u32 arrived = 0;
     if (lane == 0)
     {
-        uint2 o;
-        o.x = bswap32(outHi);
-        o.y = bswap32(outLo);
-        *reinterpret_cast<uint2 *>(out + (size_t)blockIndex * A.outStride + A.outOffset) = o;
+        outStage[waveInWg][0] = whole ? alphaW0 : bswap32(outHi);
+        outStage[waveInWg][1] = whole ? alphaW1 : bswap32(outLo);
+        outStage[waveInWg][2] = bswap32(outHi);
+        outStage[waveInWg][3] = bswap32(outLo);
+        arrived = __hip_atomic_fetch_add(&outCount, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    arrived = (u32)__builtin_amdgcn_readfirstlane((int)arrived);
+    if (arrived == (u32)(WGW - 1) && lane < WGW)
+    {
+        const u32 firstBlock = blockIndex - (u32)waveInWg;
+        if (whole)
+        {
+            uint4 o;
+            o.x = outStage[lane][0];
+            o.y = outStage[lane][1];
+            o.z = outStage[lane][2];
+            o.w = outStage[lane][3];
+            *reinterpret_cast<uint4 *>(out + (size_t)(firstBlock + (u32)lane) * 16u) = o;
+        }
+        else
+        {
+            uint2 o;
+            o.x = outStage[lane][0];
+            o.y = outStage[lane][1];
+            *reinterpret_cast<uint2 *>(out + (size_t)(firstBlock + (u32)lane) * A.outStride + A.outOffset) = o;
+        }
     }
 }
 
@@ -2516,15 +2694,15 @@ extern "C" hipError_t cvttmi_launch_etc2(const void *d_blocks, void *d_out, cons
     CvttEtcArgs a = *args;
     a.outStride = (mode == 1) ? 16u : 8u;
     const bool fake = (a.flags & CVTTMI_FLAG_ETC_USE_FAKE_BT709) != 0;
-    const uint32_t colourGrid = ((a.numBlocks / 8u + 7u) / 8u) * 64u; // eight XCDs x whole groups (see the kernel's block map)
+    const uint32_t colourGrid = ((a.numBlocks / 8u + 7u) / 8u) * (64u / CVTT_ETC2_WG_WAVES); // eight XCDs x whole groups (see the kernel's block map)
 #define CVTT_LAUNCH_COLOR(M)                                                                                                      \
     do                                                                                                                            \
     {                                                                                                                             \
         if (fake)                                                                                                                 \
-            hipLaunchKernelGGL((cvttmi_etc2_color_kernel<M, true>), dim3(colourGrid), dim3(64), 0, stream,                 \
+            hipLaunchKernelGGL((cvttmi_etc2_color_kernel<M, true>), dim3(colourGrid), dim3(64 * CVTT_ETC2_WG_WAVES), 0, stream, \
                                (const uint8_t *)d_blocks, (uint8_t *)d_out, a, d_tables);                                         \
         else                                                                                                                      \
-            hipLaunchKernelGGL((cvttmi_etc2_color_kernel<M, false>), dim3(colourGrid), dim3(64), 0, stream,                \
+            hipLaunchKernelGGL((cvttmi_etc2_color_kernel<M, false>), dim3(colourGrid), dim3(64 * CVTT_ETC2_WG_WAVES), 0, stream, \
                                (const uint8_t *)d_blocks, (uint8_t *)d_out, a, d_tables);                                         \
     } while (0)
     if (mode == 3 || mode == 4)
@@ -2542,7 +2720,7 @@ extern "C" hipError_t cvttmi_launch_etc2(const void *d_blocks, void *d_out, cons
         CVTT_LAUNCH_COLOR(0);
     }
 #undef CVTT_LAUNCH_COLOR
-    if (mode != 0)
+    if (mode == 2) // EncodeETC2Alpha alone (RGBA: the colour kernel searches the alpha half itself and stores the whole block)
     {
         a.outOffset = 0u;
         if (a.numBlocks <= kEacSpreadMax)
