@@ -94,6 +94,12 @@ __device__ __forceinline__ int udivSmall20(int d)
 
 __device__ __forceinline__ u32 bswap32(u32 v) { return __builtin_bswap32(v); }
 
+// A value that is the same in every lane (a wave-wide winner, a best-so-far) moved to a scalar register: the compiler cannot
+// see the uniformity through shuffles and LDS reads and would keep one copy per lane alive across the search phases.
+__device__ __forceinline__ u32 uniU(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int uniI(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uniF(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
 // wave-wide argmin of (err, id); ties -> lowest id.  All lanes receive the winner.
 __device__ __forceinline__ void waveArgmin(float &err, int &id)
 {
@@ -375,56 +381,35 @@ extern "C" int cvttmi_etc_prof_read(unsigned long long *out)
 #ifndef CVTT_ETC2_WAVES
 #define CVTT_ETC2_WAVES 5
 #endif
-// Waves (= blocks) per workgroup.  The waves of a workgroup never wait for each other during the search; they only share the
-// output: each files its 8 / 16 bytes in LDS and the one that finishes last stores the workgroup's blocks with ONE coalesced
-// instruction (2 x 16 B = a full 32-byte sector for EncodeETC2RGBA).  Isolated 16-byte stores, one per wave, were written to
-// HBM as 32-byte sectors: WRITE_SIZE 37 MB for the 16 MB of a 4096^2 image (profiles/r05).  Two waves keep the LDS at 14
-// allocation granules per workgroup = 18 waves per CU as before; four would be 16.
-#ifndef CVTT_ETC2_WG_WAVES
-#define CVTT_ETC2_WG_WAVES 1
-#endif
 struct EtcGroupPixels { u32 w[8][16]; };
 struct EtcNoGroupPixels { u32 unused; };
 template <int MODE, bool FAKE>
 // (the punch-through instantiation keeps its group pixels apart -- 9.4 KB, 16 workgroups per CU -- so a tighter register budget
 // would only make it spill)
-__global__ __launch_bounds__(64 * CVTT_ETC2_WG_WAVES, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_etc2_color_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_etc2_color_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
                                                               const CvttEtcArgs A, const CvttDeviceTables *__restrict__ T)
 {
     // One wave = one workgroup = one block.  What a block needs from the other seven of its reference group (the maxima of
     // the unique-colour counts and of the line-pixel counts, the two punch-through predicates) it computes itself: lane l
     // works for group member l & 7 from the 512 bytes of the group's pixels.  No workgroup barrier, no waiting for the
     // slowest block of the group, and 9 KB of LDS per wave instead of 72 KB per eight.
-    constexpr int WGW = CVTT_ETC2_WG_WAVES;
-    __shared__ EtcWaveShared sharedAll[WGW];
-    __shared__ u32 outStage[WGW][4];
-    __shared__ u32 outCount;
-    const int waveInWg = (int)(threadIdx.x >> 6);
-    EtcWaveShared &shared1 = sharedAll[waveInWg];
+    __shared__ EtcWaveShared shared1;
     // The group's pixels (512 B).  EncodeETC2 / EncodeETC1 need them for the sector split and the T modes only, which are over
     // before the H mode and the cluster fit use the union `u`: there they live in it (8 940 B of LDS = 7 allocation granules =
     // 18 workgroups per CU instead of 16).  The punch-through modes look at the group again after the cluster fit.
-    __shared__ typename std::conditional<MODE == 2, EtcGroupPixels, EtcNoGroupPixels>::type groupSeparateAll[WGW];
-    u32 (*const gpix)[16] = (MODE == 2) ? reinterpret_cast<u32 (*)[16]>(&groupSeparateAll[waveInWg]) : reinterpret_cast<u32 (*)[16]>(&shared1.u);
+    __shared__ typename std::conditional<MODE == 2, EtcGroupPixels, EtcNoGroupPixels>::type groupSeparate;
+    u32 (*const gpix)[16] = (MODE == 2) ? reinterpret_cast<u32 (*)[16]>(&groupSeparate) : reinterpret_cast<u32 (*)[16]>(&shared1.u);
 
-    const int lane = (int)(threadIdx.x & 63u);
+    const int lane = threadIdx.x;
     // The eight waves of a reference group read the same 512 bytes.  Workgroup b runs on XCD b % 8 (observed, for speed only;
     // nothing depends on it), each XCD with an L2 of its own: with block = workgroup number the group's pixels were fetched from
     // HBM eight times (851 MB per 4096^2 image against 75 MB of algorithmic bytes).  So XCD x takes the x-th eighth of the
     // groups, and the waves of a group are the workgroups b, b + 8, ... b + 56 of one XCD, dispatched within a few microseconds
     // of each other.
     const u32 xcdChunk = ((A.numBlocks / 8u + 7u) / 8u) * 8u; // blocks per XCD: whole groups
-    const u32 wgFirst = (blockIdx.x >> 3) * (u32)WGW;           // first block of this workgroup inside its XCD's chunk
-    const u32 blockIndex = (blockIdx.x & 7u) * xcdChunk + wgFirst + (u32)waveInWg;
-    // (numBlocks and the chunk are multiples of 8 and WGW divides 8: the blocks of a workgroup exist together or not at all)
-    if (wgFirst >= xcdChunk || (blockIdx.x & 7u) * xcdChunk + wgFirst >= A.numBlocks)
+    const u32 blockIndex = (blockIdx.x & 7u) * xcdChunk + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= xcdChunk || blockIndex >= A.numBlocks)
         return;
-    if (WGW > 1)
-    {
-        if (threadIdx.x == 0)
-            outCount = 0;
-        __syncthreads(); // the only workgroup barrier: both waves have just started
-    }
     const int own = (int)(blockIndex & 7u), jb = lane & 7;
     EtcWaveShared &S = shared1;
     const EtcErr E = {(A.flags & CVTTMI_FLAG_UNIFORM) != 0, A.rw, A.gw, A.bw, FAKE};
@@ -853,6 +838,7 @@ __global__ __launch_bounds__(64 * CVTT_ETC2_WG_WAVES, MODE == 2 ? 4 : CVTT_ETC2_
     }
 
     DBG_TAP(0);
+    bestError = uniF(bestError); outHi = uniU(outHi); outLo = uniU(outLo);
     // ============ sector split along the chroma principal axis (ETC.cpp:1723-1848) ============
     // every lane does it for group member jb; the block's own split is lane `own`'s
     {
@@ -1015,7 +1001,7 @@ __global__ __launch_bounds__(64 * CVTT_ETC2_WG_WAVES, MODE == 2 ? 4 : CVTT_ETC2_
         prefix[0] = 0;
 #pragma unroll
         for (int t = 0; t < 8; t++)
-            prefix[t + 1] = prefix[t] + S.tCount[t];
+            prefix[t + 1] = __builtin_amdgcn_readfirstlane(prefix[t] + S.tCount[t]); // wave-uniform: scalar registers
         // attempt 0: zero slots tracked apart (tentative); attempt 1 (rare): the slots of the tables in presentMask are
         // candidates like the others, the rest is skipped.  One copy of the evaluation loop serves both.
         float wErr = FLT_MAX;
@@ -1066,7 +1052,7 @@ __global__ __launch_bounds__(64 * CVTT_ETC2_WG_WAVES, MODE == 2 ? 4 : CVTT_ETC2_
                     auto tPixels = [&](auto uniTag) {
                         constexpr bool UNI = decltype(uniTag)::value;
                         const EtcErr EE = {UNI, E.rw, E.gw, E.bw, E.fake};
-                        EtcWaveShared &S = sharedAll[waveInWg]; // (static storage: named again here, a generic lambda does not capture the outer reference)
+                        EtcWaveShared &S = shared1; // (static storage: named again here, a generic lambda does not capture the outer reference)
 #pragma unroll 4
                         for (int px = 0; px < 16; px++)
                         {
@@ -1223,6 +1209,7 @@ __global__ __launch_bounds__(64 * CVTT_ETC2_WG_WAVES, MODE == 2 ? 4 : CVTT_ETC2_
             emitT(outHi, outLo, lineColor, isoQ, selectors, table);
         }
         DBG_TAP(1 + call);
+        bestError = uniF(bestError); outHi = uniU(outHi); outLo = uniU(outLo);
         WAVE_SYNC();
     }
 
@@ -1306,7 +1293,8 @@ __global__ __launch_bounds__(64 * CVTT_ETC2_WG_WAVES, MODE == 2 ? 4 : CVTT_ETC2_
         for (int tp = 0; tp < 4; tp++)
         {
             const int tabA = 2 * tp, tabB = tabA + 1;
-            const int nA0 = S.dCount[tabA * 2], nA1 = S.dCount[tabA * 2 + 1], nB0 = S.dCount[tabB * 2], nB1 = S.dCount[tabB * 2 + 1];
+            const int nA0 = __builtin_amdgcn_readfirstlane(S.dCount[tabA * 2]), nA1 = __builtin_amdgcn_readfirstlane(S.dCount[tabA * 2 + 1]),
+                      nB0 = __builtin_amdgcn_readfirstlane(S.dCount[tabB * 2]), nB1 = __builtin_amdgcn_readfirstlane(S.dCount[tabB * 2 + 1]); // wave-uniform
             const int rowsA = nA0 + nA1, rowsB = nB0 + nB1; // table B's rows follow table A's
             // per-colour error rows: lane = colour (ETC.cpp:752-787)
             for (int base = 0; base < rowsA + rowsB; base += 64)
@@ -1335,7 +1323,7 @@ __global__ __launch_bounds__(64 * CVTT_ETC2_WG_WAVES, MODE == 2 ? 4 : CVTT_ETC2_
                     auto hPixels = [&](auto uniTag) {
                         constexpr bool UNI = decltype(uniTag)::value;
                         const EtcErr EE = {UNI, E.rw, E.gw, E.bw, E.fake};
-                        EtcWaveShared &S = sharedAll[waveInWg];
+                        EtcWaveShared &S = shared1;
 #pragma unroll 4
                         for (int px = 0; px < 16; px++)
                         {
@@ -1456,6 +1444,7 @@ __global__ __launch_bounds__(64 * CVTT_ETC2_WG_WAVES, MODE == 2 ? 4 : CVTT_ETC2_
     }
 
     DBG_TAP(3);
+    bestError = uniF(bestError); outHi = uniU(outHi); outLo = uniU(outLo);
     } // !ETC1
     // ====================== ETC1 cluster fit ======================
     // ETC2 reaches it through CompressETC2Block, which asks for the differential mode only (d = 1, ETC.cpp:1862);
@@ -1642,7 +1631,7 @@ __global__ __launch_bounds__(64 * CVTT_ETC2_WG_WAVES, MODE == 2 ? 4 : CVTT_ETC2_
             prefix[0] = 0;
 #pragma unroll
             for (int i = 0; i < 16; i++)
-                prefix[i + 1] = prefix[i] + S.dCount[i];
+                prefix[i + 1] = __builtin_amdgcn_readfirstlane(prefix[i] + S.dCount[i]); // wave-uniform: scalar registers, not seventeen per lane
             const int numA0 = prefix[8], numA1 = prefix[16] - prefix[8];
 
             // ---- TestHalfBlock per candidate: lane = candidate (ETC.cpp:94-149, 2793-2828) ----
@@ -2052,6 +2041,12 @@ __global__ __launch_bounds__(64 * CVTT_ETC2_WG_WAVES, MODE == 2 ? 4 : CVTT_ETC2_
                 }
             }
             WAVE_SYNC();
+            // the block's best after this (flip, mode): wave-uniform
+            bestError = uniF(bestError);
+            etcBest = uniI(etcBest ? 1 : 0) != 0;
+            bFlip = uniI(bFlip); bD = uniI(bD);
+            bPacked0 = uniU(bPacked0); bPacked1 = uniU(bPacked1);
+            bTable0 = uniI(bTable0); bTable1 = uniI(bTable1);
         }
 
         if (etcBest)
@@ -2400,59 +2395,27 @@ __global__ __launch_bounds__(64 * CVTT_ETC2_WG_WAVES, MODE == 2 ? 4 : CVTT_ETC2_
     }
 
     DBG_TAP(4);
-    const bool whole = MODE == 0 && A.outStride == 16u; // [EAC alpha | colour]: the kernel owns the whole 16-byte block
-    if (WGW == 1)
-    {
-        if (lane == 0)
-        {
-            if (whole)
-            {
-                uint4 o;
-                o.x = alphaW0;
-                o.y = alphaW1;
-                o.z = bswap32(outHi);
-                o.w = bswap32(outLo);
-                *reinterpret_cast<uint4 *>(out + (size_t)blockIndex * 16u) = o;
-            }
-            else
-            {
-                uint2 o;
-                o.x = bswap32(outHi);
-                o.y = bswap32(outLo);
-                *reinterpret_cast<uint2 *>(out + (size_t)blockIndex * A.outStride + A.outOffset) = o;
-            }
-        }
-        return;
-    }
-    // the workgroup's blocks are consecutive: the wave that finishes last stores them all with one instruction
-    u32 arrived = 0;
     if (lane == 0)
     {
-        outStage[waveInWg][0] = whole ? alphaW0 : bswap32(outHi);
-        outStage[waveInWg][1] = whole ? alphaW1 : bswap32(outLo);
-        outStage[waveInWg][2] = bswap32(outHi);
-        outStage[waveInWg][3] = bswap32(outLo);
-        arrived = __hip_atomic_fetch_add(&outCount, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    arrived = (u32)__builtin_amdgcn_readfirstlane((int)arrived);
-    if (arrived == (u32)(WGW - 1) && lane < WGW)
-    {
-        const u32 firstBlock = blockIndex - (u32)waveInWg;
-        if (whole)
+        if (MODE == 0 && A.outStride == 16u)
         {
+            // [EAC alpha | colour]: one 16-byte store per block.  (Built and measured in round 5: two waves per workgroup that
+            // file their results in LDS, the last finisher storing both blocks as one 32-byte sector -- 27.1 instead of 25.8 ms
+            // at 4096^2: the per-wave LDS base costs registers the kernel does not have at five waves per SIMD.  What WRITE_SIZE
+            // shows above the 16 MB of payload is the kernel's scratch, not the store width.)
             uint4 o;
-            o.x = outStage[lane][0];
-            o.y = outStage[lane][1];
-            o.z = outStage[lane][2];
-            o.w = outStage[lane][3];
-            *reinterpret_cast<uint4 *>(out + (size_t)(firstBlock + (u32)lane) * 16u) = o;
+            o.x = alphaW0;
+            o.y = alphaW1;
+            o.z = bswap32(outHi);
+            o.w = bswap32(outLo);
+            *reinterpret_cast<uint4 *>(out + (size_t)blockIndex * 16u) = o;
         }
         else
         {
             uint2 o;
-            o.x = outStage[lane][0];
-            o.y = outStage[lane][1];
-            *reinterpret_cast<uint2 *>(out + (size_t)(firstBlock + (u32)lane) * A.outStride + A.outOffset) = o;
+            o.x = bswap32(outHi);
+            o.y = bswap32(outLo);
+            *reinterpret_cast<uint2 *>(out + (size_t)blockIndex * A.outStride + A.outOffset) = o;
         }
     }
 }
@@ -2694,15 +2657,15 @@ extern "C" hipError_t cvttmi_launch_etc2(const void *d_blocks, void *d_out, cons
     CvttEtcArgs a = *args;
     a.outStride = (mode == 1) ? 16u : 8u;
     const bool fake = (a.flags & CVTTMI_FLAG_ETC_USE_FAKE_BT709) != 0;
-    const uint32_t colourGrid = ((a.numBlocks / 8u + 7u) / 8u) * (64u / CVTT_ETC2_WG_WAVES); // eight XCDs x whole groups (see the kernel's block map)
+    const uint32_t colourGrid = ((a.numBlocks / 8u + 7u) / 8u) * 64u; // eight XCDs x whole groups (see the kernel's block map)
 #define CVTT_LAUNCH_COLOR(M)                                                                                                      \
     do                                                                                                                            \
     {                                                                                                                             \
         if (fake)                                                                                                                 \
-            hipLaunchKernelGGL((cvttmi_etc2_color_kernel<M, true>), dim3(colourGrid), dim3(64 * CVTT_ETC2_WG_WAVES), 0, stream, \
+            hipLaunchKernelGGL((cvttmi_etc2_color_kernel<M, true>), dim3(colourGrid), dim3(64), 0, stream,                 \
                                (const uint8_t *)d_blocks, (uint8_t *)d_out, a, d_tables);                                         \
         else                                                                                                                      \
-            hipLaunchKernelGGL((cvttmi_etc2_color_kernel<M, false>), dim3(colourGrid), dim3(64 * CVTT_ETC2_WG_WAVES), 0, stream, \
+            hipLaunchKernelGGL((cvttmi_etc2_color_kernel<M, false>), dim3(colourGrid), dim3(64), 0, stream,                 \
                                (const uint8_t *)d_blocks, (uint8_t *)d_out, a, d_tables);                                         \
     } while (0)
     if (mode == 3 || mode == 4)
