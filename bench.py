@@ -709,7 +709,8 @@ def per_config_legs(torch, api, synth, ctx, dev, h, rcp, rcp_gold, same_lut, arg
         out = encode(d_in, None)
         ms_min, ms_mean = timed_encode(torch, lambda: encode(d_in, out), reps)
         host = out.cpu().numpy()
-        c = (fmtc or {}).get(prof) if prof else None
+        # prof: the profiled format(s) whose counters describe this leg, most specific first
+        c = next((fmtc[k] for k in ([prof] if isinstance(prof, str) else (prof or [])) if fmtc and isinstance(fmtc.get(k), dict)), None)
         if c:
             roof = roofline_block(fmt, n, ms_min, "+".join(c["kernels"]), insts_per_block=c["valu_wave_insts_per_block"],
                                   hbm_bytes_per_block=c["hbm_bytes_per_block"], waves_per_simd=c["avg_waves_per_simd"], source=fmtc["source"])
@@ -739,12 +740,12 @@ def per_config_legs(torch, api, synth, ctx, dev, h, rcp, rcp_gold, same_lut, arg
     leg("2b_bc7_4096_opaque", "bc7", synth.tile_blocks(synth.image_rgba8(2, 4096, 4096, opaque=True)),
         lambda t, out: ctx.encode_bc7(t, o, p, out=out), "config2b_bc7_4096_seed2_opaque", o, p, prof="bc7o")
     leg("3_bc6hu_4096", "bc6hu", synth.tile_blocks(synth.image_f16bits(3, 4096, 4096)), lambda t, out: ctx.encode_bc6h(t, o, signed=False, out=out),
-        "config3_bc6hu_4096_seed3", o, reps=1, prof="bc6hu")
+        "config3_bc6hu_4096_seed3", o, reps=2, prof="bc6hu")
     leg("4_etc2rgba_4096", "etc2rgba", synth.tile_blocks(synth.image_rgba8(4, 4096, 4096)), lambda t, out: ctx.encode_etc2_rgba(t, o, out=out),
         "config4_etc2rgba_4096_seed4", o, prof="etc2rgba")
     big = synth.tile_blocks(synth.image_rgba8(5, 16384, 16384))
-    leg("5a_bc7_16384", "bc7", big, lambda t, out: ctx.encode_bc7(t, o, p, out=out), "config5_bc7_16384_seed5", o, p, prof="bc7")
-    leg("5b_bc7_16384_ultra", "bc7", big, lambda t, out: ctx.encode_bc7(t, ultra, p, out=out), "config5b_bc7_16384_seed5_ultra", ultra, p, reps=1, prof="bc7u")
+    leg("5a_bc7_16384", "bc7", big, lambda t, out: ctx.encode_bc7(t, o, p, out=out), "config5_bc7_16384_seed5", o, p, prof=["bc7c5", "bc7"])
+    leg("5b_bc7_16384_ultra", "bc7", big, lambda t, out: ctx.encode_bc7(t, ultra, p, out=out), "config5b_bc7_16384_seed5_ultra", ultra, p, reps=1, prof=["bc7c5u", "bc7u"])
     return legs
 
 

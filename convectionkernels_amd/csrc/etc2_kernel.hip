@@ -41,6 +41,9 @@ struct EtcWaveShared
     int tCount[8];
     union
     {
+        // the group's 512 bytes of pixels (EncodeETC2 / EncodeETC1): read by pixJ / pwJ until the T modes are done, i.e. strictly
+        // before the first store to `h` or `a` below (the hand-over point is marked in the kernel)
+        u32 group[8][16];
         struct
         {
             float err[16][72];       // H mode: min error of colour ci +/- modifier per pixel, two tables at a time; [pixel][colour]: the
@@ -99,6 +102,9 @@ __device__ __forceinline__ u32 bswap32(u32 v) { return __builtin_bswap32(v); }
 __device__ __forceinline__ u32 uniU(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ int uniI(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float uniF(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+// the value lane `lane` holds, `lane` the same in every lane: v_readlane_b32 (a scalar result) instead of a ds_bpermute_b32
+__device__ __forceinline__ int laneI(int v, int lane) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(lane)); }
+__device__ __forceinline__ float laneF(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(lane))); }
 
 // wave-wide argmin of (err, id); ties -> lowest id.  All lanes receive the winner.
 __device__ __forceinline__ void waveArgmin(float &err, int &id)
@@ -112,6 +118,11 @@ __device__ __forceinline__ void waveArgmin(float &err, int &id)
         err = take ? oe : err;
         id = take ? oi : id;
     }
+#ifndef CVTT_ETC_NO_UNI_ARGMIN // (round 5: +1.6 % EncodeETC2RGBA, +2.3 % punch-through, same bytes; profiles/r05/ab_etc2.txt)
+    // (every lane holds the winner: as scalars, what is derived from it is scalar arithmetic)
+    err = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(err)));
+    id = __builtin_amdgcn_readfirstlane(id);
+#endif
 }
 
 // ConvertToFakeBT709, ETC.cpp:2343-2352
@@ -398,7 +409,7 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
     // before the H mode and the cluster fit use the union `u`: there they live in it (8 940 B of LDS = 7 allocation granules =
     // 18 workgroups per CU instead of 16).  The punch-through modes look at the group again after the cluster fit.
     __shared__ typename std::conditional<MODE == 2, EtcGroupPixels, EtcNoGroupPixels>::type groupSeparate;
-    u32 (*const gpix)[16] = (MODE == 2) ? reinterpret_cast<u32 (*)[16]>(&groupSeparate) : reinterpret_cast<u32 (*)[16]>(&shared1.u);
+    u32 (*const gpix)[16] = (MODE == 2) ? reinterpret_cast<u32 (*)[16]>(&groupSeparate) : shared1.u.group;
 
     const int lane = threadIdx.x;
     // The eight waves of a reference group read the same 512 bytes.  Workgroup b runs on XCD b % 8 (observed, for speed only;
@@ -538,8 +549,8 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
         }
         const int bestC = (int)(key & 511u);
         const int bestTable = (int)(((u32)bestC * 3277u) >> 16);
-        bestBase = __shfl(bestBase, bestC & 63);
-        bestMultiplier = __shfl(bestMultiplier, bestC & 63);
+        bestBase = laneI(bestBase, bestC & 63);
+        bestMultiplier = laneI(bestMultiplier, bestC & 63);
         // the winner's indexes: lane px < 16 its pixel's code, at the place the column-major emission order gives it
         // (16 x 3 bits, MSB first, ETC.cpp:2049-2084: the s-th code emitted is the pixel ((s & 3) << 2) | (s >> 2))
         u32 bitsLo = 0, bitsHi = 0; // bits 0..31 / 32..47 of the 48-bit field
@@ -785,8 +796,8 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
 #pragma unroll
         for (int c3 = 0; c3 < 3; c3++)
         {
-            const float eBest = __shfl(cErr, c3 * 8);
-            const int win = __shfl(cId, c3 * 8);
+            const float eBest = laneF(cErr, c3 * 8);
+            const int win = laneI(cId, c3 * 8);
             // bestChannelError starts at FLT_MAX and is replaced on a strict '<'
             chErr[c3] = eBest < FLT_MAX ? eBest : FLT_MAX;
             coeffs[c3][0] = S.planarRange[c3][0][(win >> 2) & 1];
@@ -1153,7 +1164,7 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
             presentMask = 0;
 #pragma unroll
             for (int t = 0; t < 8; t++)
-                if (__shfl(nMember, t * 8) > S.tCount[t])
+                if (laneI(nMember, t * 8) > S.tCount[t])
                     presentMask |= 1u << t;
         }
         if (wErr < bestError)
@@ -1214,6 +1225,11 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
     }
 
     // =================================== H mode ===================================
+    // HAND-OVER POINT of the stage union: up to here `S.u.group` (the group's pixels, read through pixJ / pwJ by the sector
+    // split and the T modes' group counts) was alive; the H mode's `S.u.h` and the cluster fit's `S.u.a` overwrite it.  The
+    // WAVE_SYNC at the end of the T-mode loop above (a wavefront-scope fence) orders every read of the group before the stores
+    // below; no pixJ / pwJ call may be added after this line for MODE 0 / 1 (the punch-through instantiation keeps its group
+    // pixels in LDS of their own).
     // groupings = the flipped sector assignment (ETC.cpp:1855-1860)
     if (!groupAll)
     {
@@ -1395,7 +1411,7 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
             const bool mine = (hBestId == wId) && (hBestErr == wErr);
             const u64 who = __ballot(mine);
             const int src = __ffsll((long long)who) - 1;
-            const int bc0 = __shfl(hBestC0, src), bc1 = __shfl(hBestC1, src);
+            const int bc0 = laneI(hBestC0, src), bc1 = laneI(hBestC1, src);
             const int table = wId >> 10;
             // the winner's sector and sign bits: lane px works out pixel px again (the operations of the colour rows above)
             u32 sectorBits, signBits;
@@ -2281,7 +2297,7 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
             prefix[0] = 0;
 #pragma unroll
             for (int t = 0; t < 8; t++)
-                prefix[t + 1] = prefix[t] + __shfl(nUnique, t * 8);
+                prefix[t + 1] = prefix[t] + laneI(nUnique, t * 8);
 
             // candidate `id` = (table, ci) in the reference's order; own colours, then (hazard H2) one zero slot, then
             // copies of colour 0

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Kernel timing of one format on synthetic BASELINE-style input (developer tool, GPU box).
    python tools/fmt_bench.py bc7|bc7o|bc7b|bc7u|bc1|bc1x|bc2|bc3|bc4|bc5|bc6hu|bc6hs|etc1|etc2|etc2pt|etc2rgba|eac [size] [reps]   (bc1x / bc7b = with Flags::Better, bc7u = Flags::Ultra)
+   bc7c5 / bc7c5u = BASELINE config 5a / 5b (seed-5 image, default / Flags::Ultra)
    bc7photo|bc7grad|bc7two = EncodeBC7 on (size/4)^2 blocks of the photo-like / smooth opaque gradient / two-colour family of synth.content_families"""
 import sys, os, json, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,12 +15,14 @@ ctx = api.Context(0)
 FAMILY = {"bc7photo": "photo-like", "bc7grad": "gradient opaque", "bc7two": "two colours"}
 if fmt in FAMILY:
     b = synth.content_families((size // 4) ** 2)[FAMILY[fmt]]
+elif fmt in ("bc7c5", "bc7c5u"):  # BASELINE config 5a / 5b: the seed-5 image (16384^2 at full size), default options / Flags::Ultra
+    b = synth.tile_blocks(synth.image_rgba8(5, size, size))
 elif fmt in ("bc7", "bc7o", "bc7b", "bc7u", "bc1", "bc1x", "bc2", "bc3", "bc4", "bc5", "etc1", "etc2", "etc2pt", "etc2rgba", "eac"):
     b = synth.tile_blocks(synth.image_rgba8(2, size, size, opaque=(fmt == "bc7o")))
 else:
     b = synth.tile_blocks(synth.image_f16bits(3, size, size))
 t = torch.from_numpy(b).cuda()
-enc = {"bc7": ctx.encode_bc7, "bc7o": ctx.encode_bc7, "bc7photo": ctx.encode_bc7, "bc7grad": ctx.encode_bc7, "bc7two": ctx.encode_bc7, "bc7b": lambda x, out=None: ctx.encode_bc7(x, api.Options(flags=api.Flags.Better), out=out),
+enc = {"bc7": ctx.encode_bc7, "bc7c5": ctx.encode_bc7, "bc7c5u": lambda x, out=None: ctx.encode_bc7(x, api.Options(flags=api.Flags.Ultra), out=out), "bc7o": ctx.encode_bc7, "bc7photo": ctx.encode_bc7, "bc7grad": ctx.encode_bc7, "bc7two": ctx.encode_bc7, "bc7b": lambda x, out=None: ctx.encode_bc7(x, api.Options(flags=api.Flags.Better), out=out),
        "bc7u": lambda x, out=None: ctx.encode_bc7(x, api.Options(flags=api.Flags.Ultra), out=out), "bc1": ctx.encode_bc1,
        "bc1x": lambda x, out=None: ctx.encode_bc1(x, api.Options(flags=api.Flags.Better), out=out),
        "bc6hu": lambda x, out=None: ctx.encode_bc6h(x, signed=False, out=out),

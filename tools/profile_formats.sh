@@ -9,14 +9,14 @@ OUT=gpurun_out/$TAG/fmt
 mkdir -p $OUT
 : > $OUT/fmt_bench.jsonl
 if [ -z "$PROFILE_SKIP_BENCH" ]; then
-for spec in "bc7 4096" "bc7o 4096" "bc7b 4096" "bc7u 4096" "bc7photo 2048" "bc7grad 2048" "bc7two 2048" "bc1 4096" "bc1x 2048" "bc2 4096" "bc3 4096" "bc4 4096" "bc5 4096" "bc6hu 4096" "bc6hs 2048" "etc1 2048" "etc2 4096" "etc2rgba 4096" "etc2pt 2048" "eac 4096"; do
+for spec in "bc7 4096" "bc7o 4096" "bc7b 4096" "bc7u 4096" "bc7photo 4096" "bc7grad 4096" "bc7two 4096" "bc7c5 16384" "bc7c5u 16384" "bc1 4096" "bc1x 2048" "bc2 4096" "bc3 4096" "bc4 4096" "bc5 4096" "bc6hu 4096" "bc6hs 2048" "etc1 2048" "etc2 4096" "etc2rgba 4096" "etc2pt 2048" "eac 4096"; do
   set -- $spec
   python tools/fmt_bench.py $1 $2 3 >> $OUT/fmt_bench.jsonl 2>> $OUT/fmt_bench.err
 done
 fi
 cat $OUT/fmt_bench.jsonl
 # PROFILE_FORMATS="bc6hu:4096,bc7o:4096" restricts the counter passes
-IFS=',' read -ra SPECS <<< "${PROFILE_FORMATS:-bc7:4096,bc7o:4096,bc7u:4096,bc6hu:4096,etc2rgba:4096,bc1:4096,bc7photo:2048}"
+IFS=',' read -ra SPECS <<< "${PROFILE_FORMATS:-bc7:4096,bc7o:4096,bc7u:4096,bc6hu:4096,etc2rgba:4096,bc1:4096,bc7photo:4096,bc7grad:4096,bc7two:4096,bc7c5:16384,bc7c5u:16384}"
 for spec in "${SPECS[@]}"; do
   spec=${spec/:/ }
   set -- $spec
