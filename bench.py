@@ -323,7 +323,7 @@ def run_sharded(args):
             if pmc and not pmc.get("stale"):
                 result["roofline"] = roofline_block("bc7", nloc, k_ms, "cvttmi_bc7_kernel", insts_per_block=pmc["valu_insts_per_wave"] / 16.0,
                                                     hbm_bytes_per_block=pmc["hbm_bytes_per_launch"] / float(pmc["blocks"]),
-                                                    waves_per_simd=pmc.get("avg_waves_per_simd"), source=pmc["source"])
+                                                    waves_per_simd=pmc.get("avg_waves_per_simd"), source=pmc["source"], mix=pmc.get("valu_mix"))
             else:
                 result["roofline"] = roofline_block("bc7", nloc, k_ms, "cvttmi_bc7_kernel")
             result["roofline"]["note"] = "rank 0's shard (%d blocks) per launch; per-block counters of the 4096^2 profile of the same kernel" % nloc
@@ -483,13 +483,14 @@ def format_counters(src_sha):
             out[fmt] = {"valu_wave_insts_per_block": insts / blocks[fmt],
                         "hbm_bytes_per_block": (sum(hbm) / blocks[fmt]) if len(hbm) == len(kernels) else None,
                         "avg_waves_per_simd": sum(k["derived"]["avg_waves_per_simd"] * k["dur_us"] for k in kernels if "derived" in k) / dur,
-                        "kernels": [k["kernel"] for k in kernels], "profiled_blocks": blocks[fmt]}
+                        "kernels": [k["kernel"] for k in kernels], "profiled_blocks": blocks[fmt],
+                        "valu_mix": max(kernels, key=lambda k: k["dur_us"]).get("valu_mix")}
         return out
     except Exception:  # noqa
         return None
 
 
-def roofline_block(fmt, nblk, k_ms, kernel, insts_per_block=None, hbm_bytes_per_block=None, waves_per_simd=None, source=None):
+def roofline_block(fmt, nblk, k_ms, kernel, insts_per_block=None, hbm_bytes_per_block=None, waves_per_simd=None, source=None, mix=None):
     """The roofline of one kernel launch.  The search kernels are VALU-issue bound (72-144 algorithmic bytes per block against
     thousands of instructions), so when the PMC profile of this very library is at hand `bound` is "valu": achieved =
     wave-level VALU instructions per second (SQ_INSTS_VALU of the profile, per block, x the blocks of this launch / the kernel
@@ -516,6 +517,15 @@ def roofline_block(fmt, nblk, k_ms, kernel, insts_per_block=None, hbm_bytes_per_
          "peak_source": "MI355X_MICROARCH.md: one wave64 VALU instruction per SIMD per 2 cycles, 1024 SIMDs at %.1f GHz" % (SHADER_CLOCK_HZ / 1e9)}
     if hbm.get("traffic_over_algorithmic") is not None:
         r["traffic_over_algorithmic"] = hbm["traffic_over_algorithmic"]
+    if mix and mix.get("issue_floor_cycles_per_inst"):
+        # The 2-cycle peak holds for plain f32 add / sub / mul, moves, integer add and logic only; everything else occupies the
+        # SIMD for 4.3 cycles (8.3: rcp / sqrt) -- measured, profiles/r02/valu_peak.json.  `valu_mix` prices THIS kernel's
+        # instruction classes (SQ_INSTS_VALU_* of the same profile; tools/valu_mix.py says how, and that it is an estimate):
+        # frac_of_mix_floor = the cycles per instruction its mix needs at full overlap / the cycles it takes.
+        actual = (VALU_PEAK * VALU_CYCLES_PER_INST) / rate  # SIMD cycles per wave instruction, as measured here
+        r["valu_mix"] = dict(mix)
+        r["valu_mix"]["actual_cycles_per_inst"] = actual
+        r["valu_mix"]["frac_of_mix_floor"] = mix["issue_floor_cycles_per_inst"] / actual
     return r
 
 
@@ -538,6 +548,7 @@ def profiled_counters(lib_sha):
                 "hbm_bytes_per_launch": d["hbm_traffic_bytes_per_launch"]["bytes_corrected"],
                 "valu_insts_per_wave": sq["derived"]["valu_insts_per_wave"],
                 "avg_waves_per_simd": sq["derived"].get("avg_waves_per_simd(WAVE_CYCLES*4/simd_cycles)"),
+                "valu_mix": d.get("valu_mix"),
                 "blocks": int(sq["grid"]) // 4}
     except Exception:  # noqa
         return None
@@ -622,7 +633,7 @@ def run_single(args):
         waves = (nblk + 15) // 16
         result["roofline"] = roofline_block("bc7", nblk, k_ms, "cvttmi_bc7_kernel", insts_per_block=pmc["valu_insts_per_wave"] * waves / float(nblk),
                                             hbm_bytes_per_block=pmc["hbm_bytes_per_launch"] / float(nblk),
-                                            waves_per_simd=pmc.get("avg_waves_per_simd"), source=pmc["source"])
+                                            waves_per_simd=pmc.get("avg_waves_per_simd"), source=pmc["source"], mix=pmc.get("valu_mix"))
         result["roofline"]["note"] = ("kernel_ms brackets the launches of one encode on its stream (search + hand-over launch + commit); "
                                       "%d algorithmic bytes per block, so the HBM fraction (`hbm`) is small by construction" % ALGO_BYTES["bc7"])
         result["valu_issue"] = {"insts_per_wave": pmc["valu_insts_per_wave"], "achieved": result["roofline"]["achieved"], "unit": "wave-instructions/s",
@@ -713,7 +724,7 @@ def per_config_legs(torch, api, synth, ctx, dev, h, rcp, rcp_gold, same_lut, arg
         c = next((fmtc[k] for k in ([prof] if isinstance(prof, str) else (prof or [])) if fmtc and isinstance(fmtc.get(k), dict)), None)
         if c:
             roof = roofline_block(fmt, n, ms_min, "+".join(c["kernels"]), insts_per_block=c["valu_wave_insts_per_block"],
-                                  hbm_bytes_per_block=c["hbm_bytes_per_block"], waves_per_simd=c["avg_waves_per_simd"], source=fmtc["source"])
+                                  hbm_bytes_per_block=c["hbm_bytes_per_block"], waves_per_simd=c["avg_waves_per_simd"], source=fmtc["source"], mix=c.get("valu_mix"))
             if c["profiled_blocks"] != n:
                 roof["counters_note"] = "per-block counters of the same kernel on %d blocks of the same kind of content" % c["profiled_blocks"]
         else:

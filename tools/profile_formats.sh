@@ -26,6 +26,8 @@ for spec in "${SPECS[@]}"; do
   # HBM traffic: FETCH_SIZE and WRITE_SIZE in passes of their own (MI355X_MICROARCH.md, HBM / rocprofv3 section)
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmcf_$1 -o $1 -- python tools/fmt_bench.py $1 $2 1 > $OUT/pmcf_$1.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmcw_$1 -o $1 -- python tools/fmt_bench.py $1 $2 1 > $OUT/pmcw_$1.log 2>&1
+  # instruction-class mix (tools/valu_mix.py)
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT --kernel-trace --output-format csv -d $OUT/pmcm_$1 -o $1 -- python tools/fmt_bench.py $1 $2 1 > $OUT/pmcm_$1.log 2>&1
   cat $OUT/trace_$1/*kernel_stats.csv | head -4
 done
 python tools/summarize_fmt_pmc.py $OUT > /dev/null

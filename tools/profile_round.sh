@@ -16,6 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bc7 -- pyt
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -o bc7 -- python bench.py $STEPS --no-cpu --no-extra "$@" > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bc7 -- python bench.py $STEPS --no-cpu --no-extra "$@" > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bc7 -- python bench.py $STEPS --no-cpu --no-extra "$@" > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT --kernel-trace --output-format csv -d $OUT/pmc_mix -o bc7 -- python bench.py $STEPS --no-cpu --no-extra "$@" > $OUT/pmc_mix.log 2>&1
 grep -o '{"metric.*' $OUT/bench.json | cut -c1-1500
 cat $OUT/trace/bc7_kernel_stats.csv
 python tools/summarize_pmc.py $OUT

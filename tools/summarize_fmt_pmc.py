@@ -2,6 +2,12 @@
 """Condense the per-format rocprofv3 CSVs of tools/profile_formats.sh into fmt_summary.json."""
 import csv, glob, json, os, sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import valu_mix  # noqa: E402
+try:
+    STATIC = valu_mix.static_split()
+except Exception:  # noqa
+    STATIC = {}
 out_dir = sys.argv[1]
 summary = {"fmt_bench": [json.loads(l) for l in open(os.path.join(out_dir, "fmt_bench.jsonl")) if l.strip()]}
 for d in sorted(glob.glob(os.path.join(out_dir, "pmc_*"))):
@@ -67,6 +73,20 @@ for d in sorted(glob.glob(os.path.join(out_dir, "pmc_*"))):
         if kname in last and "FETCH_SIZE" in c3 and "WRITE_SIZE" in c3:
             last[kname]["hbm"] = {"fetch_kib_raw": c3["FETCH_SIZE"], "write_kib_raw": c3["WRITE_SIZE"],
                                   "bytes_corrected": (2 * c3["FETCH_SIZE"] + c3["WRITE_SIZE"]) * 1024}
+    # fifth pass: instruction-class counters -> the mix and what it can issue at best (tools/valu_mix.py)
+    f5 = glob.glob(os.path.join(out_dir, "pmcm_" + fmt, "*counter_collection.csv"))
+    if f5:
+        d5 = {}
+        for r in csv.DictReader(open(f5[0])):
+            if "cvttmi" in r["Kernel_Name"]:
+                e5 = d5.setdefault((r["Kernel_Name"].split("(")[0], r["Dispatch_Id"]), {})
+                e5[r["Counter_Name"]] = e5.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        for (kname, _), c5 in d5.items():  # the last dispatch of each kernel stays
+            if kname in last and c5.get("SQ_INSTS_VALU"):
+                try:
+                    last[kname]["valu_mix"] = valu_mix.floor(c5, STATIC.get(kname.replace("void ", "")))
+                except Exception as ex:  # noqa
+                    last[kname]["valu_mix_error"] = str(ex)
     summary[fmt] = list(last.values())
     st = glob.glob(os.path.join(out_dir, "trace_" + fmt, "*kernel_stats.csv"))
     if st:

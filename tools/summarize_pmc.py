@@ -44,7 +44,7 @@ def per_kernel(rows):
     return out
 
 
-for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
+for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_mix"):
     f = glob.glob(os.path.join(out_dir, sub, "*counter_collection.csv"))
     if not f:
         continue
@@ -86,6 +86,16 @@ try:
                                                "bytes_corrected": (2 * fetch + write) * 1024, "dispatches_averaged": fe["mean_last20"]["n"]}
 except Exception as e:  # noqa
     summary["traffic_error"] = str(e)
+# instruction-class mix of the dominant kernel and the issue rate that mix allows (tools/valu_mix.py)
+try:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import valu_mix
+    name = summary["pmc_sq"][0]["kernel"]
+    me = [e for e in summary["pmc_mix"] if e["kernel"] == name][0]
+    summary["valu_mix"] = valu_mix.floor(me["mean_last20"]["counters"], valu_mix.static_split().get(name.replace("void ", "")))
+    summary["valu_mix"]["kernel"] = name
+except Exception as e:  # noqa
+    summary["valu_mix_error"] = str(e)
 # which kernel objects these counters belong to: bench.py quotes them only while the loaded library still holds the same ones
 try:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
