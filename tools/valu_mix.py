@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
 """Instruction-class mix of the kernels and what that mix can issue at best (developer / measurement tool).
 
-The guide's VALU peak -- one wave64 instruction per SIMD per 2 cycles -- holds for a few instruction kinds only.  Measured on
-MI355X with two or more waves per SIMD (tools/valu_peak.hip, profiles/r02/valu_peak.json): plain f32 add / sub / mul, moves,
-integer add / sub, and / or / xor, right shifts: 2.3 cycles; fma, min / max, compares, selects, conversions, 24-bit and 32-bit
-multiplies, left shifts, three-operand integer ops, v_perm, dot, SDWA / DPP, lane access, packed f32: 4.2-4.3; rcp / sqrt: 8.3.
+The guide's VALU peak -- one wave64 instruction per SIMD per 2 cycles -- is a DUAL-ISSUE figure.  Measured on MI355X
+(tools/valu_peak.hip, profiles/r02/valu_peak.json: 291 instruction kinds and pairs, 1-8 waves per SIMD): a wave64 VALU instruction
+occupies its SIMD for 4.2-4.3 cycles (rcp / sqrt 8.3), and a second instruction OF ANOTHER WAVE shares that slot (2.3 cycles per
+instruction) only for certain pairs:
+    F   plain v_add / v_sub / v_mul_f32, v_mov_b32                      pairs with F, I and S1
+    I   integer add / sub, and / or / xor / not, right shifts          pairs with F and I            (add_u32 + lshl: 4.2)
+    S1  fma, min / max, compares, selects, conversions, left shifts,    pairs with F only             (mul_f32 + max_f32: 2.3,
+        bfe, perm, three-operand integer ops, med3, rndne, mul_lo        max_f32 + max_f32: 4.3)
+    S2  24-bit multiplies, dot, SDWA, DPP, packed, lane access          pairs with nothing            (mul_f32 + mad_i24: 4.2)
+    T   rcp / sqrt / rsq                                                8.3 cycles, alone
+So the fewest 4.3-cycle slots a mix needs is a matching problem: S1 with F first, then what is left of F with I and itself.
 
 The SQ class counters (SQ_INSTS_VALU_ADD_F32, _MUL_F32, _FMA_F32, _TRANS_F32, _INT32, _CVT; what each counts:
 tools/valu_mix_calibrate.sh, profiles/r05/valu_mix_calibration.txt) give the DYNAMIC size of six classes and, by difference, of
-"other" (logic, shifts, moves, float compares / min / max, selects, perm, lane access).  Three of the classes mix 2.3- and
-4.3-cycle kinds (ADD/MUL: plain or packed; INT32: add/sub or the rest; other: logic / right shift / move or the rest); their
-split is taken from the kernel's ISA (static count: the hot loops are unrolled and dominate the text), which makes the result an
-ESTIMATE, reported as such:  floor = sum(class size x cycles of its kinds) / SQ_INSTS_VALU  cycles per instruction.
+"other" (logic, shifts, moves, float compares / min / max, selects, perm, lane access).  How a counter class splits into F / I / S1 /
+S2 is taken from the kernel's ISA (static count: the hot loops are unrolled and dominate the text).  That, the perfect interleaving
+of the waves the matching assumes, and 2.3 / 4.3 as the only two costs make the result an ESTIMATE of a floor, reported as such.
 
     python tools/valu_mix.py [lib.so]                  static split per kernel (no GPU)
     valu_mix.floor(dynamic_counters, static_split)     used by tools/summarize_fmt_pmc.py / summarize_pmc.py
 """
 import json
+import math
 import os
 import re
 import subprocess
@@ -27,46 +34,55 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import kernel_resources  # noqa: E402
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-C2, C4, C8 = 2.3, 4.3, 8.3  # cycles per wave64 instruction, two or more waves per SIMD (profiles/r02/valu_peak.json)
+SLOT, PAIRED_SLOT, TRANS_SLOT = 4.3, 4.6, 8.3  # cycles: one instruction alone in its slot / two sharing it / rcp, sqrt
 
 TRANS = ("v_rcp_", "v_sqrt_", "v_rsq_", "v_log_", "v_exp_", "v_sin_", "v_cos_")
-INT_FAST = ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_add_co_u32", "v_sub_co_u32", "v_subrev_co_u32", "v_addc_co_u32", "v_subb_co_u32", "v_add_i32", "v_sub_i32")
-INT_SLOW = ("v_mul_", "v_mad_", "v_min_", "v_max_", "v_med3_", "v_min3_", "v_max3_", "v_add3_", "v_lshl_add", "v_add_lshl", "v_bfe_", "v_dot", "v_sad_", "v_mbcnt",
-            "v_cmp_", "v_cmpx_", "v_xad_")
-OTHER_FAST = ("v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_mov_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_bfrev")
+F_OPS = ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_mov_b32")
+I_OPS = ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_add_co_u32", "v_sub_co_u32", "v_subrev_co_u32", "v_addc_co_u32", "v_subb_co_u32", "v_add_i32", "v_sub_i32",
+         "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_lshrrev_b32", "v_ashrrev_i32")
+S2_PREFIX = ("v_mad_i32_i24", "v_mad_u32_u24", "v_mul_i32_i24", "v_mul_u32_u24", "v_mul_hi_", "v_pk_", "v_dot", "v_readlane", "v_readfirstlane", "v_writelane",
+             "v_mbcnt", "v_permlane")
+INT_CLASS = ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_add_co", "v_sub_co", "v_subrev_co", "v_addc_co", "v_subb_co", "v_add_i32", "v_sub_i32", "v_mul_", "v_mad_",
+             "v_min_u", "v_min_i", "v_max_u", "v_max_i", "v_med3_i", "v_med3_u", "v_min3_i", "v_min3_u", "v_max3_i", "v_max3_u", "v_add3_", "v_lshl_add", "v_add_lshl",
+             "v_bfe_", "v_dot", "v_sad_", "v_mbcnt", "v_cmp_lt_u", "v_cmp_gt_u", "v_cmp_le_u", "v_cmp_ge_u", "v_cmp_eq_u", "v_cmp_ne_u", "v_cmp_lg_u",
+             "v_cmp_lt_i", "v_cmp_gt_i", "v_cmp_le_i", "v_cmp_ge_i", "v_cmp_eq_i", "v_cmp_ne_i", "v_cmp_lg_i", "v_cmpx_", "v_xad_")
 
 
 def classify(op):
-    """(pmc class, fast?) of one VALU mnemonic"""
+    """(SQ counter class, pairing class F / I / S1 / S2 / T) of one VALU mnemonic"""
     base = re.sub(r"_(e32|e64|sdwa|dpp|e64_dpp)$", "", op)
     modified = op.endswith(("_sdwa", "_dpp"))
-    if base.startswith("v_pk_add_f32") or base.startswith("v_pk_mul_f32"):
-        return ("ADD_F32" if "add" in base else "MUL_F32"), False
-    if base.startswith("v_pk_fma_f32"):
-        return "FMA_F32", False
-    if base in ("v_add_f32", "v_sub_f32", "v_subrev_f32"):
-        return "ADD_F32", not modified
-    if base == "v_mul_f32" or base == "v_mul_legacy_f32":
-        return "MUL_F32", not modified
-    if base.startswith(("v_fma_f32", "v_fmac_f32", "v_mad_f32", "v_mac_f32", "v_fma_mix")):
-        return "FMA_F32", False
+    # --- counter class (profiles/r05/valu_mix_calibration.txt) ---
+    if base.startswith(("v_pk_add_f32",)) or base in ("v_add_f32", "v_sub_f32", "v_subrev_f32"):
+        cls = "ADD_F32"
+    elif base.startswith("v_pk_mul_f32") or base in ("v_mul_f32", "v_mul_legacy_f32"):
+        cls = "MUL_F32"
+    elif base.startswith(("v_fma_f32", "v_fmac_f32", "v_mad_f32", "v_mac_f32", "v_pk_fma_f32")):
+        cls = "FMA_F32"
+    elif base.startswith(TRANS):
+        cls = "TRANS_F32"
+    elif base.startswith("v_cvt"):
+        cls = "CVT"
+    elif base.startswith(INT_CLASS) and not base.startswith(("v_mul_f", "v_mad_f", "v_mul_legacy")):
+        cls = "INT32"
+    else:
+        cls = "OTHER"
+    # --- pairing class (profiles/r02/valu_peak.json) ---
     if base.startswith(TRANS):
-        return "TRANS_F32", False
-    if base.startswith("v_cvt_") or base.startswith("v_cvt"):
-        return "CVT", False
-    if base.endswith(("_f32", "_f16", "_f64")) or "_f32_" in base:  # float min / max / compares / rndne / med3 ...
-        return "OTHER", False
-    if base in INT_FAST:
-        return "INT32", not modified
-    if base.startswith(INT_SLOW):
-        return "INT32", False
-    if base in OTHER_FAST:
-        return "OTHER", not modified
-    return "OTHER", False  # shifts left, selects, perm, bfi, lane access, dpp moves, ...
+        pair = "T"
+    elif modified or base.startswith(S2_PREFIX):
+        pair = "S2"
+    elif base in F_OPS:
+        pair = "F"
+    elif base in I_OPS:
+        pair = "I"
+    else:
+        pair = "S1"
+    return cls, pair
 
 
 def static_split(path=None):
-    """{kernel: {class: {"fast": n, "slow": n}}} from the ISA of the library's code objects"""
+    """{kernel: {counter class: {pairing class: n}}} from the ISA of the library's code objects"""
     path = path or os.path.join(kernel_resources.ROOT, "convectionkernels_amd", "lib", "libcvtt_mi355x.so")
     res = {}
     for obj in kernel_resources.code_objects(path):
@@ -83,9 +99,9 @@ def static_split(path=None):
             m = re.match(r"^\s+(v_[a-z0-9_]+)", line)
             if cur is None or not m:
                 continue
-            cls, fast = classify(m.group(1))
-            e = cur.setdefault(cls, {"fast": 0, "slow": 0})
-            e["fast" if fast else "slow"] += 1
+            cls, pair = classify(m.group(1))
+            e = cur.setdefault(cls, {})
+            e[pair] = e.get(pair, 0) + 1
     names = [n for n in res if n.startswith("_Z")]
     try:
         dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.splitlines()
@@ -97,33 +113,43 @@ def static_split(path=None):
     return {k: v for k, v in res.items() if v}
 
 
+def slots(n):
+    """fewest issue slots for n = {F, I, S1, S2, T} instructions: (alone, shared, trans)"""
+    f, i, s1, s2, t = (float(n.get(k, 0.0)) for k in ("F", "I", "S1", "S2", "T"))
+    p1 = min(s1, f)                # every S1 that finds an F shares its slot with it
+    rest = (f - p1) + i            # what is left of F, and I, pair among themselves
+    shared = p1 + rest / 2.0
+    alone = (s1 - p1) + s2
+    return alone, shared, t
+
+
 def floor(counters, split):
     """counters: SQ_INSTS_VALU and the six class counters of one dispatch; split: static_split()[kernel].
-    Returns the mix and the estimated cycles per VALU instruction this mix needs at full overlap."""
+    Returns the mix and the estimated cycles per VALU instruction it needs when two or more waves interleave perfectly."""
     total = float(counters["SQ_INSTS_VALU"])
     if total <= 0:
         return None
     cls = {k: float(counters.get("SQ_INSTS_VALU_" + k, 0.0)) for k in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "INT32", "CVT")}
     cls["OTHER"] = max(0.0, total - sum(cls.values()))
-
-    def fast_frac(name):
-        e = (split or {}).get(name) or {}
-        n = e.get("fast", 0) + e.get("slow", 0)
-        return e.get("fast", 0) / n if n else 0.5
-
-    cycles = cls["FMA_F32"] * C4 + cls["CVT"] * C4 + cls["TRANS_F32"] * C8
-    lo = hi = cycles
-    for name in ("ADD_F32", "MUL_F32", "INT32", "OTHER"):
-        f = fast_frac(name)
-        cycles += cls[name] * (f * C2 + (1.0 - f) * C4)
-        lo += cls[name] * C2
-        hi += cls[name] * C4
+    default = {"ADD_F32": {"F": 1}, "MUL_F32": {"F": 1}, "FMA_F32": {"S1": 1}, "TRANS_F32": {"T": 1}, "INT32": {"I": 1, "S1": 1, "S2": 1}, "CVT": {"S1": 1},
+               "OTHER": {"F": 1, "I": 1, "S1": 2}}
+    n = {}
+    for name, dyn in cls.items():
+        e = (split or {}).get(name) or default[name]
+        tot = float(sum(e.values())) or 1.0
+        for pair, cnt in e.items():
+            n[pair] = n.get(pair, 0.0) + dyn * cnt / tot
+    alone, shared, t = slots(n)
+    cycles = alone * SLOT + shared * PAIRED_SLOT + t * TRANS_SLOT
+    # no S1-F sharing at all (an S1 instruction always alone): the pessimistic end of the bracket
+    pess = (n.get("S1", 0.0) + n.get("S2", 0.0)) * SLOT + (n.get("F", 0.0) + n.get("I", 0.0)) / 2.0 * PAIRED_SLOT + t * TRANS_SLOT
     return {"fraction_of_valu_instructions": {k: round(v / total, 4) for k, v in cls.items()},
-            "static_fast_fraction_within_class": {k: round(fast_frac(k), 3) for k in ("ADD_F32", "MUL_F32", "INT32", "OTHER")},
+            "pairing_classes": {k: round(v / total, 4) for k, v in sorted(n.items())},
             "issue_floor_cycles_per_inst": round(cycles / total, 3),
-            "issue_floor_bracket": [round(lo / total, 3), round(hi / total, 3)],
-            "note": "estimate: dynamic class sizes (SQ_INSTS_VALU_*), the 2.3 / 4.3-cycle split inside the mixed classes from the static ISA; "
-                    "bracket = all of them fast / all slow; costs from profiles/r02/valu_peak.json"}
+            "issue_floor_without_S1_F_sharing": round(pess / total, 3),
+            "two_cycle_peak_cycles_per_inst": 2.0,
+            "note": "estimate: dynamic class sizes from SQ_INSTS_VALU_*, their split into pairing classes from the static ISA, slot costs "
+                    "4.3 (alone) / 4.6 (two instructions of two waves) / 8.3 (rcp, sqrt) from profiles/r02/valu_peak.json, perfect interleaving assumed"}
 
 
 if __name__ == "__main__":
@@ -133,7 +159,11 @@ if __name__ == "__main__":
         print(json.dumps(s, indent=1))
     else:
         for k in sorted(s):
-            tot = sum(e["fast"] + e["slow"] for e in s[k].values())
-            fast = sum(e["fast"] for e in s[k].values())
-            print("%-60s VALU %6d  2.3-cycle kinds %.2f  %s" % (k[:60], tot, fast / max(tot, 1),
-                  " ".join("%s %d/%d" % (c, e["fast"], e["fast"] + e["slow"]) for c, e in sorted(s[k].items()))))
+            n = {}
+            for e in s[k].values():
+                for pair, cnt in e.items():
+                    n[pair] = n.get(pair, 0) + cnt
+            tot = sum(n.values())
+            alone, shared, t = slots(n)
+            print("%-58s VALU %6d  %s  static floor %.2f cycles/inst" % (k[:58], tot, " ".join("%s %.2f" % (p, n.get(p, 0) / max(tot, 1)) for p in ("F", "I", "S1", "S2", "T")),
+                  (alone * SLOT + shared * PAIRED_SLOT + t * TRANS_SLOT) / max(tot, 1)))
