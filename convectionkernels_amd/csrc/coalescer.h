@@ -202,19 +202,17 @@ namespace cvttmi_dropin
             batch.push_back(&me);
             {
                 size_t keep = 0;
-                bool tookMe = false;
                 for (size_t i = 0; i < s.pending.size(); i++)
                 {
                     Request *r = s.pending[i];
                     if (r == &me)
-                        tookMe = true;
-                    else if (batch.size() < maxGroups_)
+                        continue; // already first in the batch
+                    if (batch.size() < maxGroups_)
                         batch.push_back(r);
                     else
                         s.pending[keep++] = r;
                 }
                 s.pending.resize(keep);
-                (void)tookMe;
             }
             // what "recently" means: this launch, or one less than before when it carried fewer calls (a lone caller is back at 1 after a few calls)
             s.recent = batch.size() >= s.recent ? batch.size() : s.recent - 1;

@@ -226,6 +226,24 @@ __device__ __forceinline__ void resolveHalfFake(int (&quantized)[3], const int (
     }
 }
 
+// Two f32 values that go through the same operations: two plain instructions each (default), or, with CVTT_ETC_PACKED_F32, one
+// v_pk_mul_f32 / v_pk_add_f32.  Same operations on the same values in the same order either way.  A packed instruction does two
+// values in one 4.3-cycle issue slot but never shares the slot with another wave's instruction; a plain f32 instruction shares it
+// with nearly anything (tools/valu_mix.py), and this kernel has more compares, minima and selects looking for such a partner than
+// plain f32 work.  Round 2 measured packed ahead (3.7 waves per SIMD, 24 spilled registers); round 5, with 4.2 waves and no
+// scratch: plain EncodeETC2RGBA 41.1 -> 42.6, EncodeETC2 44.1 -> 46.2, EncodeETC1 42.2 -> 44.0 Mblocks/s (profiles/r05/ab_etc2.txt).
+#ifndef CVTT_ETC_PACKED_F32
+struct EtcPair
+{
+    float x, y;
+};
+__device__ __forceinline__ EtcPair operator-(const EtcPair &a, const EtcPair &b) { return EtcPair{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ EtcPair operator+(const EtcPair &a, const EtcPair &b) { return EtcPair{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ EtcPair operator*(const EtcPair &a, const EtcPair &b) { return EtcPair{a.x * b.x, a.y * b.y}; }
+#else
+typedef float EtcPair __attribute__((ext_vector_type(2)));
+#endif
+
 struct EtcErr
 {
     bool uniform;
@@ -243,10 +261,10 @@ struct EtcErr
         }
         return wu(r, g, b, px, pw);
     }
-    // The weighted metric for TWO colours at once in packed f32 lanes (v_pk_mul_f32 / v_pk_add_f32): each lane does
+    // The weighted metric for TWO colours at once (an EtcPair: plain or packed f32, see above): each of the two does
     // ComputeErrorWeighted's operations in its order (product, difference, squares added left to right), so both results are
     // the numbers the scalar form gives.  Only valid when !uniform (and, where the caller would use operator(), !fake).
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef EtcPair f32x2;
     __device__ __forceinline__ void weigh2(f32x2 (&mw)[3], const int (&a)[3], const int (&b)[3]) const
     {
         mw[0] = f32x2{(float)a[0] * rw, (float)b[0] * rw};
@@ -1723,10 +1741,10 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
                     if (!punch && !FAKE && !E.uniform)
                     {
                         // the weighted metric (ComputeErrorWeighted, ETC.cpp:70-80), the four paint colours of a candidate two
-                        // at a time in packed f32 lanes: every lane does the reference's operations in the reference's order
+                        // at a time (EtcPair): each value goes through the reference's operations in the reference's order
                         // (product, difference, squares added left to right), so the sums are the same numbers; 16 packed
                         // instructions per pixel instead of 32 plain ones
-                        typedef float pk2 __attribute__((ext_vector_type(2)));
+                        typedef EtcPair pk2;
                         pk2 mw01[3], mw23[3];
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++)

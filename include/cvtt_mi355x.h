@@ -339,7 +339,8 @@ int cvttmi_encode_etc2_rgba_multi(const int *devices, int numDevices, uint8_t *o
                                   const cvttmi_options *options);
 /* The device list of the C++ face's *Batch entry points (cvtt::Kernels::EncodeBC7Batch, EncodeBC1Batch, EncodeBC6HU/SBatch,
  * EncodeETC2RGBABatch): more than one entry = calls of at least 65 536 blocks are sharded over the list as above (by groups).
- * Default: the environment variable CVTTMI_DEVICES ("0,1,2,3"), else the single device CVTTMI_DEVICE (default 0). */
+ * Default: the environment variable CVTTMI_DEVICES ("0,1,2,3"), else the single device CVTTMI_DEVICE (default 0).
+ * Configuration call: not to be made while another thread is inside a *Batch call (it replaces the handle those calls use). */
 int cvttmi_dropin_set_devices(const int *devices, int numDevices);
 
 /* Arithmetic self-test: evaluates binary32 divide and square root on `count` pseudo-random finite
