@@ -429,7 +429,11 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
     __shared__ typename std::conditional<MODE == 2, EtcGroupPixels, EtcNoGroupPixels>::type groupSeparate;
     u32 (*const gpix)[16] = (MODE == 2) ? reinterpret_cast<u32 (*)[16]>(&groupSeparate) : shared1.u.group;
 
-    const int lane = threadIdx.x;
+    // (not const: ETC_REFRESH_LANE() hands the optimiser the same number as a NEW value at the start of the later stages, so that
+    // what is derived from it -- lane & 7, lane & 15, lane >> 3 ... -- is computed where it is used instead of being kept alive,
+    // and spilled, from the sector split to the last stage)
+    int lane = threadIdx.x;
+#define ETC_REFRESH_LANE() do { lane = (int)threadIdx.x; asm volatile("" : "+v"(lane)); } while (0)
     // The eight waves of a reference group read the same 512 bytes.  Workgroup b runs on XCD b % 8 (observed, for speed only;
     // nothing depends on it), each XCD with an L2 of its own: with block = workgroup number the group's pixels were fetched from
     // HBM eight times (851 MB per 4096^2 image against 75 MB of algorithmic bytes).  So XCD x takes the x-th eighth of the
@@ -1486,6 +1490,7 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
     // CompressETC1PunchthroughBlockInternal (ETC.cpp:2885-3082): three paint colours + "transparent" per half block
     auto clusterFit = [&](const bool punch)
     {
+        ETC_REFRESH_LANE();
         bool etcBest = false;
         int bFlip = 0, bD = 1;
         u32 bPacked0 = 0, bPacked1 = 0; // selectors | colour << 16
