@@ -145,7 +145,8 @@ extern "C"
         m->lastLast.assign(world, 0);
         std::vector<int> rcs(world, CVTTMI_OK);
         std::vector<std::thread> workers;
-        for (int r = 0; r < world; r++)
+        bool spawnFailed = false;
+        for (int r = 0; r < world && !spawnFailed; r++)
         {
             size_t lo = 0, hi = 0;
             cvttmi_shard_block_rows(rows, blocksPerRow, r, world, &lo, &hi);
@@ -153,6 +154,8 @@ extern "C"
             m->lastLast[r] = hi;
             if (hi <= lo)
                 continue;
+            try
+            {
             workers.push_back(std::thread([=, &rcs]() {
                 cvttmi_context *c = m->ctx[r];
                 uint8_t *o = out + lo * outBpb;
@@ -170,9 +173,19 @@ extern "C"
                 }
                 rcs[r] = rc;
             }));
+            }
+            catch (...) // no thread to be had: finish what was started, then report (a C interface must not throw)
+            {
+                spawnFailed = true;
+            }
         }
         for (size_t i = 0; i < workers.size(); i++)
             workers[i].join();
+        if (spawnFailed)
+        {
+            m->lastError = "could not start a worker thread";
+            return CVTTMI_E_HIP;
+        }
         for (int r = 0; r < world; r++)
             if (rcs[r] != CVTTMI_OK)
             {
