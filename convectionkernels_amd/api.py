@@ -210,6 +210,14 @@ def load_library():
     if not os.path.exists(path):
         raise CvttError("%s is missing: build it with `make -C convectionkernels_amd/csrc` "
                         "(or __graft_entry__.build())" % path)
+    # One HIP runtime per process.  The library links against the system libamdhip64; PyTorch-ROCm brings a runtime of its own.
+    # Loaded in the order library -> torch the process ends up with two, and the library's one finds no device any more
+    # (cvttmi_create = CVTTMI_E_NO_DEVICE; observed on the MI355X box, round 5).  With torch imported first the library binds
+    # to the runtime that is already there.  Callers without PyTorch (C / C++, numpy-only Python) are not affected.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(path)
     variant = "CVTTMI_LIB" in os.environ  # a developer's A/B library (tools/ab_*.sh) may predate the newest entry points
     for name in _EXPORTS:

@@ -295,3 +295,16 @@ def test_headline_kernel_needs_no_scratch():
     head = [v for name, v in k.items() if name.startswith("cvttmi_bc7_kernel<true, false, false>")]
     assert len(head) == 1, sorted(k)
     assert head[0]["scratch_bytes_per_lane"] == 0 and head[0]["vgpr"] <= 128 and head[0]["lds_bytes"] <= 10240, head[0]
+
+
+@pytest.mark.gpu
+def test_library_before_torch_in_one_process():
+    """api.load_library() first, `import torch` afterwards, then a context: one HIP runtime per process (round 5: in this order
+    the library's own runtime found no device any more; load_library now imports torch first when it is installed)"""
+    import subprocess
+    import sys
+    code = ("from convectionkernels_amd import api; api.load_library(); import torch; "
+            "assert torch.cuda.is_available(); c = api.Context(0); import numpy as np; "
+            "print(c.encode_bc1(np.zeros((8, 16, 4), np.uint8)).shape)")
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, timeout=600).decode()
+    assert "(8, 8)" in out, out
