@@ -19,7 +19,7 @@ from oracle import pyref
 
 pytestmark = pytest.mark.gpu
 
-N_SETS = 32
+N_SETS = int(os.environ.get("CVTT_FUZZ_SETS", "32"))  # the driver's run: 32; builder runs with more (profiles/r05/options_fuzz_gpu_160.log)
 GROUPS = 512  # 4 096 blocks per format and option set
 
 
