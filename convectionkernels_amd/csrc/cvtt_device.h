@@ -38,6 +38,9 @@ struct CvttDeviceTables
     uint8_t clusterCount[8];
     uint16_t clusterStart[8];
     int16_t clusterOffsets[632];
+    // the same list with what the base-colour pass of the cluster fit derives from the entry number: offset (bits 0-15) |
+    // table << 16 | (first entry of its table) << 19 -- one load instead of a seven-step comparison chain per lane and trip
+    uint32_t clusterEntry[640];
     // pixel bitmasks of subsets 1 and 2 of every three-subset partition (subset 1 of a
     // two-subset partition is partition2 itself)
     uint16_t subsetMask3[64][2];

@@ -105,19 +105,33 @@ __device__ __forceinline__ float uniF(float v) { return __int_as_float(__builtin
 // the value lane `lane` holds, `lane` the same in every lane: v_readlane_b32 (a scalar result) instead of a ds_bpermute_b32
 __device__ __forceinline__ int laneI(int v, int lane) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(lane)); }
 __device__ __forceinline__ float laneF(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(lane))); }
+// The value of lane (l ^ M), M a power of two: ds_swizzle_b32 in bit mode inside the 32-lane halves (no address register, a
+// third of the LDS-crossbar time of ds_bpermute_b32), ds_bpermute_b32 across them.  __shfl_xor computes its lane index with the
+// wave-size arithmetic of amd_warp_functions.h, whose common subexpression the compiler kept alive -- and spilled -- through the
+// whole kernel.
+template <int M>
+__device__ __forceinline__ int xorLaneI(int v)
+{
+    if (M < 32)
+        return __builtin_amdgcn_ds_swizzle(v, (M << 10) | 0x1f);
+    return __builtin_amdgcn_ds_bpermute((int)((threadIdx.x ^ 32u) << 2), v);
+}
+template <int M>
+__device__ __forceinline__ float xorLaneF(float v) { return __int_as_float(xorLaneI<M>(__float_as_int(v))); }
 
 // wave-wide argmin of (err, id); ties -> lowest id.  All lanes receive the winner.
 __device__ __forceinline__ void waveArgmin(float &err, int &id)
 {
-#pragma unroll
-    for (int step = 1; step < 64; step <<= 1)
-    {
-        const float oe = __shfl_xor(err, step);
-        const int oi = __shfl_xor(id, step);
-        const bool take = (oe < err) || (oe == err && oi < id);
-        err = take ? oe : err;
-        id = take ? oi : id;
+#define ETC_ARGMIN_STEP(M)                                          \
+    {                                                               \
+        const float oe = xorLaneF<M>(err);                          \
+        const int oi = xorLaneI<M>(id);                             \
+        const bool take = (oe < err) || (oe == err && oi < id);     \
+        err = take ? oe : err;                                      \
+        id = take ? oi : id;                                        \
     }
+    ETC_ARGMIN_STEP(1) ETC_ARGMIN_STEP(2) ETC_ARGMIN_STEP(4) ETC_ARGMIN_STEP(8) ETC_ARGMIN_STEP(16) ETC_ARGMIN_STEP(32)
+#undef ETC_ARGMIN_STEP
 #ifndef CVTT_ETC_NO_UNI_ARGMIN // (round 5: +1.6 % EncodeETC2RGBA, +2.3 % punch-through, same bytes; profiles/r05/ab_etc2.txt)
     // (every lane holds the winner: as scalars, what is derived from it is scalar arithmetic)
     err = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(err)));
@@ -563,12 +577,9 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
             }
         }
         u32 key = bestKey;
-#pragma unroll
-        for (int step = 1; step < 64; step <<= 1)
-        {
-            const u32 o = (u32)__shfl_xor((int)key, step);
-            key = o < key ? o : key;
-        }
+#define ETC_KEYMIN_STEP(M) { const u32 o = (u32)xorLaneI<M>((int)key); key = o < key ? o : key; }
+        ETC_KEYMIN_STEP(1) ETC_KEYMIN_STEP(2) ETC_KEYMIN_STEP(4) ETC_KEYMIN_STEP(8) ETC_KEYMIN_STEP(16) ETC_KEYMIN_STEP(32)
+#undef ETC_KEYMIN_STEP
         const int bestC = (int)(key & 511u);
         const int bestTable = (int)(((u32)bestC * 3277u) >> 16);
         bestBase = laneI(bestBase, bestC & 63);
@@ -588,12 +599,9 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
             const u64 placed = lane < 16 ? code << (3 * (15 - s)) : 0ull;
             bitsLo = (u32)placed;
             bitsHi = (u32)(placed >> 32);
-#pragma unroll
-            for (int step = 1; step < 16; step <<= 1)
-            {
-                bitsLo |= (u32)__shfl_xor((int)bitsLo, step);
-                bitsHi |= (u32)__shfl_xor((int)bitsHi, step);
-            }
+#define ETC_OR_STEP(M) { bitsLo |= (u32)xorLaneI<M>((int)bitsLo); bitsHi |= (u32)xorLaneI<M>((int)bitsHi); }
+            ETC_OR_STEP(1) ETC_OR_STEP(2) ETC_OR_STEP(4) ETC_OR_STEP(8)
+#undef ETC_OR_STEP
         }
         const u32 w0 = ((u32)bestBase & 0xffu) | ((u32)(((bestMultiplier << 4) | bestTable) & 0xff) << 8) | (((bitsHi >> 8) & 0xffu) << 16) | ((bitsHi & 0xffu) << 24);
         alphaW0 = (u32)__builtin_amdgcn_readfirstlane((int)w0);
@@ -640,12 +648,12 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
     const bool groupAll = PUNCH && (__ballot(transJ == 0xffffu) & 0xffull) == 0xffull;
     // maximum over the eight members (lanes that differ in their low three bits)
     auto groupMax = [](int v) {
-#pragma unroll
-        for (int step = 1; step <= 4; step <<= 1)
-        {
-            const int o = __shfl_xor(v, step);
-            v = o > v ? o : v;
-        }
+        int o = xorLaneI<1>(v);
+        v = o > v ? o : v;
+        o = xorLaneI<2>(v);
+        v = o > v ? o : v;
+        o = xorLaneI<4>(v);
+        v = o > v ? o : v;
         return v;
     };
 
@@ -805,15 +813,9 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
         // argmin over the 8 lanes of a channel, ties -> lowest combination
         float cErr = lane < 24 ? error : FLT_MAX;
         int cId = combo;
-#pragma unroll
-        for (int step = 1; step < 8; step <<= 1)
-        {
-            const float oe = __shfl_xor(cErr, step);
-            const int oi = __shfl_xor(cId, step);
-            const bool take = (oe < cErr) || (oe == cErr && oi < cId);
-            cErr = take ? oe : cErr;
-            cId = take ? oi : cId;
-        }
+#define ETC_CH_STEP(M) { const float oe = xorLaneF<M>(cErr); const int oi = xorLaneI<M>(cId); const bool take = (oe < cErr) || (oe == cErr && oi < cId); cErr = take ? oe : cErr; cId = take ? oi : cId; }
+        ETC_CH_STEP(1) ETC_CH_STEP(2) ETC_CH_STEP(4)
+#undef ETC_CH_STEP
         float chErr[3];
 #pragma unroll
         for (int c3 = 0; c3 < 3; c3++)
@@ -1523,28 +1525,20 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
                 // neighbouring lane's colour (the last lane's of the previous trip for lane 0), so the kept colours are filed
                 // straight into their lists at ballot-prefix positions -- no raw array, no second pass of LDS round trips.  A trip
                 // covers at most two tables (the shortest list has 57 entries): `A` = the table of lane 0, `B` = the next one.
-                int cs[8];
-#pragma unroll
-                for (int t = 0; t < 8; t++)
-                    cs[t] = __builtin_amdgcn_readfirstlane((int)T->clusterStart[t]);
+                // (table, offset and "first entry of its table" of entry f come as one word of a table made on the host: derived
+                // from f with a comparison chain they were 21 instructions per lane and trip)
                 int keptA[2] = {0, 0}, prevLast[2] = {-1, -1}, curT = 0; // wave-uniform
-                int offNext = T->clusterOffsets[lane < kMaxAttempts ? lane : 0];
+                u32 entryNext = T->clusterEntry[lane];
                 for (int base = 0; base < kMaxAttempts; base += 64)
                 {
                     const int f = base + lane;
                     const bool in = f < kMaxAttempts;
-                    const int off = offNext;
+                    const u32 entry = entryNext;
                     if (base + 64 < kMaxAttempts)
-                        offNext = T->clusterOffsets[f + 64 < kMaxAttempts ? f + 64 : 0];
-                    int table = 0, start = 0;
-#pragma unroll
-                    for (int t = 1; t < 8; t++)
-                    {
-                        const bool ge = f >= cs[t];
-                        table = ge ? t : table;
-                        start = ge ? cs[t] : start;
-                    }
-                    const int oi = f - start;
+                        entryNext = T->clusterEntry[f + 64];
+                    const int off = (int)(short)(entry & 0xffffu);
+                    const int table = (int)((entry >> 16) & 7u);
+                    const bool firstOfTable = (entry & (1u << 19)) != 0;
                     const int tLo = __builtin_amdgcn_readfirstlane(table);
                     if (tLo != curT)
                     {
@@ -1590,7 +1584,7 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
                         int prevCol = __shfl_up(packed, 1);
                         if (lane == 0)
                             prevCol = prevLast[sector];
-                        const bool keep = in && (oi == 0 || packed != prevCol);
+                        const bool keep = in && (firstOfTable || packed != prevCol);
                         const u64 balA = __ballot(keep && isA), balB = __ballot(keep && !isA);
                         const u64 below = (1ull << lane) - 1ull;
                         const int pos = isA ? keptA[sector] + __popcll(balA & below) : __popcll(balB & below);
@@ -1692,9 +1686,8 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
                     float mn = FLT_MAX;
                     for (int i = lane; i < numA0; i += 64)
                         mn = fminf(mn, S.u.a.err[0][i]);
-#pragma unroll
-                    for (int st = 1; st < 64; st <<= 1)
-                        mn = fminf(mn, __shfl_xor(mn, st));
+                    mn = fminf(mn, xorLaneF<1>(mn)); mn = fminf(mn, xorLaneF<2>(mn)); mn = fminf(mn, xorLaneF<4>(mn));
+                    mn = fminf(mn, xorLaneF<8>(mn)); mn = fminf(mn, xorLaneF<16>(mn)); mn = fminf(mn, xorLaneF<32>(mn));
                     const float l = (flipBest - mn) + flipBest * 2.4e-7f;
                     limit1 = (l < flipBest) ? l : flipBest; // (also when nothing of sector 0 is below the best: the difference is <= 0, every pass stops at once)
                     limit1Ready = true;
