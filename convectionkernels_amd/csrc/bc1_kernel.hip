@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64) void cvttmi_bc1_kernel(const uint8_t *__restric
 #pragma unroll
         for (int step = 1; step <= 4; step <<= 1)
         {
-            const int o = __shfl_xor(groupMaxElements, step);
+            const int o = xorLane(groupMaxElements, step);
             groupMaxElements = o > groupMaxElements ? o : groupMaxElements;
         }
         // pre-weighted pixels in descending key order; slots past numElements stay zero

@@ -240,8 +240,8 @@ __device__ __forceinline__ void quadArgminBroadcast(ShapeBest &b, int lane)
 #pragma unroll
     for (int step = 1; step <= 2; step <<= 1)
     {
-        const float oErr = __shfl_xor(err, step);
-        const int oWho = __shfl_xor(who, step);
+        const float oErr = xorLane(err, step);
+        const int oWho = xorLane(who, step);
         const bool take = (oErr < err) || (oErr == err && oWho < who);
         err = take ? oErr : err;
         who = take ? oWho : who;
@@ -597,14 +597,22 @@ __device__ __forceinline__ void groupArgminBroadcast(ShapeBest &b, int lane, int
 {
     int who = lane;
     float err = b.err;
-    for (int step = 1; step < width; step <<= 1)
-    {
-        const float oErr = __shfl_xor(err, step);
-        const int oWho = __shfl_xor(who, step);
-        const bool take = (oErr < err) || (oErr == err && oWho < who);
-        err = take ? oErr : err;
-        who = take ? oWho : who;
+    // (width is 4, 8 or 16, wave-uniform: the steps are spelled out so that each is a ds_swizzle with a literal pattern)
+#define CVTT_GROUP_STEP(STEP)                                             \
+    {                                                                     \
+        const float oErr = xorLane(err, STEP);                            \
+        const int oWho = xorLane(who, STEP);                              \
+        const bool take = (oErr < err) || (oErr == err && oWho < who);    \
+        err = take ? oErr : err;                                          \
+        who = take ? oWho : who;                                          \
     }
+    CVTT_GROUP_STEP(1)
+    CVTT_GROUP_STEP(2)
+    if (width > 4)
+        CVTT_GROUP_STEP(4)
+    if (width > 8)
+        CVTT_GROUP_STEP(8)
+#undef CVTT_GROUP_STEP
     b.err = err;
     b.ep0 = __shfl(b.ep0, who);
     b.ep1 = __shfl(b.ep1, who);
@@ -1483,10 +1491,10 @@ __device__ __forceinline__ void blockRawSumsQuad(const u32 (&pix)[16], int c, in
     {
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            s[i] += __shfl_xor(s[i], step);
+            s[i] += xorLane(s[i], step);
 #pragma unroll
         for (int i = 0; i < 10; i++)
-            p[i] += __shfl_xor(p[i], step);
+            p[i] += xorLane(p[i], step);
     }
 }
 
@@ -2423,7 +2431,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             float t = valid ? lbRotOf(r) : 0.0f;
 #pragma unroll
             for (int step = 1; step < 64; step <<= 1)
-                t += __shfl_xor(t, step);
+                t += xorLane(t, step);
             tot[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t)));
         }
 #pragma unroll
@@ -3056,7 +3064,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 int sharpCand = __popc(rem2);
 #pragma unroll
                 for (int step = 1; step < 64; step <<= 1)
-                    sharpCand += __shfl_xor(sharpCand, step);
+                    sharpCand += xorLane(sharpCand, step);
                 if (maySharp && sharpCand >= 2 * sharpNeed)
                 {
                     const u32 aliveMid = aliveBits;
@@ -3124,12 +3132,12 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             // near the end of the launch (workgroups are dispatched in order), where it would run on alone: the number
             // of partitions a wave may keep shrinks with the number of waves still to be dispatched after it.
             int cnt = __popc(aliveBits);
-            cnt += __shfl_xor(cnt, 1);
-            cnt += __shfl_xor(cnt, 2);
+            cnt += xorLane(cnt, 1);
+            cnt += xorLane(cnt, 2);
             int waveCnt = cnt;
 #pragma unroll
             for (int step = 4; step < 64; step <<= 1)
-                waveCnt += __shfl_xor(waveCnt, step);
+                waveCnt += xorLane(waveCnt, step);
             u32 allowed = (gridDim.x - blockIdx.x) / A.hardDiv;
             allowed = allowed > A.hardMin ? allowed : A.hardMin;
             // the blocks that make up most of the excess go; an eighth of the allowance each may stay
@@ -3149,10 +3157,10 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     m = (m | (m << 3)) & 0x1111111111111111ull;
                     m <<= c;
                     u32 lo = (u32)m, hi = (u32)(m >> 32);
-                    lo |= __shfl_xor(lo, 1);
-                    hi |= __shfl_xor(hi, 1);
-                    lo |= __shfl_xor(lo, 2);
-                    hi |= __shfl_xor(hi, 2);
+                    lo |= xorLane(lo, 1);
+                    hi |= xorLane(hi, 1);
+                    lo |= xorLane(lo, 2);
+                    hi |= xorLane(hi, 2);
                     aliveBits = 0;
                     if (c == 0)
                     {
@@ -3168,7 +3176,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #ifdef CVTT_BC7_PROFILE
         {
             int cntAlive = __popc(aliveBits);
-            for (int st = 1; st < 64; st <<= 1) cntAlive += __shfl_xor(cntAlive, st);
+            for (int st = 1; st < 64; st <<= 1) cntAlive += xorLane(cntAlive, st);
             PROF_STAGE(stageIter, 2, cntAlive)
             PROF_STAGE(stageIter, 6, 1)
         }
@@ -3220,10 +3228,10 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 m = (m | (m << 3)) & 0x1111111111111111ull;
                 m <<= c;
                 u32 lo = (u32)m, hi = (u32)(m >> 32);
-                lo |= __shfl_xor(lo, 1);
-                hi |= __shfl_xor(hi, 1);
-                lo |= __shfl_xor(lo, 2);
-                hi |= __shfl_xor(hi, 2);
+                lo |= xorLane(lo, 1);
+                hi |= xorLane(hi, 1);
+                lo |= xorLane(lo, 2);
+                hi |= xorLane(hi, 2);
                 const int kb = __popc(lo) + __popc(hi);
                 int allTotal = 0;
 #pragma unroll
@@ -3264,8 +3272,8 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #pragma unroll
                     for (int step = 1; step <= 2; step <<= 1)
                     {
-                        const float oLb = __shfl_xor(pickLb, step);
-                        const int oPick = __shfl_xor(pick, step);
+                        const float oLb = xorLane(pickLb, step);
+                        const int oPick = xorLane(pick, step);
                         const bool take = (oLb < pickLb) || (oLb == pickLb && oPick < pick);
                         pickLb = take ? oLb : pickLb;
                         pick = take ? oPick : pick;
@@ -3285,8 +3293,8 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #pragma unroll
                     for (int step = 4; step <= 16; step <<= 1)
                     {
-                        const float oLb = __shfl_xor(pickLb, step);
-                        const int oPick = __shfl_xor(pick, step);
+                        const float oLb = xorLane(pickLb, step);
+                        const int oPick = xorLane(pick, step);
                         const bool take = (oLb < pickLb) || (oLb == pickLb && oPick < pick);
                         pickLb = take ? oLb : pickLb;
                         pick = take ? oPick : pick;
@@ -3326,10 +3334,10 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             if (laneOffers)
             {
                 u32 lo = (u32)offerMask, hi = (u32)(offerMask >> 32);
-                lo |= __shfl_xor(lo, 1);
-                hi |= __shfl_xor(hi, 1);
-                lo |= __shfl_xor(lo, 2);
-                hi |= __shfl_xor(hi, 2);
+                lo |= xorLane(lo, 1);
+                hi |= xorLane(hi, 1);
+                lo |= xorLane(lo, 2);
+                hi |= xorLane(hi, 2);
                 offerMask = ((u64)hi << 32) | lo;
             }
             PROF_MARK(8)
@@ -3588,7 +3596,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #pragma unroll
                     for (int step = 1; step < 64; step <<= 1)
                     {
-                        const int o = __shfl_xor(maxCount, step);
+                        const int o = xorLane(maxCount, step);
                         maxCount = o > maxCount ? o : maxCount;
                     }
                     maxCount = __builtin_amdgcn_readfirstlane(maxCount);
@@ -3623,7 +3631,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #pragma unroll
                     for (int step = 1; step < 64; step <<= 1)
                     {
-                        const int o = __shfl_xor(maxCount, step);
+                        const int o = xorLane(maxCount, step);
                         maxCount = o > maxCount ? o : maxCount;
                     }
                     maxCount = __builtin_amdgcn_readfirstlane(maxCount);
@@ -3700,7 +3708,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #pragma unroll
                 for (int step = 1; step < 64; step <<= 1)
                 {
-                    const int o = __shfl_xor(maxCount, step);
+                    const int o = xorLane(maxCount, step);
                     maxCount = o > maxCount ? o : maxCount;
                 }
                 maxCount = __builtin_amdgcn_readfirstlane(maxCount);
@@ -3806,7 +3814,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     int filterCand = __popcll(surv);
 #pragma unroll
                     for (int step = 1; step < 64; step <<= 1)
-                        filterCand += __shfl_xor(filterCand, step);
+                        filterCand += xorLane(filterCand, step);
 #ifdef CVTT_NO_SHARP_FILTER
                     if (false)
 #else
@@ -3855,10 +3863,10 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 }
                 {
                     u32 lo = (u32)surv, hi = (u32)(surv >> 32);
-                    lo |= __shfl_xor(lo, 1);
-                    hi |= __shfl_xor(hi, 1);
-                    lo |= __shfl_xor(lo, 2);
-                    hi |= __shfl_xor(hi, 2);
+                    lo |= xorLane(lo, 1);
+                    hi |= xorLane(hi, 1);
+                    lo |= xorLane(lo, 2);
+                    hi |= xorLane(hi, 2);
                     surv = ((u64)hi << 32) | lo;
                 }
                 pend |= surv;
@@ -3933,7 +3941,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #pragma unroll
                 for (int step = 1; step < 64; step <<= 1)
                 {
-                    const int o = __shfl_xor(maxCount, step);
+                    const int o = xorLane(maxCount, step);
                     maxCount = o > maxCount ? o : maxCount;
                 }
                 maxCount = __builtin_amdgcn_readfirstlane(maxCount);
@@ -4074,10 +4082,10 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                     pos |= ((cat >> (4 * k)) & 0xfull) << (4 * px);
                 }
                 u32 lo = (u32)pos, hi = (u32)(pos >> 32);
-                lo |= __shfl_xor(lo, 1);
-                hi |= __shfl_xor(hi, 1);
-                lo |= __shfl_xor(lo, 2);
-                hi |= __shfl_xor(hi, 2);
+                lo |= xorLane(lo, 1);
+                hi |= xorLane(hi, 1);
+                lo |= xorLane(lo, 2);
+                hi |= xorLane(hi, 2);
                 packed.idxLo = lo;
                 packed.idxHi = hi;
             }
@@ -4302,10 +4310,10 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #pragma unroll
         for (int step = 1; step <= 2; step <<= 1)
         {
-            w0 |= __shfl_xor(w0, step);
-            w1 |= __shfl_xor(w1, step);
-            w2 |= __shfl_xor(w2, step);
-            w3 |= __shfl_xor(w3, step);
+            w0 |= xorLane(w0, step);
+            w1 |= xorLane(w1, step);
+            w2 |= xorLane(w2, step);
+            w3 |= xorLane(w3, step);
         }
         }
 

@@ -732,9 +732,9 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
 #pragma unroll
             for (int c3 = 0; c3 < 3; c3++)
             {
-                o3[c3] = __shfl(oc, c3);
-                h3[c3] = __shfl(hc, c3);
-                v3[c3] = __shfl(vc, c3);
+                o3[c3] = laneF(oc, c3);
+                h3[c3] = laneF(hc, c3);
+                v3[c3] = laneF(vc, c3);
             }
             auto fromFake = [](float (&rgb)[3], const float (&yuv)[3]) { // ConvertFromFakeBT709, ETC.cpp:2354-2364
                 const float yy = yuv[0] * 0.57735026466774571071f;
@@ -1581,7 +1581,8 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
                                 packed |= (int)q << (ch * 5);
                             }
                         }
-                        int prevCol = __shfl_up(packed, 1);
+                        // the neighbouring lane's colour: a DPP wave shift (no LDS round trip in the middle of the chain that decides `keep`)
+                        int prevCol = __builtin_amdgcn_update_dpp(packed, packed, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                         if (lane == 0)
                             prevCol = prevLast[sector];
                         const bool keep = in && (firstOfTable || packed != prevCol);
@@ -2026,7 +2027,7 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
                                     ci0[k] = 0x7fffffff;
                                 }
                             const u64 who = __ballot(have);
-                            c0 = __shfl(mine, __ffsll((long long)who) - 1);
+                            c0 = laneI(mine, __ffsll((long long)who) - 1);
                         }
                         // the sorted scan of sector 1 stops at the first entry with error >= maxError1,
                         // so the partner is the cheapest LEGAL entry provided it is below maxError1
@@ -2374,7 +2375,7 @@ __global__ __launch_bounds__(64, MODE == 2 ? 4 : CVTT_ETC2_WAVES) void cvttmi_et
             if (wErr < bestError)
             {
                 bestError = wErr;
-                const bool useH = __shfl((int)candH, wId & 63) != 0;
+                const bool useH = laneI((int)candH, wId & 63) != 0;
                 int table;
                 const int packed = candidateOf(wId, table);
                 const int modifier = thDist(table);
