@@ -119,24 +119,35 @@ __device__ __forceinline__ int xorLaneI(int v)
 template <int M>
 __device__ __forceinline__ float xorLaneF(float v) { return __int_as_float(xorLaneI<M>(__float_as_int(v))); }
 
-// wave-wide argmin of (err, id); ties -> lowest id.  All lanes receive the winner.
+// wave-wide argmin of (err, id); ties -> lowest id.  All lanes receive the winner (as scalars: what is derived from it is scalar
+// arithmetic).  The errors are sums of squares or FLT_MAX -- no NaN, no -0 -- so the lexicographic minimum of (err, id) is the
+// minimum of the errors (six ds_swizzle + v_min_f32) followed by the lowest id among the lanes that hold it: nearly always ONE
+// lane (a ballot, s_ff1, v_readlane), otherwise a second reduction over the ids.  (Round 5: the pair-at-a-time form -- two
+// swizzles, two compares, two selects per step -- was a third of the pair walk's instructions.)
 __device__ __forceinline__ void waveArgmin(float &err, int &id)
 {
-#define ETC_ARGMIN_STEP(M)                                          \
-    {                                                               \
-        const float oe = xorLaneF<M>(err);                          \
-        const int oi = xorLaneI<M>(id);                             \
-        const bool take = (oe < err) || (oe == err && oi < id);     \
-        err = take ? oe : err;                                      \
-        id = take ? oi : id;                                        \
+    float m = err;
+    m = minLoaded(m, xorLaneF<1>(m));
+    m = minLoaded(m, xorLaneF<2>(m));
+    m = minLoaded(m, xorLaneF<4>(m));
+    m = minLoaded(m, xorLaneF<8>(m));
+    m = minLoaded(m, xorLaneF<16>(m));
+    m = minLoaded(m, xorLaneF<32>(m));
+    const bool mine = err == m;
+    const u64 holders = __ballot(mine);
+    int best;
+    if (__popcll(holders) == 1)
+        best = __builtin_amdgcn_readlane(id, __ffsll((long long)holders) - 1);
+    else
+    {
+        int c = mine ? id : 0x7fffffff;
+#define ETC_IDMIN_STEP(M) { const int o = xorLaneI<M>(c); c = o < c ? o : c; }
+        ETC_IDMIN_STEP(1) ETC_IDMIN_STEP(2) ETC_IDMIN_STEP(4) ETC_IDMIN_STEP(8) ETC_IDMIN_STEP(16) ETC_IDMIN_STEP(32)
+#undef ETC_IDMIN_STEP
+        best = __builtin_amdgcn_readfirstlane(c);
     }
-    ETC_ARGMIN_STEP(1) ETC_ARGMIN_STEP(2) ETC_ARGMIN_STEP(4) ETC_ARGMIN_STEP(8) ETC_ARGMIN_STEP(16) ETC_ARGMIN_STEP(32)
-#undef ETC_ARGMIN_STEP
-#ifndef CVTT_ETC_NO_UNI_ARGMIN // (round 5: +1.6 % EncodeETC2RGBA, +2.3 % punch-through, same bytes; profiles/r05/ab_etc2.txt)
-    // (every lane holds the winner: as scalars, what is derived from it is scalar arithmetic)
-    err = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(err)));
-    id = __builtin_amdgcn_readfirstlane(id);
-#endif
+    err = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m)));
+    id = best;
 }
 
 // ConvertToFakeBT709, ETC.cpp:2343-2352
