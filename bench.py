@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Benchmark of the BC7 hot path (BASELINE.json), one JSON line on rank 0.
+"""Benchmark of the BC7 hot path (BASELINE.json).  Rank 0 prints ONE short JSON line (< 4 KB: the contract's fields, `roofline`,
+`cpu_baseline`, one entry per other BASELINE config) as the last line of stdout and writes every leg in full to bench_detail.json.
 
     python bench.py --gpus N --steps K --warmup W
     N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -95,6 +96,105 @@ def golden_rcp(h):
 def sha256(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# output: ONE short JSON line (the driver's parser reads the last stdout line; round 5's 21 KB line was not parsed) + a
+# side file with every leg in full
+# ---------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+DTYPE = "f32+u16"  # bit-exact emulation of the reference's SSE2 lanes (binary32 + 16-bit wrapping integers)
+
+
+def _r(x, digits=5):
+    """floats to `digits` significant figures (the side file keeps them in full)"""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    return x
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(full):
+    """The driver-facing line: the contract's fields, `roofline`, `cpu_baseline`, and one short entry per other BASELINE
+    config -- nothing else.  Always shorter than LINE_LIMIT (tests/test_bench_cli.py checks it on a maximal synthetic result)."""
+    out = _pick(full, ("metric", "value", "unit", "gpixel_per_s", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                       "scaling", "vs_baseline", "dtype", "data"))
+    cfg = full.get("config", {})
+    out["config"] = {k: cfg[k] for k in ("workload", "blocks", "blocks_per_rank", "exchange", "search") if k in cfg}
+    roof = full.get("roofline")
+    if roof:
+        r = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "valu_insts_per_block",
+                         "avg_waves_per_simd", "counters_from"))
+        hbm = roof.get("hbm", roof)
+        r["hbm"] = _pick(hbm, ("achieved", "peak", "unit", "frac", "traffic", "traffic_bytes_per_launch", "traffic_over_algorithmic"))
+        if "note" in roof and roof["bound"] == "hbm":
+            r["note"] = roof["note"][:120]
+        out["roofline"] = r
+    cpu = full.get("cpu_baseline")
+    if cpu:
+        c = _pick(cpu, ("value", "unit", "cores", "kind", "gpu_mismatching_blocks", "blocks_checked"))
+        c["sample"] = str(cpu.get("sample", ""))[:200]
+        if "one_thread" in cpu:
+            c["one_thread"] = _pick(cpu["one_thread"], ("value", "blocks"))
+        if "host" in cpu and "cpu_model" in cpu["host"]:
+            c["cpu_model"] = cpu["host"]["cpu_model"][:48]
+        out["cpu_baseline"] = c
+    for k in ("bit_exact_vs_cpu", "scale_base_mblocks_s", "rank0_search_mblocks_s", "dry_run", "value_note", "profile_note"):
+        if k in full:
+            out[k] = _r(full[k])
+    if "output_check" in full:
+        out["output_check"] = _pick(full["output_check"], ("matches_reference", "matches_single_process", "steps_checked", "every_step_identical"))
+    if "sustained" in full:
+        out["sustained_mblocks_s"] = _r(full["sustained"]["mblocks_s"])
+    if "exhaustive_search" in full:
+        out["exhaustive_identical_output"] = full["exhaustive_search"].get("identical_output")
+    if "configs" in full:
+        out["configs"] = {}
+        for name, e in full["configs"].items():
+            s = {"mblocks_s": _r(e["mblocks_s"], 4), "frac": _r(e["roofline"].get("frac"), 3), "bound": e["roofline"].get("bound")}
+            if "sha256_matches_reference" in e:
+                s["sha_ok"] = e["sha256_matches_reference"]
+            if "cpu_baseline" in e:
+                s["cpu_mblocks_s"] = _r(e["cpu_baseline"]["value"], 3)
+                s["cpu_mismatch"] = e["cpu_baseline"]["gpu_mismatching_blocks"]
+            out["configs"][name] = s
+    for fam in ("content_families", "bc6h_content_families"):
+        if fam in full:
+            out[fam] = {k: _r(v["mblocks_s"], 4) for k, v in full[fam].items()}
+            bad = sum(v.get("mismatches_vs_cpu", 0) for v in full[fam].values())
+            out[fam + "_mismatches"] = bad
+    if "detail_file" in full:
+        out["detail"] = full["detail_file"]
+    line = json.dumps(out, separators=(",", ":"))
+    # belt and braces: drop the optional parts, last first, rather than ever print a line the driver cannot read
+    for k in ("bc6h_content_families", "content_families", "configs", "output_check"):
+        if len(line) < LINE_LIMIT:
+            break
+        out.pop(k, None)
+        out.pop(k + "_mismatches", None)
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line) < LINE_LIMIT, len(line)
+    return line
+
+
+def emit(full):
+    """Write every leg in full to bench_detail.json (next to this script, and under gpurun_out/ when that exists), then print the
+    short line as the LAST line of stdout."""
+    names = [os.path.join(ROOT, "bench_detail.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        names.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    full["detail_file"] = "bench_detail.json"
+    for n in names:
+        try:
+            with open(n, "w") as f:
+                json.dump(full, f, indent=1)
+        except OSError as e:
+            sys.stderr.write("bench.py: cannot write %s: %r\n" % (n, e))
+    sys.stdout.flush()
+    print(compact_line(full), flush=True)
 
 # ---------------------------------------------------------------------------------------------------------------------
 # N > 1 (and --workload config5): one image, block-row sharded, gather to rank 0
@@ -302,7 +402,7 @@ def run_sharded(args):
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32+u16 (bit-exact emulation of the reference's SSE2 lanes)",
+            "dtype": DTYPE,
             "data": "synthetic",
             "config": {
                 "workload": "EncodeBC7, BC7EncodingPlan() + Options(), ONE %dx%d SplitMix64 random RGBA image%s, seed 5, %d blocks, block rows "
@@ -335,7 +435,7 @@ def run_sharded(args):
                 result["cpu_baseline"] = cpu_baseline("bc7", shard, got[lo:hi], opt_b, plan_b, golden_rcp(h), budget_one=2.0, budget_all=6.0)
                 result["cpu_baseline"]["host"] = host_info()
                 result["bit_exact_vs_cpu"] = result["cpu_baseline"]["gpu_mismatching_blocks"] == 0
-        print(json.dumps(result), flush=True)
+        emit(result)
     if n_ranks > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -609,14 +709,15 @@ def run_single(args):
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32+u16 (bit-exact emulation of the reference's SSE2 lanes)",
+        "dtype": DTYPE,
         "data": "synthetic",
         "config": {
             "workload": "EncodeBC7, BC7EncodingPlan() + Options(), %dx%d SplitMix64 random RGBA%s, seed 2, %d blocks resident in HBM "
                         "(BASELINE configs[1])" % (size, size, " alpha=255" if args.opaque else "", nblk),
             "flags": "0x%x" % opt.flags, "refineRoundsBC7": opt.refineRoundsBC7, "exchange": "none",
             "search": "exhaustive (every candidate evaluated, as the reference does)" if args.exhaustive else
-                      "exact branch-and-bound (candidates whose rigorous error lower bound exceeds the running best are skipped; output bit-identical)",
+                      "exact branch-and-bound (output bit-identical)",
+            "blocks": nblk,
         },
         "roofline": roofline_block("bc7", nblk, k_ms, "cvttmi_bc7_kernel"),
         "burst_value": mblocks,
@@ -704,7 +805,7 @@ def run_single(args):
         db = dropin_8block_leg()
         if db:
             result["dropin_8block"] = db
-    print(json.dumps(result), flush=True)
+    emit(result)
     return result
 
 

@@ -119,3 +119,35 @@ def test_committed_profiles_feed_the_rooflines_when_they_belong_to_this_library(
         assert c["valu_wave_insts_per_block"] > 100 and c["hbm_bytes_per_block"] > 64, (fmt, c)
     # BC6H keeps its search state on the chip: traffic ~ algorithmic (round 3: 687 x)
     assert fmtc["bc6hu"]["hbm_bytes_per_block"] < 1.2 * bench.ALGO_BYTES["bc6hu"]
+
+
+def test_the_printed_line_stays_short_enough_for_the_driver():
+    """Round 5's single line had grown to 21 KB and the driver's parser gave up on it (BENCH_r05.parsed = null).  The line
+    is now a summary (bench.compact_line) and every leg in full goes to bench_detail.json: on the largest result there is --
+    round 5's full N = 1 result, every leg present, plus padding in every free-text field -- it stays under 4 KB and still
+    carries the contract's fields, `roofline` and `cpu_baseline`."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05", "bench.json")))
+    full["config"]["workload"] = full["config"]["workload"] + " (padding)" * 5
+    full["cpu_baseline"]["sample"] = "x" * 2000
+    full["roofline"]["note"] = "y" * 2000
+    full["output_check"] = {"matches_reference": True, "steps_checked": 20, "every_step_identical": True, "sha256": "0" * 64}
+    line = bench.compact_line(full)
+    assert len(line) < 4096 and "\n" not in line
+    r = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in r, k
+    assert r["config"]["workload"].startswith("EncodeBC7")
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
+        assert k in r["roofline"], k
+    assert set(("achieved", "peak", "frac", "traffic_over_algorithmic")) <= set(r["roofline"]["hbm"])
+    for k in ("value", "unit", "cores", "kind", "sample", "gpu_mismatching_blocks", "blocks_checked"):
+        assert k in r["cpu_baseline"], k
+    assert r["cpu_baseline"]["one_thread"]["value"] > 0 and r["bit_exact_vs_cpu"] is True
+    assert set(r["configs"]) == set(full["configs"]) and all("sha_ok" in v for v in r["configs"].values())
+    # a result with fifty more configs drops the optional parts instead of growing past the limit
+    for i in range(50):
+        full["configs"]["extra_%d" % i] = full["configs"]["3_bc6hu_4096"]
+    line = bench.compact_line(full)
+    assert len(line) < 4096 and "roofline" in json.loads(line) and "cpu_baseline" in json.loads(line)
