@@ -8,6 +8,7 @@ gfx950 device is present every encode raises ``CvttError``.
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -193,12 +194,39 @@ _EXPORTS = (
     "cvttmi_default_bc7_fine_tuning", "cvttmi_bc7_plan_from_quality", "cvttmi_bc7_plan_from_fine_tuning",
     "cvttmi_host_alloc", "cvttmi_host_free", "cvttmi_host_register", "cvttmi_host_unregister",
     "cvttmi_shard_block_rows", "cvttmi_multi_create", "cvttmi_multi_destroy", "cvttmi_multi_last_error", "cvttmi_multi_num_devices",
-    "cvttmi_multi_context", "cvttmi_multi_last_shard", "cvttmi_multi_set_rcp_table", "cvttmi_multi_set_exhaustive", "cvttmi_multi_encode",
+    "cvttmi_multi_context", "cvttmi_multi_last_shard", "cvttmi_multi_set_rcp_table", "cvttmi_multi_set_exhaustive", "cvttmi_multi_encode", "cvttmi_multi_encode_device",
     "cvttmi_encode_bc7_multi", "cvttmi_encode_bc1_multi", "cvttmi_encode_bc6h_multi", "cvttmi_encode_etc2_rgba_multi",
     "cvttmi_dropin_set_devices",
 )
 
 _lib = None
+
+
+def _preload_hip_runtime():
+    want = os.environ.get("CVTTMI_PRELOAD_HIP", "")
+    if want == "0" or "torch" in sys.modules:
+        return None
+    cand = None
+    if want:
+        cand = want
+    else:
+        import importlib.util
+        try:
+            spec = importlib.util.find_spec("torch")  # locates the package without importing it
+        except (ImportError, ValueError):
+            spec = None
+        if spec is not None and spec.submodule_search_locations:
+            for d in spec.submodule_search_locations:
+                c = os.path.join(d, "lib", "libamdhip64.so")
+                if os.path.exists(c):
+                    cand = c
+                    break
+    if not cand:
+        return None
+    try:
+        return ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        return None
 
 
 def load_library():
@@ -210,14 +238,16 @@ def load_library():
     if not os.path.exists(path):
         raise CvttError("%s is missing: build it with `make -C convectionkernels_amd/csrc` "
                         "(or __graft_entry__.build())" % path)
-    # One HIP runtime per process.  The library links against the system libamdhip64; PyTorch-ROCm brings a runtime of its own.
-    # Loaded in the order library -> torch the process ends up with two, and the library's one finds no device any more
-    # (cvttmi_create = CVTTMI_E_NO_DEVICE; observed on the MI355X box, round 5).  With torch imported first the library binds
-    # to the runtime that is already there.  Callers without PyTorch (C / C++, numpy-only Python) are not affected.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # One HIP runtime per process.  The library links against libamdhip64 by soname; PyTorch-ROCm ships a libamdhip64 of its own.
+    # Loaded in the order library -> torch, the process ends up with two runtimes and the library's finds no device any more
+    # (cvttmi_create = CVTTMI_E_NO_DEVICE; observed on the MI355X box, round 5).  The dynamic loader binds a soname once per
+    # process, so it is enough that torch's runtime is mapped (RTLD_GLOBAL) BEFORE this library: then both use that one.
+    #   * torch already imported: its runtime is there, nothing to do;
+    #   * torch installed but not imported (numpy-only callers): preload just its libamdhip64.so -- no `import torch`, no
+    #     multi-second start-up, no GPU initialisation -- so that a later `import torch` meets the runtime it expects;
+    #   * no torch: the system runtime, as for any C / C++ caller (INTEGRATION.md "One HIP runtime per process").
+    # CVTTMI_PRELOAD_HIP=<path> names the runtime to preload explicitly; CVTTMI_PRELOAD_HIP=0 turns the preload off.
+    _preload_hip_runtime()
     lib = ctypes.CDLL(path)
     variant = "CVTTMI_LIB" in os.environ  # a developer's A/B library (tools/ab_*.sh) may predate the newest entry points
     for name in _EXPORTS:
@@ -294,6 +324,8 @@ def load_library():
         lib.cvttmi_multi_last_shard.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
         lib.cvttmi_multi_set_rcp_table.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.cvttmi_multi_set_exhaustive.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.cvttmi_multi_encode_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                                   ctypes.c_void_p, ctypes.c_void_p]
         lib.cvttmi_multi_encode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
                                             ctypes.c_void_p, ctypes.c_void_p]
         lib.cvttmi_encode_bc7_multi.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
@@ -796,6 +828,29 @@ class MultiContext:
         if rc != 0:
             raise CvttError("cvttmi_multi_encode(%s) failed (%d): %s" % (fmt, rc, self._lib.cvttmi_multi_last_error(self._h).decode()))
         return res
+
+
+    def encode_device(self, fmt, shards, out, blocks_per_row=0, options=None, plan=None):
+        """cvttmi_multi_encode_device: `shards[r]` = a device tensor on devices[r] holding shard r's PixelBlocks (None for an empty
+        shard), `out` = a device tensor on devices[0] for all the packed blocks.  The shard table is that of
+        shard_block_rows(rows, blocks_per_row, r, len(devices)); returns `out` when it is complete."""
+        code, in_bytes, out_bytes = self.FORMATS[fmt]
+        options = options if options is not None else Options()
+        if fmt == "bc7" and plan is None:
+            plan = BC7EncodingPlan()
+        n = out.numel() * out.element_size() // out_bytes
+        if len(shards) != len(self.devices):
+            raise CvttError("one shard (or None) per device")
+        ptrs = (ctypes.c_void_p * len(shards))(*[None if t is None else t.data_ptr() for t in shards])
+        import torch
+        for t in shards:
+            if t is not None:
+                torch.cuda.current_stream(t.device).synchronize()  # the library launches on streams of its own
+        rc = self._lib.cvttmi_multi_encode_device(self._h, code, out.data_ptr(), ptrs, n, blocks_per_row,
+                                                  ctypes.addressof(options), ctypes.addressof(plan) if plan is not None else None)
+        if rc != 0:
+            raise CvttError("cvttmi_multi_encode_device(%s) failed (%d): %s" % (fmt, rc, self._lib.cvttmi_multi_last_error(self._h).decode()))
+        return out
 
 
 def default_context(device=0):

@@ -124,8 +124,13 @@ __device__ __forceinline__ float xorLaneF(float v) { return __int_as_float(xorLa
 // minimum of the errors (six ds_swizzle + v_min_f32) followed by the lowest id among the lanes that hold it: nearly always ONE
 // lane (a ballot, s_ff1, v_readlane), otherwise a second reduction over the ids.  (Round 5: the pair-at-a-time form -- two
 // swizzles, two compares, two selects per step -- was a third of the pair walk's instructions.)
+// An error that IS NaN (infinite weights: 0 * inf) would leave the lanes with different minima -- minLoaded keeps its second
+// operand on an unordered compare -- and the id without a holder: such errors count as FLT_MAX, so the id returned is always
+// one of the candidates (one v_cmp_u_f32 and a scalar branch in the common path).
 __device__ __forceinline__ void waveArgmin(float &err, int &id)
 {
+    if (__ballot(err != err) != 0)
+        err = (err == err) ? err : FLT_MAX;
     float m = err;
     m = minLoaded(m, xorLaneF<1>(m));
     m = minLoaded(m, xorLaneF<2>(m));

@@ -307,9 +307,15 @@ int cvttmi_decode_bc6h(cvttmi_context *ctx, uint8_t *blocksF16, const uint8_t *b
  * its own device from its own host thread, and the packed blocks land in `out` at the range's offset.  Output bytes equal the
  * single-device call's.  `devices` may name a device more than once (a context each).  blocksPerRow = blocks in one block row of
  * the tiled image (ceil(ceil(w/4)/8)*8, cvttmi_tiled_block_count); 0 = no rows, shard by groups.
- * cvttmi_multi_*: a handle owning one context per list entry.  cvttmi_encode_*_multi: stateless forms that keep a handle per
- * device list for the life of the process.  Between processes (one per GPU) the packed output is gathered with RCCL send/recv
- * over xGMI instead: sharding.py, bench.py --gpus N. ---- */
+ * cvttmi_multi_*: a handle owning one context per list entry.  A handle runs ONE job at a time (a mutex; the setters take it
+ * too): concurrent callers of one handle -- including the C++ face's *Batch calls, which share the handle of the drop-in's device
+ * list -- are serialised; use a handle per worker thread to overlap jobs.
+ * cvttmi_encode_*_multi: stateless forms.  They keep one handle (contexts, staging) per distinct device list FOR THE LIFE OF THE
+ * PROCESS -- nothing is released before exit -- and report failures through cvttmi_multi_last_error(NULL): the text of the calling
+ * thread's most recent failed multi-device call.
+ * No call of this section lets a C++ exception out; allocation failures come back as CVTTMI_E_HIP.
+ * Between processes (one per GPU) the packed output is gathered with RCCL send/recv over xGMI instead: sharding.py,
+ * bench.py --gpus N. ---- */
 #define CVTTMI_FMT_BC7 0
 #define CVTTMI_FMT_BC1 1
 #define CVTTMI_FMT_BC6HU 2
@@ -329,6 +335,16 @@ int cvttmi_multi_set_exhaustive(cvttmi_multi *m, int exhaustive);
 /* format = CVTTMI_FMT_*; plan: BC7 only (NULL otherwise); host buffers (page-locked ones are transferred in place) */
 int cvttmi_multi_encode(cvttmi_multi *m, int format, uint8_t *out, const uint8_t *blocks, size_t numBlocks, size_t blocksPerRow,
                         const cvttmi_options *options, const cvttmi_bc7_plan *plan);
+/* Device-resident callers (the tiling kernel or an upload of the caller's own has put every shard where it is searched):
+ * d_shards[r] = HBM pointer ON devices[r] to the PixelBlocks of shard r, i.e. blocks [first_r, last_r) of the job as
+ * cvttmi_shard_block_rows(numBlocks / blocksPerRow, blocksPerRow, r, numDevices) cuts it (NULL allowed for an empty shard);
+ * d_out = numBlocks packed blocks ON devices[0].  Every device searches its shard on a stream of its own; shards on the root
+ * device write their slice of d_out directly, the others write a buffer on their own device that is then copied into the slice
+ * with hipMemcpyPeerAsync -- over xGMI, with peer access enabled where the pair allows it: the north-star's gather of the packed
+ * output for a single process.  Returns when d_out is complete.  (CVTTMI_MULTI_FORCE_STAGE=1 in the environment when the handle is
+ * created sends root-device shards through the staged route too: how a one-GPU box tests it.) */
+int cvttmi_multi_encode_device(cvttmi_multi *m, int format, void *d_out, const void *const *d_shards, size_t numBlocks, size_t blocksPerRow,
+                               const cvttmi_options *options, const cvttmi_bc7_plan *plan);
 int cvttmi_encode_bc7_multi(const int *devices, int numDevices, uint8_t *out, const uint8_t *blocks, size_t numBlocks, size_t blocksPerRow,
                             const cvttmi_options *options, const cvttmi_bc7_plan *plan);
 int cvttmi_encode_bc1_multi(const int *devices, int numDevices, uint8_t *out, const uint8_t *blocks, size_t numBlocks, size_t blocksPerRow,

@@ -3,6 +3,8 @@ include/cvtt_mi355x.h declares, and its PODs have the reference's layout.  No co
 import ctypes
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -308,3 +310,41 @@ def test_library_before_torch_in_one_process():
             "print(c.encode_bc1(np.zeros((8, 16, 4), np.uint8)).shape)")
     out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, timeout=600).decode()
     assert "(8, 8)" in out, out
+
+
+def test_loading_the_library_does_not_import_torch():
+    """api.load_library() preloads the HIP runtime PyTorch ships (when PyTorch is installed) instead of importing torch: a
+    numpy-only caller pays no multi-second import and no GPU initialisation, and a later `import torch` finds the one runtime
+    of the process."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from convectionkernels_amd import api\n"
+            "api.load_library()\n"
+            "assert 'torch' not in sys.modules, 'load_library imported torch'\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "n = len({l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l})\n"
+            "print('runtimes', n)\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout.split()[-1] == "1"  # exactly one libamdhip64 mapped
+
+
+@pytest.mark.gpu
+def test_numpy_only_process_then_torch_share_one_runtime():
+    """a process that loads the library WITHOUT torch, encodes, and only then imports torch: one HIP runtime, both work"""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from convectionkernels_amd import api\n"
+            "ctx = api.Context(0)\n"
+            "assert 'torch' not in sys.modules\n"
+            "b = np.arange(8 * 64, dtype=np.uint8).reshape(8, 16, 4)\n"
+            "first = ctx.encode_bc1(b)\n"
+            "import torch\n"
+            "assert torch.cuda.is_available()\n"
+            "t = torch.from_numpy(b).cuda()\n"
+            "again = ctx.encode_bc1(t).cpu().numpy()\n"
+            "assert (first == again).all() and int(t.sum().item()) == int(b.sum())\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "print('runtimes', len({l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l}))\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.stdout.split()[-1] == "1"

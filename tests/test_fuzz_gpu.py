@@ -153,3 +153,110 @@ def test_etc2_rgba_options_fuzz(gpu_ctx, cpu, ldr):
         exp = cpu.run("etc2rgba", ldr, _bytes(o))
         bad["#%d %s" % (i, fo.describe(o))] = int((got != exp).any(axis=1).sum())
     _report("ETC2 RGBA options fuzz vs %s" % cpu.kind, bad, t0)
+
+
+# ---- the (f)4 formats and the decoders: 10 fuzzed Options sets each (5 corners + 5 random), against the real reference on the box ----
+N_WIDE = int(os.environ.get("CVTT_FUZZ_WIDE_SETS", "10"))
+
+
+def _wide_sets():
+    """the corners that matter for these formats (zero / negative weights, refine rounds and seed points out of range, thresholds
+    outside [0, 1], FakeBT709 / Uniform / paranoid bits through the random flags) + seeded random sets"""
+    sets = fo.options_sets(32)
+    pick = [2, 5, 7, 8, 9] + list(range(10, 32)) + [0, 1, 3, 4, 6]
+    return [sets[i] for i in pick[:N_WIDE]]
+
+
+def _ref_or_skip(cpu):
+    if cpu.ref is None:
+        pytest.skip("oracle/_ref did not travel: the reference build is the checker of this test")
+    return cpu.ref
+
+
+@pytest.mark.parametrize("fmt", ["bc2", "bc3", "bc4u", "bc4s", "bc5u", "bc5s"])
+def test_s3tc_family_options_fuzz(gpu_ctx, cpu, ldr, fmt):
+    ref = _ref_or_skip(cpu)
+    gpu_ctx.set_rcp_table(cpu.rcp)
+    code = {"bc2": 2, "bc3": 3, "bc4u": 4, "bc4s": 5, "bc5u": 6, "bc5s": 7}[fmt]
+    enc = {"bc2": lambda b, o: gpu_ctx.encode_bc2(b, o), "bc3": lambda b, o: gpu_ctx.encode_bc3(b, o),
+           "bc4u": lambda b, o: gpu_ctx.encode_bc4(b, o, signed=False), "bc4s": lambda b, o: gpu_ctx.encode_bc4(b, o, signed=True),
+           "bc5u": lambda b, o: gpu_ctx.encode_bc5(b, o, signed=False), "bc5s": lambda b, o: gpu_ctx.encode_bc5(b, o, signed=True)}[fmt]
+    bad, t0 = {}, time.time()
+    for i, o in enumerate(_wide_sets()):
+        exp = ref.encode_s3tc(ldr, _bytes(o), code)
+        bad["#%d %s" % (i, fo.describe(o))] = int((enc(ldr, o) != exp).any(axis=1).sum())
+    _report("%s options fuzz vs reference" % fmt.upper(), bad, t0)
+
+
+@pytest.mark.parametrize("mode,name", [(0, "etc2"), (3, "etc1"), (4, "etc2_punchthrough"), (2, "etc2_alpha")])
+def test_etc_family_options_fuzz(gpu_ctx, cpu, ldr, mode, name):
+    """EncodeETC2 / EncodeETC1 / EncodeETC2PunchthroughAlpha / EncodeETC2Alpha; every second set allocates the scratch with OTHER
+    Options than it encodes with (the chroma axes belong to AllocETC2Data's, ETC.cpp:3117-3145)"""
+    ref = _ref_or_skip(cpu)
+    from convectionkernels_amd import api
+    enc = {0: lambda b, o, ao: gpu_ctx.encode_etc2(b, o, compression_data=ao), 3: lambda b, o, ao: gpu_ctx.encode_etc1(b, o),
+           4: lambda b, o, ao: gpu_ctx.encode_etc2_punchthrough_alpha(b, o, compression_data=ao),
+           2: lambda b, o, ao: gpu_ctx.encode_etc2_alpha(b, o)}[mode]
+    sets = _wide_sets()
+    bad, t0 = {}, time.time()
+    for i, o in enumerate(sets):
+        ao = sets[(i + 3) % len(sets)] if (i & 1) and mode in (0, 4) else None
+        exp = ref.encode_etc2(ldr, _bytes(o), mode, alloc_options=None if ao is None else _bytes(ao))
+        got = enc(ldr, o, ao)
+        bad["#%d %s%s" % (i, fo.describe(o), " alloc#%d" % ((i + 3) % len(sets)) if ao is not None else "")] = int((got != exp).any(axis=1).sum())
+    _report("%s options fuzz vs reference" % name, bad, t0)
+
+
+@pytest.mark.parametrize("signed", [False, True])
+def test_eac_r11_options_fuzz(gpu_ctx, cpu, signed):
+    """EncodeETC2Alpha11: 16 int16 per block -- in range, at the clamps and far outside (the reference clamps, ETC.cpp:2087-2114)"""
+    ref = _ref_or_skip(cpu)
+    rng = np.random.Generator(np.random.PCG64(99 + int(signed)))
+    n = GROUPS * 8
+    lo, hi = (-1023, 1023) if signed else (0, 2047)
+    blocks = rng.integers(lo, hi + 1, (n, 16)).astype(np.int16)
+    blocks[n // 4:n // 2] = (blocks[n // 4:n // 2] // 64) * 64                      # few distinct values
+    blocks[n // 2:n // 2 + n // 8] = rng.integers(-32768, 32768, (n // 8, 16))       # far outside the range
+    blocks[n // 2 + n // 8:n // 2 + n // 4] = rng.choice([lo, hi, lo + 1, hi - 1, 0], (n // 8, 16))
+    base = rng.integers(lo, hi + 1, (n // 4, 1))
+    blocks[3 * n // 4:] = np.clip(base + rng.integers(-6, 7, (n // 4, 16)), -32768, 32767)  # narrow ranges: small multipliers
+    bad, t0 = {}, time.time()
+    for i, o in enumerate(_wide_sets()):
+        exp = ref.encode_eac11(blocks, _bytes(o), signed=signed)
+        got = gpu_ctx.encode_etc2_alpha11(blocks, signed=signed, options=o)
+        bad["#%d %s" % (i, fo.describe(o))] = int((got != exp).any(axis=1).sum())
+    _report("EAC R11 %s options fuzz vs reference" % ("signed" if signed else "unsigned"), bad, t0)
+
+
+def test_decoders_on_random_bytes(gpu_ctx, cpu):
+    """DecodeBC7 / DecodeBC6HU / DecodeBC6HS take no Options: the fuzz is over the packed bytes -- uniform random blocks (every
+    mode, reserved modes and illegal headers included), each mode forced in turn, and what the encoders produce"""
+    ref = _ref_or_skip(cpu)
+    rng = np.random.Generator(np.random.PCG64(2718))
+    n = 8192
+    raw = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    bc7 = raw.copy()
+    for m in range(9):  # mode m = m zero bits then a one (m = 8: the reserved all-zero mode byte)
+        sl = slice(n // 2 + m * 256, n // 2 + (m + 1) * 256)
+        bc7[sl, 0] = ((bc7[sl, 0].astype(np.uint16) << (m + 1)) | (1 << m)).astype(np.uint8) if m < 8 else 0
+    got = gpu_ctx.decode_bc7(bc7)
+    exp = ref.decode_bc7(bc7)
+    assert int((got != exp).any(axis=(1, 2)).sum()) == 0
+    bc6 = raw.copy()
+    modes = [0, 1, 2, 6, 10, 14, 18, 22, 26, 30, 3, 7, 11, 15, 19, 23, 27, 31]  # the 14 real 5-bit / 2-bit headers and the reserved ones
+    for k, hdr in enumerate(modes):
+        sl = slice(n // 2 + k * 128, n // 2 + (k + 1) * 128)
+        bc6[sl, 0] = (bc6[sl, 0] & (0xFC if hdr < 2 else 0xE0)) | hdr
+    for signed in (False, True):
+        got = gpu_ctx.decode_bc6h(bc6, signed=signed)
+        exp = ref.decode_bc6h(bc6, signed=signed)
+        assert int((got != exp).any(axis=(1, 2)).sum()) == 0, "bc6h signed=%s" % signed
+    # round trip of real encoder output, fuzzed options
+    ldr = content.mixed_ldr_blocks(5150, 128)
+    hdr = content.mixed_hdr_blocks(5151, 128)
+    from convectionkernels_amd import api
+    for o in _wide_sets()[:4]:
+        packed = gpu_ctx.encode_bc7(ldr, o, api.BC7EncodingPlan())
+        assert (gpu_ctx.decode_bc7(packed) == ref.decode_bc7(packed)).all()
+        packed = gpu_ctx.encode_bc6h(hdr, o, signed=False)
+        assert (gpu_ctx.decode_bc6h(packed, signed=False) == ref.decode_bc6h(packed, signed=False)).all()

@@ -86,6 +86,72 @@ def test_multi_config5_hash(gpu_ctx):
     assert hashlib.sha256(out.tobytes()).hexdigest() == h["config5_bc7_16384_seed5"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_stage", [False, True])
+def test_multi_device_resident_shards_gathered_on_the_root_device(gpu_ctx, force_stage, monkeypatch):
+    """cvttmi_multi_encode_device with devices = {0,0,0}: every shard's PixelBlocks in HBM, the packed blocks gathered in one
+    buffer on the root device -- written in place by root-device shards, or (CVTTMI_MULTI_FORCE_STAGE=1: the route shards on
+    OTHER devices take) staged on the shard's device and copied with hipMemcpyPeerAsync.  Ragged rows, BC7 / BC6H / ETC2 RGBA /
+    BC1; bytes equal the single-context call's."""
+    import torch
+    if force_stage:
+        monkeypatch.setenv("CVTTMI_MULTI_FORCE_STAGE", "1")
+    else:
+        monkeypatch.delenv("CVTTMI_MULTI_FORCE_STAGE", raising=False)
+    m = api.MultiContext([0, 0, 0])
+    m.set_rcp_table(gpu_ctx.get_rcp_table())
+    ldr = content.mixed_ldr_blocks(93, 35)[:7 * 40]
+    hdr = content.mixed_hdr_blocks(94, 35)[:7 * 40]
+    opt, plan = api.Options(), api.BC7EncodingPlan()
+    dev = torch.device("cuda", 0)
+    for fmt, blocks, per_row, single in (("bc7", ldr, 40, lambda b: gpu_ctx.encode_bc7(b, opt, plan)),
+                                         ("bc6hu", hdr, 40, lambda b: gpu_ctx.encode_bc6h(b, opt, signed=False)),
+                                         ("etc2rgba", ldr, 12, lambda b: gpu_ctx.encode_etc2_rgba(b, opt)),
+                                         ("bc1", ldr, 8, lambda b: gpu_ctx.encode_bc1(b, opt))):
+        n = blocks.shape[0]
+        rows = n // per_row
+        table = [sharding.shard_block_rows(rows, per_row, r, 3) for r in range(3)]
+        shards = [torch.from_numpy(np.ascontiguousarray(blocks[lo:hi])).to(dev) if hi > lo else None for lo, hi in table]
+        out = torch.full((n, api.MultiContext.FORMATS[fmt][2]), 0xEE, dtype=torch.uint8, device=dev)
+        m.encode_device(fmt, shards, out, blocks_per_row=per_row, options=opt, plan=plan if fmt == "bc7" else None)
+        assert m.last_shards() == table
+        assert (out.cpu().numpy() == single(blocks)).all(), fmt
+    # a missing shard pointer is an error with a text, not a crash
+    with pytest.raises(api.CvttError, match="d_shards"):
+        m.encode_device("bc1", [None, None, None], torch.empty((n, 8), dtype=torch.uint8, device=dev), blocks_per_row=8, options=opt)
+
+
+@pytest.mark.gpu
+def test_multi_device_config5_hash_through_the_peer_copy_route(gpu_ctx, monkeypatch):
+    """BASELINE config 5 with device-resident shards, three contexts, staged + hipMemcpyPeerAsync gather: the reference's SHA-256"""
+    import torch
+    from convectionkernels_amd import synth
+    monkeypatch.setenv("CVTTMI_MULTI_FORCE_STAGE", "1")
+    h = json.load(open(os.path.join(GOLD, "config_hashes.json")))
+    m = api.MultiContext([0, 0, 0])
+    m.set_rcp_table(np.array(h["rcp_hex"], np.uint32).view(np.float32))
+    blocks = synth.tile_blocks(synth.image_rgba8(5, 16384, 16384))
+    dev = torch.device("cuda", 0)
+    table = [sharding.shard_block_rows(4096, 4096, r, 3) for r in range(3)]
+    shards = [torch.from_numpy(blocks[lo:hi]).to(dev) for lo, hi in table]
+    out = torch.empty((blocks.shape[0], 16), dtype=torch.uint8, device=dev)
+    m.encode_device("bc7", shards, out, blocks_per_row=4096)
+    assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == h["config5_bc7_16384_seed5"]
+
+
+def test_stateless_error_text_without_a_handle():
+    """the stateless forms have no handle: their failure text is the calling thread's (cvttmi_multi_last_error(NULL))"""
+    lib = api.load_library()
+    opt = api.Options()
+    devs = (ctypes.c_int * 1)(0)
+    out = np.zeros((8, 16), np.uint8)
+    blocks = np.zeros((8, 64), np.uint8)
+    rc = lib.cvttmi_encode_bc7_multi(devs, 1, out.ctypes.data, blocks.ctypes.data, 8, 8, ctypes.addressof(opt), None)
+    assert rc != 0
+    # without a GPU the handle cannot even be made (no text of its own); with one the text names the missing plan
+    assert isinstance(lib.cvttmi_multi_last_error(None), bytes)
+
+
 CXX_MULTI = r"""
 #include "cvtt/ConvectionKernels.h"
 #include "cvtt_mi355x.h"
