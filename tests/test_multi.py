@@ -106,7 +106,7 @@ def test_multi_device_resident_shards_gathered_on_the_root_device(gpu_ctx, force
     dev = torch.device("cuda", 0)
     for fmt, blocks, per_row, single in (("bc7", ldr, 40, lambda b: gpu_ctx.encode_bc7(b, opt, plan)),
                                          ("bc6hu", hdr, 40, lambda b: gpu_ctx.encode_bc6h(b, opt, signed=False)),
-                                         ("etc2rgba", ldr, 12, lambda b: gpu_ctx.encode_etc2_rgba(b, opt)),
+                                         ("etc2rgba", ldr, 20, lambda b: gpu_ctx.encode_etc2_rgba(b, opt)),  # 20: rows end inside a group
                                          ("bc1", ldr, 8, lambda b: gpu_ctx.encode_bc1(b, opt))):
         n = blocks.shape[0]
         rows = n // per_row
