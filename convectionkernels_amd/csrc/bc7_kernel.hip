@@ -2192,10 +2192,11 @@ __device__ __forceinline__ u32 everyFourth(u64 m, int c)
 // best and leaves its best candidate, packed, in A.hardCand; cvttmi_bc7_hard_commit_kernel picks the winner.
 // Every candidate is compared by (error, position in the reference's order), so the split cannot change the result.
 template <bool FAST, bool PT, bool HARD>
-// (the punch-through instantiation holds 22 KB of LDS: two waves per SIMD is all that fits, so it may use their registers)
-__global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVES_SLOW) void cvttmi_bc7_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
-                                                        const CvttBc7Args A, const CvttDeviceTables *__restrict__ T,
-                                                        const CvttBc7DevicePlan *__restrict__ dplan)
+// (the body of the kernel as a function of its work item: the encoder's launches run it once per workgroup, the HARD launch
+// loops a fixed-size grid over its items -- cvttmi_bc7_kernel below)
+__device__ __forceinline__ void bc7Body(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+                                        const CvttBc7Args &A, const CvttDeviceTables *__restrict__ T,
+                                        const CvttBc7DevicePlan *__restrict__ dplan, const u32 vBlock, const u32 vGrid)
 {
     // error lower bound of every partition of the current mode, per block: the upper 16 bits of the binary32 value
     // (truncated, i.e. rounded down -- a bound may always be smaller).  Half the bytes of a float table: with that and 64
@@ -2230,7 +2231,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     __shared__ float s_trialErr[PT ? 32 * 16 * kMaxPTRefine : 1];
     // ... and with more rounds than that (the reference only clamps refineRoundsBC7 from below, BC67.cpp:1044-1045) the
     // table of this wave lives in HBM; it is written and read inside the wave, between barriers
-    float *const trialHbm = (PT && A.ptTrial) ? A.ptTrial + (size_t)blockIdx.x * (size_t)(32 * 16) * (size_t)(A.refineRounds < 1 ? 1 : A.refineRounds) : nullptr;
+    float *const trialHbm = (PT && A.ptTrial) ? A.ptTrial + (size_t)vBlock * (size_t)(32 * 16) * (size_t)(A.refineRounds < 1 ? 1 : A.refineRounds) : nullptr;
     const cvttmi_bc7_plan *__restrict__ plan = &dplan->plan;
     // (not const: REFRESH_LANE() below hands the optimiser the same values as "new" ones at the start of every section of the
     // single-plane search, so that the LDS addresses and masks it derives from them are computed where they are used instead
@@ -2246,7 +2247,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
     int hardSeq = -1;
     if (HARD)
     {
-        hardIndex = blockIdx.x / kHardWaves;
+        hardIndex = vBlock / kHardWaves;
         const u32 count = *A.hardCount;
         if (hardIndex >= (count < A.hardCap ? count : A.hardCap))
             return;
@@ -2256,7 +2257,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         hardSeq = rec.seq;
         // this wavefront's share: every kHardWaves-th of the partitions that were alive when the block was handed over
         u64 m = ((u64)rec.aliveHi << 32) | rec.aliveLo;
-        const int q = (int)(blockIdx.x % kHardWaves);
+        const int q = (int)(vBlock % kHardWaves);
         for (int r = 0; m != 0; r++)
         {
             const u64 low = m & (0ull - m);
@@ -2267,11 +2268,11 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
         if (hardMine == 0)
         {
             if (lane == 0)
-                A.hardCand[blockIdx.x].err = FLT_MAX;
+                A.hardCand[vBlock].err = FLT_MAX;
             return;
         }
     }
-    const u32 blockIndex = (HARD ? (hardBlock & ~15u) : blockIdx.x * 16u) + (u32)(lane >> 2);
+    const u32 blockIndex = (HARD ? (hardBlock & ~15u) : vBlock * 16u) + (u32)(lane >> 2);
     const bool inRange = blockIndex < A.numBlocks;
     // The per-lane predicates of the search live as bits of one register (`lf`) rather than as one lane mask each: the
     // scalar registers a mask takes (two each, for the whole kernel) are what the register allocator runs out of first.
@@ -2645,7 +2646,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
             }
 
 #ifdef CVTT_BC7_DEBUG
-            if (blockIdx.x * 16u + (u32)(lane >> 2) == g_bc7DbgBlock && c == 0)
+            if (vBlock * 16u + (u32)(lane >> 2) == g_bc7DbgBlock && c == 0)
             {
                 const int cfgSlot = (int)g_bc7Dbg[0];
                 g_bc7Dbg[1 + cfgSlot] = (float)(rotation * 100 + cfg);
@@ -3138,7 +3139,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #pragma unroll
             for (int step = 4; step < 64; step <<= 1)
                 waveCnt += xorLane(waveCnt, step);
-            u32 allowed = (gridDim.x - blockIdx.x) / A.hardDiv;
+            u32 allowed = (vGrid - vBlock) / A.hardDiv;
             allowed = allowed > A.hardMin ? allowed : A.hardMin;
             // the blocks that make up most of the excess go; an eighth of the allowance each may stay
             if ((u32)waveCnt >= allowed && cnt >= 2 && (u32)cnt >= allowed / 8u)
@@ -4331,7 +4332,7 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
                 cand.err = improved ? work.err : FLT_MAX;
                 cand.seq = workSeq;
                 cand.pad[0] = cand.pad[1] = 0;
-                A.hardCand[blockIdx.x] = cand;
+                A.hardCand[vBlock] = cand;
             }
         }
         else if (valid && c == 0)
@@ -4363,6 +4364,35 @@ __global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT
 #undef allowRGBModes
 #undef allowMode7
 #undef blockHasNonMaxAlpha
+}
+
+template <bool FAST, bool PT, bool HARD>
+// (the punch-through instantiation holds 22 KB of LDS: two waves per SIMD is all that fits, so it may use their registers)
+__global__ __launch_bounds__(64, PT ? 3 : (FAST || HARD) ? CVTT_BC7_WAVES : CVTT_BC7_WAVES_SLOW) void cvttmi_bc7_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+                                                        const CvttBc7Args A, const CvttDeviceTables *__restrict__ T,
+                                                        const CvttBc7DevicePlan *__restrict__ dplan)
+{
+    if constexpr (!HARD)
+    {
+        // the counter of the NEXT encode's hand-over list (the two alternate, shim.cpp): nothing that read it is still running
+        // (launches that use the list are ordered, orderAfterPrevious), and nothing of this encode touches it -- no memset launch
+        if (!PT && A.hardCap != 0 && blockIdx.x == 0 && threadIdx.x == 0)
+            *A.hardCountNext = 0u;
+        bc7Body<FAST, PT, HARD>(blocks, out, A, T, dplan, blockIdx.x, gridDim.x);
+    }
+    else
+    {
+        // The second launch is a FIXED grid (cvttmi_launch_bc7: at most 4 096 waves) whose waves walk the items -- kHardWaves per
+        // recorded block -- in strides of the grid.  On content that hands nothing over (RGBA noise) it used to be 16 waves per
+        // SLOT, every one dispatched only to read the count and leave: 24 us of a 1.5 ms encode.
+        const u32 count = *A.hardCount;
+        const u32 total = (count < A.hardCap ? count : A.hardCap) * (u32)kHardWaves;
+        for (u32 item = blockIdx.x; item < total; item += gridDim.x)
+        {
+            bc7Body<FAST, PT, HARD>(blocks, out, A, T, dplan, item, total);
+            __syncthreads(); // the next item reuses the LDS of this one
+        }
+    }
 }
 
 // Third launch: the winner among the recorded best of a handed-over block and the candidates of its partition slices.
@@ -4413,18 +4443,13 @@ extern "C" hipError_t cvttmi_launch_bc7(const void *d_blocks, void *d_out, const
         if (fast) CVTT_LAUNCH(true, true, false, waves); else CVTT_LAUNCH(false, true, false, waves);
         return hipGetLastError();
     }
-    const bool split = args->hardCap != 0;
-    if (split)
-    {
-        const hipError_t e = hipMemsetAsync(args->hardCount, 0, sizeof(uint32_t), stream);
-        if (e != hipSuccess)
-            return e;
-    }
+    const bool split = args->hardCap != 0; // (the hand-over counter is zero: the previous encode's first launch cleared it, the context's creation the first two)
     if (fast) CVTT_LAUNCH(true, false, false, waves); else CVTT_LAUNCH(false, false, false, waves);
     if (split)
     {
-        // sized for every slot: the wavefronts past the recorded count leave at once
-        const uint32_t hardGrid = args->hardCap * (uint32_t)kHardWaves;
+        // a fixed grid that walks the items (kHardWaves per recorded block): one resident generation at most
+        const uint32_t hardItems = args->hardCap * (uint32_t)kHardWaves;
+        const uint32_t hardGrid = hardItems < 4096u ? hardItems : 4096u;
         if (fast) CVTT_LAUNCH(true, false, true, hardGrid); else CVTT_LAUNCH(false, false, true, hardGrid);
         hipLaunchKernelGGL(cvttmi_bc7_hard_commit_kernel, dim3((args->hardCap + 63u) / 64u), dim3(64), 0, stream, (uint8_t *)d_out, *args);
     }

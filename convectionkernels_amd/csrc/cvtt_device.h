@@ -102,7 +102,8 @@ struct CvttBc7Args
     uint32_t hardCap;   // record slots of this launch
     uint32_t hardMin;   // live partitions of a wave from which its blocks are handed over, at the end of the grid
     uint32_t hardDiv;   // ... and one more for every hardDiv waves that follow it
-    uint32_t *hardCount;
+    uint32_t *hardCount;     // slots claimed in THIS encode (zero when its first launch starts: see hardCountNext)
+    uint32_t *hardCountNext; // the counter of the next encode on this context: zeroed by this encode's first launch
     CvttBc7HardRec *hardRec;
     CvttBc7HardCand *hardCand; // [hardCap][kHardWaves]
     // BC7_RespectPunchThrough with more refine rounds than the LDS trial table holds (bc7_kernel.hip, kMaxPTRefine): the

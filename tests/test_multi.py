@@ -38,7 +38,8 @@ def test_multi_ragged_shards_equal_single_context(gpu_ctx, oracle_lib):
     """devices = {0,0,0}: three contexts, block rows that are no multiple of the world size and a row length that is no
     multiple of 8 blocks; every format; bytes equal the one-context call's, and BC7's equal the oracle's"""
     m = api.MultiContext([0, 0, 0])
-    rcp = gpu_ctx.get_rcp_table()
+    rcp = oracle_lib.probe_rcp()  # this box's table: what the contexts behind the stateless forms probe for themselves
+    gpu_ctx.set_rcp_table(rcp)    # (the session's context may carry the golden table of an earlier test)
     m.set_rcp_table(rcp)
     ldr = content.mixed_ldr_blocks(91, 7 * 5 * 3 // 3)  # 35 groups = 280 blocks
     ldr = ldr[:7 * 40]                                    # 7 block rows of 40 blocks
