@@ -7,41 +7,52 @@
 // in its canonical build (zero-initialised automatics, program-order rounding
 // scopes).
 //
-// Mapping: one LANE owns one block, a wave owns 8 reference groups (64 consecutive blocks).
-// The reference couples the 8 lanes of a group in two places -- the duplicate-round skip
-// (BC67.cpp:2853-2877, AllSet) and the mode-commit loop (2936-2984, AnySet) -- and both are
-// evaluated in the reference's exact candidate order, so every loop here is wave-uniform and
-// the two group predicates are 8-lane slices of a wave ballot.
-//   * pixels: 2CL integers packed in 32 VGPRs; their weighted linear values are re-derived per
-//     use (one v_cvt_f32_f16 + multiply) instead of living in 48 more registers;
-//   * slow indexing: the weighted linear colours of the 8 / 16 interpolants of a round sit in
-//     registers and every pixel scans them in order (strict '<', IndexSelectorHDR.h:125-139);
-//     the anchor pixel goes first because its index decides the endpoint inversion, and a
-//     round that turns out to be a duplicate never looks at the other pixels;
-//   * the "meta round" results of a partition (errors and quantised end points of both subsets) live in LDS, [entry][lane]
-//     so every access is conflict free; indexes are not kept (the winner's are selected again after the search) and nothing
-//     goes to memory between the load of the block and the store of its 16 bytes.
+// Mapping (round 6): a lane QUAD owns one block, sub-lane t of the quad runs the chain of seed point ("tweak") t -- its up to
+// three refine rounds -- so a wave owns 16 blocks = two reference groups, and the four chains a subset has per block advance
+// side by side instead of one after the other.  (Rounds 1-5: one lane per block, 64 blocks per wave, 236 registers and 18 KB
+// of LDS per wave = two waves per SIMD, VALU issue at 0.50 of its peak.)
+//   * the pixels of the 16 blocks live in LDS ([pixel][block]: the quad's four lanes read one address, the 16 blocks
+//     consecutive words): 2CL integers and their linear values (TwosCLHalfToFloat, BC67.cpp:2711), 5 KB; nothing of a block
+//     occupies registers, so a lane needs about a hundred and the wave 10 KB of LDS: four waves per SIMD;
+//   * the history of a partition's 2 x 12 "meta rounds" (quantised end points, errors) is in LDS too, [subset][round][block],
+//     each lane writing the rounds of its own chain: the commit loop (run redundantly by the four lanes of a quad, which keeps
+//     the block's running best in all four) and the legality pass read it from there;
+//   * the reference couples the 8 lanes of a group in two places -- the duplicate-round skip (BC67.cpp:2853-2877, AllSet) and the
+//     mode-commit loop (2936-2984, AnySet); both are 32-lane slices of a wave ballot (8 blocks x 4 identical sub-lanes).
+//   * THE DUPLICATE TEST AND THE PARALLEL CHAINS.  Round (t, r) is dropped when in all eight blocks of the group its quantised end
+//     points repeat those of an EARLIER meta round (t' < t with any r', or t' = t with r' < r), and a dropped round leaves the
+//     refiner of (t, r + 1) empty.  With the four chains in lock-step over r, the rounds (t' < t, r' <= r) and (t, r' < r) are
+//     known when round (t, r) has quantised its end points (the neighbours' words come over DPP quad_perm): a group-wide match
+//     among those is a drop, decided where the reference decides it.  What is not known yet are the rounds (t' < t, r' > r).  They
+//     are compared after the last pass; a group-wide match that only they produce (the first such round in the reference's
+//     order is certain: everything before it is final) is recorded as a forced drop and the subset's three passes run again --
+//     which content does about never (0 of 1.5 M partition searches of the noise image, 2e-4 of them on smooth ramps:
+//     profiles/r06/bc6h_rerun_stats.txt).  The state this converges to is the reference's: by induction over the meta-round
+//     order every round's end points follow from its chain's earlier rounds and their validity, every validity from the end
+//     points of the earlier rounds.
+//   * slow indexing: the weighted linear colours of the 8 / 16 interpolants of a round sit in registers and every pixel scans
+//     them in order (strict '<', IndexSelectorHDR.h:125-139); the anchor pixel goes first because its index decides the
+//     endpoint inversion; indexes are not kept (the winner's are selected again, once, after the search).
 //
-// What is NOT searched ("Round 3"): nine of the ten two-subset modes delta-code three of their four end
-// points, the reference's commit loop skips a (round, round, mode) triple whose deltas do not fit with a `continue` that
-// changes no state (BC67.cpp:2954-2955), and whether a triple fits depends on the rounds' quantised end points alone --
-// known before a round looks at a pixel.  So
+// What is NOT searched: nine of the ten two-subset modes delta-code three of their four end points, the
+// reference's commit loop skips a (round, round, mode) triple whose deltas do not fit with a `continue` that changes no state
+// (BC67.cpp:2954-2955), and whether a triple fits depends on the rounds' quantised end points alone -- known before a round
+// looks at a pixel.  So
 //   * a round whose end points fit no mode in any lane of the wave runs without errors (`needError`), and not at all in the
-//     last refine pass; a partition without a usable subset-0 round skips subset 1 and the commit loop (`usable0`);
+//     last refine pass; a partition without a usable subset-0 round skips subset 1 and the commit loop (`usable0`) -- with 16
+//     blocks per wave that is decided for a quarter of the blocks it used to be decided for;
 //   * precisions of 8 bits and more are searched lazily (`lazy`): chains of both subsets without errors, then the exact set of
-//     round pairs some lane could commit, then a replay of just those rounds with errors (a separate block of code);
-// On content without structure that is two thirds of the reference's work; the output is bit-identical because every
-// skipped piece is one the reference computes and then cannot use.
+//     round pairs some block could commit -- per block for the single-mode precisions, per GROUP for the three-mode ones,
+//     whose mode loop couples the group -- then a replay of just those rounds with errors, each by the lane whose chain it is.
+// The output is bit-identical because every skipped piece is one the reference computes and then cannot use.
 #include "cvtt_kernel_common.h"
 #include <hip/hip_fp16.h>
 #include <type_traits>
 
-// Developer-only phase profile (-DCVTT_BC6H_PROFILE): wave cycles per phase, summed over waves.
+// Developer-only counters (-DCVTT_BC6H_PROFILE): [0] partition searches (per wave), [1] subset passes run again after a late
+// duplicate, [2] lazy partitions, [3] lazy partitions with a replay, [4] replayed round slots, [5] eager partitions
 #ifdef CVTT_BC6H_PROFILE
 __device__ unsigned long long g_bc6hProf[16];
-#define PROF_DECL unsigned long long profT = __builtin_readcyclecounter(); unsigned long long profAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define PROF_MARK(slot) { const unsigned long long now = __builtin_readcyclecounter(); profAcc[slot] += now - profT; profT = now; }
-#define PROF_FLUSH if (threadIdx.x == 0) { for (int i = 0; i < 8; i++) atomicAdd(&g_bc6hProf[i], profAcc[i]); }
 #define PROF_COUNT(slot, n) { if (threadIdx.x == 0) atomicAdd(&g_bc6hProf[slot], (unsigned long long)(n)); }
 extern "C" int cvttmi_bc6h_prof_read(unsigned long long *out)
 {
@@ -51,31 +62,38 @@ extern "C" int cvttmi_bc6h_prof_read(unsigned long long *out)
     return 0;
 }
 #else
-#define PROF_DECL
-#define PROF_MARK(slot)
-#define PROF_FLUSH
 #define PROF_COUNT(slot, n) {}
+#endif
+// Developer-only trace (-DCVTT_BC6H_TRACE=<block index>): the round history of that block at 6 bits, per partition:
+// roundValid0, roundValid1, then [subset][round]{word a, word b, error bits} (tools/bc6h_trace.py compares it with the oracle's)
+#ifdef CVTT_BC6H_TRACE
+__device__ unsigned g_bc6hTrace[32 * 74];
+__device__ unsigned long long g_bc6hTrace2[16];
+extern "C" int cvttmi_bc6h_trace2_read(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bc6hTrace2), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+extern "C" int cvttmi_bc6h_trace_read(unsigned *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bc6hTrace), sizeof(unsigned) * 32 * 74) == hipSuccess ? 0 : -1;
+}
 #endif
 
 namespace
 {
-// ---- per-partition "meta round" state: everything stays on the chip (LDS, [entry][lane], conflict free) ----
-//   EPQ : the quantised end points of every round of BOTH subsets (duplicate-round test, legality pass, commit).
-//         two-subset precisions (<= 11 bits): two words per round -- r | g << 11 | b[9:0] << 22 per end point -- plus bit 10 of
-//         the two blue values in a register (24 bits per subset); single-subset precisions (<= 16 bits): three words per
-//         round (6 x int16).  2 x 12 x 2 = 48 entries (36 for the single-subset search)
-//   ERR : 12 rounds x 2 subsets, binary32                                                        = 24 entries
-// 72 entries x 256 B = 18 KB per wave: two waves per SIMD (8 per CU, 144 of 160 KB).  Indexes are not kept at all: the
-// winner's are selected again, once, from its end points after the search (same deterministic scan), and the PCA seeds are
-// computed per precision.  Round 3 kept the subset-0 history, the indexes of every round and the seeds in a 169 KB per wave
-// HBM work buffer and 24 errors + spills in 256 B of private scratch: 104 GB of HBM traffic per 4096^2 image (FETCH_SIZE /
-// WRITE_SIZE, profiles/r04) against 151 MB of algorithmic bytes.
-constexpr int kEpqBase = 0, kEpqDwords = 48, kErrBase = 48, kMetaDwords = 72;
-// Waves per SIMD the register allocator may assume.  The LDS footprint allows two; with 256 registers nothing spills and the
-// pixels' weighted linear values stay in registers.  Measured with round 3's code: 2 waves 7.17, 3 waves 7.25, 4 waves
-// (128 registers, 256 B of scratch) 7.70 Mblocks/s on noise -- the fourth wave bought 7 % and cost the HBM traffic above.
+// Waves per SIMD the register allocator may assume (128 registers; the LDS footprint of 10 KB per wave allows four).
 #ifndef CVTT_BC6H_WAVES
-#define CVTT_BC6H_WAVES 2
+#define CVTT_BC6H_WAVES 4
+#endif
+// Lowest two-subset precision that is searched lazily (chains without errors, then only the rounds of pairs that can be
+// committed are evaluated).  8: where a round fits its own delta with probability 2^-8 or less on content without structure.
+// 6 is never lazy: its mode stores no deltas.
+#ifndef CVTT_BC6H_LAZY_MIN
+#define CVTT_BC6H_LAZY_MIN 8
+#endif
+// a partition whose replay needs more than this many round slots switches the rest of the precision to the eager search
+#ifndef CVTT_BC6H_LAZY_SWITCH
+#define CVTT_BC6H_LAZY_SWITCH 2
 #endif
 
 // ceil(n / 31) for 0 <= n < 2^23: one v_mul_hi_u32.  2216757579 = (2^36 + 8213) / 31 (NOT ceil(2^36 / 31) = 2216757315):
@@ -208,76 +226,59 @@ __device__ __forceinline__ int reconstructChannel(int e0, int e1, int weight)
     return reconstructFrom<SIGNED, false>(e0 * 64 + 32, e1 - e0, weight);
 }
 
-struct FetchHDR
+// the 32-lane slice of a wave ballot that belongs to the lane's reference group (8 blocks x 4 sub-lanes)
+__device__ __forceinline__ u32 groupBits(u64 ballot, int lane) { return (u32)(ballot >> (lane & 32)); }
+// the value sub-lane Q of the lane's quad holds: v_mov_b32 with a DPP quad_perm (no LDS traffic, no address register)
+template <int Q>
+__device__ __forceinline__ u32 quadBcast(u32 v)
 {
-    const u32 (&pk01)[16];
-    const u32 (&pk2)[16];
-    const float (&w)[4];
-    template <int N>
-    __device__ __forceinline__ void get(int px, float (&v)[N]) const
-    {
-        const u32 a = fetchPixel(pk01[px]);
-        const u32 b = fetchPixel(pk2[px]);
-        v[0] = (float)(int)(short)(a & 0xffffu) * w[0];
-        v[1] = (float)(int)(short)(a >> 16) * w[1];
-        v[2] = (float)(int)(short)(b & 0xffffu) * w[2];
-    }
-};
-
-__device__ __forceinline__ u32 groupBits(u64 ballot, int lane) { return (u32)(ballot >> (lane & 56)) & 0xffu; }
+    return (u32)__builtin_amdgcn_mov_dpp((int)v, Q * 0x55, 0xf, 0xf, true);
+}
+// Does one of the LOWER sub-lanes of the quad hold the three words (wa, wb, wc) in (ma, mb, mc)?  Every DPP move is executed by
+// all lanes, unconditionally, before anything is compared: a cross-lane read inside a short-circuit `&&` runs with the lanes
+// that failed the first comparison switched off -- and a DPP read of a switched-off lane returns zero.
+__device__ __forceinline__ bool lowerSubLaneHolds(int tw, u32 wa, u32 wb, u32 wc, u32 ma, u32 mb, u32 mc)
+{
+    const u32 a0 = quadBcast<0>(ma), b0 = quadBcast<0>(mb), c0 = quadBcast<0>(mc);
+    const u32 a1 = quadBcast<1>(ma), b1 = quadBcast<1>(mb), c1 = quadBcast<1>(mc);
+    const u32 a2 = quadBcast<2>(ma), b2 = quadBcast<2>(mb), c2 = quadBcast<2>(mc);
+    const bool e0 = (a0 == wa) & (b0 == wb) & (c0 == wc);
+    const bool e1 = (a1 == wa) & (b1 == wb) & (c1 == wc);
+    const bool e2 = (a2 == wa) & (b2 == wb) & (c2 == wc);
+    return ((tw > 0) & e0) | ((tw > 1) & e1) | ((tw > 2) & e2);
+}
+// meta round m = 3 * tweak + refine pass: its tweak (m = 0 ... 11)
+__device__ __forceinline__ int tweakOf(int m) { return (m * 11) >> 5; }
 } // namespace
 
 template <bool SIGNED, bool FAST>
-// Developer variant for the mapping A/B VERDICT r3 asks for (make VARIANT=b6_gw EXTRA=-DCVTT_BC6H_GROUPWAVE=1; never the shipped
-// form): a wave is ONE reference group -- lane = candidate * 8 + block: eight partitions of each of the eight blocks are searched
-// side by side (partition 8 j + candidate in step j), the single-subset search runs redundantly in the eight candidate lanes.
-// The two group predicates stay the 8-lane ballot slices they are.  Per-lane partitions mean per-lane subset masks (every pixel
-// step is predicated per lane), and because the mode loop of the commit depends on the group mates' running best at that point of
-// the reference's candidate order (BC67.cpp:2936-2984), the eight candidates of a step still commit ONE AFTER THE OTHER, each
-// followed by a broadcast of the block's best to its eight lanes.  profiles/r04/ab_bc6h_mapping.txt has the measurement.
-#ifndef CVTT_BC6H_GROUPWAVE
-#define CVTT_BC6H_GROUPWAVE 0
-#endif
-// Lowest two-subset precision that is searched lazily (chains without errors, then only the rounds of pairs that can be
-// committed are evaluated).  8: where a round fits its own delta with probability 2^-8 or less on content without structure.
-// 7 (the 7-bit mode, 6-bit deltas: one round in nine fits its own delta) was built and measured in round 5 with the per-lane
-// replay below: 157.3 ms against 156.2 ms for config 3 (profiles/r05/ab_bc6h.txt) -- a lane that has one legal pair has many
-// (neighbouring refine rounds quantise to neighbouring end points), so the wave's busiest lane replays about ten rounds per
-// partition and the pair search + replay cost what the skipped errors saved.  6 is never lazy: its mode stores no deltas.
-#ifndef CVTT_BC6H_LAZY_MIN
-#define CVTT_BC6H_LAZY_MIN 8
-#endif
-// a partition whose per-lane replay needs more than this many rounds (both subsets, the wave's busiest lane each) switches the rest
-// of the precision to the eager search: content whose deltas do fit
-#ifndef CVTT_BC6H_LAZY_SWITCH
-#define CVTT_BC6H_LAZY_SWITCH 6
-#endif
-#ifndef CVTT_BC6H_WG_WAVES
-#define CVTT_BC6H_WG_WAVES 1 // waves per workgroup (independent of each other: each has its own 18 KB of the LDS block)
-#endif
-__global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC6H_WG_WAVES - 1) / CVTT_BC6H_WG_WAVES) void cvttmi_bc6h_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
-                                                         const CvttBc6hArgs A, const CvttDeviceTables *__restrict__ T)
+__global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ out,
+                                                                         const CvttBc6hArgs A, const CvttDeviceTables *__restrict__ T)
 {
-    __shared__ u32 metaAll[CVTT_BC6H_WG_WAVES][kMetaDwords][64];
-    u32 (&meta)[kMetaDwords][64] = metaAll[threadIdx.x >> 6];
-    const int lane = threadIdx.x & 63;
-    // error of round m of subset s of the current partition (indexed by wave-uniform loop counters)
-    auto errAt = [&](int m, int s) -> float & { return reinterpret_cast<float &>(meta[kErrBase + m * 2 + s][lane]); };
-    constexpr bool GW = CVTT_BC6H_GROUPWAVE != 0;
-    static_assert(!GW || CVTT_BC6H_WG_WAVES == 1, "the group-wave variant is one wave per workgroup");
-    const u32 blockIndex = GW ? blockIdx.x * 8u + (threadIdx.x & 7u) : blockIdx.x * (64u * CVTT_BC6H_WG_WAVES) + threadIdx.x;
+    // ---- everything a wave knows about its 16 blocks and the partition it is searching: 10 KB of LDS ----
+    __shared__ float4 s_px[16][16];        // [pixel][block]: the three linear values (TwosCLHalfToFloat) and, in .w, red | green << 16 (2CL)
+    __shared__ u32 s_pk2[16][16];          // [pixel][block]: blue (2CL)
+    __shared__ u32 s_epq[2][12][2][16];    // [subset][meta round][word][block]: the quantised end points of a round (layout: packEPQ)
+    __shared__ float s_err[2][12][16];     // [subset][meta round][block]
+    __shared__ uint8_t s_xb[2][16][4];     // [subset][block][tweak]: bits 2r, 2r+1 = the two spare bits of round (tweak, r) (two-subset form)
+    __shared__ uint8_t s_inv[2][16][4];    // [subset][block][tweak]: bit r = round (tweak, r) exchanged its end points (anchor index in the upper half)
+
+    const int lane = threadIdx.x;
+    const int blk = lane >> 2;
+    const int tw = lane & 3;
+    const u32 blockIndex = blockIdx.x * 16u + (u32)blk;
     const bool valid = blockIndex < A.numBlocks;
 
-    PROF_DECL
-    // ---- load + clamp to the "2CL" domain (BC67.cpp:2691-2715) ----
-    u32 pk01[16], pk2[16];
+    // ---- load + clamp to the "2CL" domain (BC67.cpp:2691-2715); sub-lane t takes pixels t, t + 4, t + 8, t + 12 ----
     {
         const uint2 *src = reinterpret_cast<const uint2 *>(blocks + (size_t)(valid ? blockIndex : 0u) * 128u);
 #pragma unroll
-        for (int px = 0; px < 16; px++)
+        for (int j = 0; j < 4; j++)
         {
+            const int px = 4 * j + tw;
             const uint2 raw = src[px];
             int v[3] = {(int)(short)(raw.x & 0xffffu), (int)(short)(raw.x >> 16), (int)(short)(raw.y & 0xffffu)};
+            float l[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ch++)
             {
@@ -292,75 +293,43 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
                     x = x < 0 ? 0 : x;
                 x = x > 31743 ? 31743 : x;
                 v[ch] = x;
+                l[ch] = twosCLHalfToFloat<SIGNED>(x);
             }
-            pk01[px] = ((u32)v[0] & 0xffffu) | ((u32)v[1] << 16);
-            pk2[px] = (u32)v[2] & 0xffffu;
+            s_px[px][blk] = make_float4(l[0], l[1], l[2], __uint_as_float(((u32)v[0] & 0xffffu) | ((u32)v[1] << 16)));
+            s_pk2[px][blk] = (u32)v[2] & 0xffffu;
         }
     }
-    const FetchHDR F = {pk01, pk2, A.w};
-    // Does any pixel value of the wave have a zero exponent field (the patterns TwosCLHalfToFloat halves)?  Almost never,
-    // and then the three fix-ups per pixel and round are skipped (unsigned format; wave-uniform).
-    bool pixelFixup = true;
-    if (!SIGNED)
-    {
-        bool z = false;
-#pragma unroll
-        for (int px = 0; px < 16; px++)
-            z = z | ((pk01[px] & 0x7c00u) == 0) | ((pk01[px] & 0x7c000000u) == 0) | ((pk2[px] & 0x7c00u) == 0);
-        pixelFixup = __ballot(z) != 0;
-    }
-    auto pixelToFloat = [&](int v16) -> float {
-        if (SIGNED)
-            return twosCLHalfToFloat<SIGNED>(v16);
-        float f = __half2float(__ushort_as_half((unsigned short)v16));
-        if (pixelFixup)
-        {
-            asm volatile("" ::: "memory"); // keep this a branch: as a select it costs what it is meant to save
-            f = (v16 & 0x7c00) ? f : f * 0.5f;
-        }
-        return f;
+    __syncthreads();
+    // pixel px of the lane's block: a = red | green << 16, b = blue (2CL integers), lf = the three linear values
+    auto pixLoad = [&](int px, u32 &a, u32 &b, float (&lf)[3]) {
+        const float4 v = s_px[px][blk];
+        lf[0] = v.x;
+        lf[1] = v.y;
+        lf[2] = v.z;
+        a = __float_as_uint(v.w);
+        b = s_pk2[px][blk];
     };
 
-    // slow indexing: the linear value of every pixel channel (TwosCLHalfToFloat of the pixel, BC67.cpp:2711), converted once:
-    // the error takes it as it is, the interpolant scan its product with the channel weight (floatPixelsLinearWeighted; a
-    // plain multiplication per use).  48 of the 256 registers two waves per SIMD leave a lane.
-    // (filled between the single-subset search, whose sixteen-entry interpolant table needs the registers, and the
-    // partitioned one; the single-subset search converts per use)
-    float lf[FAST ? 1 : 16][3];
-    // the three linear values of a pixel converted on the spot, with ONE wave-uniform branch around the rare halvings
-    auto pixelLinear = [&](u32 a, u32 b, float (&o)[3]) {
-        const int v[3] = {(int)(short)(a & 0xffffu), (int)(short)(a >> 16), (int)(short)(b & 0xffffu)};
-        if (SIGNED)
-        {
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++)
-                o[ch] = twosCLHalfToFloat<SIGNED>(v[ch]);
-            return;
-        }
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++)
-            o[ch] = __half2float(__ushort_as_half((unsigned short)v[ch]));
-        if (pixelFixup)
-        {
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++)
-                o[ch] = (v[ch] & 0x7c00) ? o[ch] : o[ch] * 0.5f;
-        }
-    };
+    const int numTweakRounds = A.seedPoints < 1 ? 1 : (A.seedPoints > 4 ? 4 : A.seedPoints);
+    const int numRefineRounds = A.refineRounds < 1 ? 1 : (A.refineRounds > 3 ? 3 : A.refineRounds);
+    const bool twActive = tw < numTweakRounds;
+    // the meta rounds the option values leave out (BC67.cpp:2819-2827): never valid, their end points stay the zeros of the
+    // canonical build's fresh automatics -- which later rounds are still compared with
+    u32 abortMask = 0;
+    for (int t = 0; t < 4; t++)
+        for (int r = 0; r < 3; r++)
+            if (t >= numTweakRounds || r >= numRefineRounds)
+                abortMask |= 1u << (3 * t + r);
+    abortMask = (u32)__builtin_amdgcn_readfirstlane((int)abortMask);
 
-    int numTweakRounds = A.seedPoints < 1 ? 1 : (A.seedPoints > 4 ? 4 : A.seedPoints);
-    int numRefineRounds = A.refineRounds < 1 ? 1 : (A.refineRounds > 3 ? 3 : A.refineRounds);
-
-    // running best (BC67.cpp:2721-2733)
+    // running best (BC67.cpp:2721-2733), the same in the four lanes of a quad
     float bestError = FLT_MAX;
     int bestMode = 0, bestPartition = 0;
     u32 bestEP[6] = {0, 0, 0, 0, 0, 0}; // [subset][3 dwords: (e0r|e0g<<16),(e0b|e1r<<16),(e1g|e1b<<16)]
-    u32 bestSwap = 0; // bit s: the winning round of subset s exchanged its end points (anchor index in the upper half)
+    u32 bestSwap = 0; // bit s: the winning round of subset s exchanged its end points
 
     // A mode of the current precision as one wave-uniform word (a scalar register): mode | transformed << 4 | the bits a
-    // delta loses per channel (16 - bPrec) << 8, 16, 24.  Read from the table once per precision: a table lookup inside a
-    // round is a per-lane memory load the round then waits for.
+    // delta loses per channel (16 - bPrec) << 8, 16, 24.
     auto modeWord = [&](int mode) -> u32 {
         const u32 w = (u32)mode | (T->bc6hModeInfo[mode][2] != 0 ? 16u : 0u) | ((16u - T->bc6hModeInfo[mode][4]) << 8) |
                       ((16u - T->bc6hModeInfo[mode][5]) << 16) | ((16u - T->bc6hModeInfo[mode][6]) << 24);
@@ -384,13 +353,98 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
         return ok;
     };
 
-    // PCA seeds of a subset and the sums of its pre-weighted pixels (the reference precomputes them for every partition,
-    // BC67.cpp:2738-2774; per precision here: 64 x 9 floats per block have no place on the chip, and the six passes cost
-    // 4 % of the kernel where a 147 KB per wave work buffer cost 14 GB of HBM traffic per 4096^2 image)
+    // PCA seeds of a subset and the sums of its pre-weighted pixels (EndpointSelector.h; the reference precomputes them for
+    // every partition, BC67.cpp:2738-2774; per precision here).  The member pixels in ascending order, from LDS.
     auto pcaSeeds = [&](u32 subsetMask, Unfinished &u, float (&sums)[3]) {
-        Moments<3> m;
-        pcaMomentsT<3>(F, subsetMask, m, sums);
-        pcaFinishT<3>(F, subsetMask, A.w, m, u);
+        float cen[3] = {0.0f, 0.0f, 0.0f};
+        float count = 0.0f;
+        for (u32 rem = subsetMask; rem != 0; rem &= rem - 1u)
+        {
+            const int px = __builtin_ctz(rem);
+            const float4 v = s_px[px][blk];
+            const u32 a = __float_as_uint(v.w), b = s_pk2[px][blk];
+            cen[0] = cen[0] + (float)(int)(short)(a & 0xffffu) * A.w[0];
+            cen[1] = cen[1] + (float)(int)(short)(a >> 16) * A.w[1];
+            cen[2] = cen[2] + (float)(int)(short)(b & 0xffffu) * A.w[2];
+            count = count + 1.0f;
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+            sums[ch] = cen[ch];
+        const float denom = safeDenom(count);
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+            cen[ch] = cen[ch] / denom;
+        float cov[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        for (u32 rem = subsetMask; rem != 0; rem &= rem - 1u)
+        {
+            const int px = __builtin_ctz(rem);
+            const float4 v = s_px[px][blk];
+            const u32 a = __float_as_uint(v.w), b = s_pk2[px][blk];
+            const float d0 = (float)(int)(short)(a & 0xffffu) * A.w[0] - cen[0];
+            const float d1 = (float)(int)(short)(a >> 16) * A.w[1] - cen[1];
+            const float d2 = (float)(int)(short)(b & 0xffffu) * A.w[2] - cen[2];
+            cov[0] = cov[0] + d0 * d0;
+            cov[1] = cov[1] + d1 * d0;
+            cov[2] = cov[2] + d1 * d1;
+            cov[3] = cov[3] + d2 * d0;
+            cov[4] = cov[4] + d2 * d1;
+            cov[5] = cov[5] + d2 * d2;
+        }
+        float approx[3] = {1.0f, 1.0f, 1.0f};
+        for (int it = 0; it < 8; it++)
+        {
+            float product[3];
+#pragma unroll
+            for (int row = 0; row < 3; row++)
+            {
+                float sum = 0.0f;
+#pragma unroll
+                for (int col = 0; col < 3; col++)
+                {
+                    const int hi = row > col ? row : col;
+                    const int lo = row > col ? col : row;
+                    sum = sum + approx[col] * cov[hi * (hi + 1) / 2 + lo];
+                }
+                product[row] = sum;
+            }
+            float largest = product[0];
+            largest = sseMax(largest, product[1]);
+            largest = sseMax(largest, product[2]);
+            largest = safeDenom(largest);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+                approx[ch] = product[ch] / largest;
+        }
+        float approxLen = approx[0] * approx[0];
+        approxLen = approxLen + approx[1] * approx[1];
+        approxLen = approxLen + approx[2] * approx[2];
+        approxLen = safeDenom(sqrtExact(approxLen));
+        float direction[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+            direction[ch] = approx[ch] / approxLen;
+        float minDist = FLT_MAX, maxDist = -FLT_MAX;
+        for (u32 rem = subsetMask; rem != 0; rem &= rem - 1u)
+        {
+            const int px = __builtin_ctz(rem);
+            const float4 v = s_px[px][blk];
+            const u32 a = __float_as_uint(v.w), b = s_pk2[px][blk];
+            float dist = 0.0f;
+            dist = dist + direction[0] * ((float)(int)(short)(a & 0xffffu) * A.w[0] - cen[0]);
+            dist = dist + direction[1] * ((float)(int)(short)(a >> 16) * A.w[1] - cen[1]);
+            dist = dist + direction[2] * ((float)(int)(short)(b & 0xffffu) * A.w[2] - cen[2]);
+            minDist = sseMin(minDist, dist);
+            maxDist = sseMax(maxDist, dist);
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+        {
+            const float mn = cen[ch] + direction[ch] * minDist;
+            const float mx = cen[ch] + direction[ch] * maxDist;
+            u.base[ch] = mn / A.w[ch];
+            u.offset[ch] = (mx - mn) / A.w[ch];
+        }
     };
 
     // the single-subset (4-bit indexes) and the partitioned (3-bit) search are two instantiations of the same body, so
@@ -404,9 +458,13 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
         const float maxValue = (float)(indexRange - 1);
         const int weightRcp = partitioned ? 4681 : 2185; // g_weightReciprocals[8], [16]
         const float rcpMaxIndex = T->rcpMaxIndex[indexBits];
+        const float tf0 = T->tweakFactors[indexBits - 2][tw][0];
+        const float tf1 = T->tweakFactors[indexBits - 2][tw][1];
 
-        // ---- the quantised end points of a round as kept in LDS (layout at the top of the file) ----
-        // wc: the two-subset form's two spare bits (bit 10 of the blue values), kept in a register per subset
+        // ---- the quantised end points of a round as kept in LDS ----
+        // two-subset precisions (<= 11 bits): two words per round -- r | g << 11 | b[9:0] << 22 per end point -- plus bit 10 of the
+        // two blue values in s_xb; single-subset precisions (<= 16 bits): three words per round (6 x int16), the third in the
+        // words of subset 1, which that search does not have
         auto packEPQ = [&](const int (&q)[2][3], u32 &wa, u32 &wb, u32 &wc) {
             if (partitioned)
             {
@@ -438,15 +496,184 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
                 e[1][0] = (int)(short)(wb >> 16); e[1][1] = (int)(short)(wc & 0xffffu); e[1][2] = (int)(short)(wc >> 16);
             }
         };
-        constexpr int epqStride = partitioned ? 2 : 3;
-        // LDS entry of word 0 of round `m` of subset `s`
-        auto epqEntry = [&](int s, int m) -> int { return kEpqBase + (s * 12 + m) * epqStride; };
-        // the stored words of a round (xb: the subset's spare-bit register)
-        auto loadEPQ = [&](int s, int m, u32 xb, int (&e)[2][3]) {
-            const int at = epqEntry(s, m);
-            const u32 wa = meta[at][lane], wb = meta[at + 1][lane];
-            const u32 wc = partitioned ? ((xb >> (2 * m)) & 3u) : meta[at + 2][lane];
+        // the stored words of round m of subset s of the lane's block (m may differ from lane to lane)
+        auto loadWords = [&](int s, int m, u32 &wa, u32 &wb, u32 &wc) {
+            wa = s_epq[s][m][0][blk];
+            wb = s_epq[s][m][1][blk];
+            if (partitioned)
+            {
+                const u32 xw = *reinterpret_cast<const u32 *>(&s_xb[s][blk][0]);
+                wc = (xw >> (2 * m + 2 * tweakOf(m))) & 3u; // byte t, bits 2r: 8 t + 2 r = 2 m + 2 t
+            }
+            else
+                wc = s_epq[1][m][0][blk];
+        };
+        auto loadEPQ = [&](int s, int m, int (&e)[2][3]) {
+            u32 wa, wb, wc;
+            loadWords(s, m, wa, wb, wc);
             unpackEPQ(wa, wb, wc, e);
+        };
+        auto wasSwapped = [&](int s, int m) -> bool {
+            const u32 iw = *reinterpret_cast<const u32 *>(&s_inv[s][blk][0]);
+            return ((iw >> (m + 5 * tweakOf(m))) & 1u) != 0; // byte t, bit r: 8 t + r = m + 5 t
+        };
+        auto errAt = [&](int m, int s) -> float & { return s_err[s][m][blk]; };
+
+        // ---- one round's index selection set up from its (un-swapped) quantised end points ----
+        struct Selector
+        {
+            float iw[indexRange][3]; // slow: weighted linear colour of every interpolant
+            float origin[3], axis[3]; // fast: projection axis
+            int recBase[3], recDiff[3];
+            bool interpFixup;
+        };
+        auto setupSelector = [&](const int (&unq)[2][3], const int (&fin)[2][3], Selector &S) {
+            S.interpFixup = true;
+            if (FAST)
+            {
+                // IndexSelector::Init on the colour-space endpoints + SelectIndexLDR
+                float epDW[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    S.origin[ch] = (float)fin[0][ch];
+                    epDW[ch] = ((float)fin[1][ch] - S.origin[ch]) * A.w[ch];
+                }
+                float lenSq = epDW[0] * epDW[0];
+                lenSq = lenSq + epDW[1] * epDW[1];
+                lenSq = lenSq + epDW[2] * epDW[2];
+                lenSq = safeDenom(lenSq);
+                const float mvdls = maxValue / lenSq;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                    S.axis[ch] = epDW[ch] * A.w[ch] * mvdls;
+            }
+            else
+            {
+                // An interpolant lies between the two finished end points (the interpolation, the unscaling and the conversion
+                // are monotone), so when no lane's end point has a zero exponent field no interpolant has one and the halving of
+                // TwosCLHalfToFloat is skipped (unsigned format; decided for the lanes that run this round)
+                if (!SIGNED)
+                {
+                    int lowest = fin[0][0] < fin[1][0] ? fin[0][0] : fin[1][0];
+#pragma unroll
+                    for (int ch = 1; ch < 3; ch++)
+                    {
+                        lowest = fin[0][ch] < lowest ? fin[0][ch] : lowest;
+                        lowest = fin[1][ch] < lowest ? fin[1][ch] : lowest;
+                    }
+                    S.interpFixup = __ballot(lowest < 0x400) != 0;
+#ifdef CVTT_BC6H_DBG_FIXUP
+                    S.interpFixup = true;
+#endif
+                }
+                if (S.interpFixup)
+                {
+#pragma unroll
+                    for (int i = 0; i < indexRange; i++)
+                    {
+                        const int weight = mad24(weightRcp, i, 256) >> 9;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                            S.iw[i][ch] = twosCLHalfToFloat<SIGNED>(reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight)) * A.w[ch];
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int i = 0; i < indexRange; i++)
+                    {
+                        const int weight = mad24(weightRcp, i, 256) >> 9;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                            S.iw[i][ch] = __half2float(__ushort_as_half((unsigned short)reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight))) * A.w[ch];
+                    }
+                }
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+            {
+                S.recBase[ch] = unq[0][ch] * 64 + 32;
+                S.recDiff[ch] = unq[1][ch] - unq[0][ch];
+            }
+        };
+        // raw (un-inverted) index of the pixel (a, b) with linear values lf; SelectIndexHDRSlow keeps the FIRST minimum
+        auto rawIndexOf = [&](const Selector &S, u32 a, u32 b, const float (&lf)[3]) -> int {
+            if (FAST)
+            {
+                const int c0 = (int)(short)(a & 0xffffu), c1 = (int)(short)(a >> 16), c2 = (int)(short)(b & 0xffffu);
+                float dist = ((float)c0 - S.origin[0]) * S.axis[0];
+                dist = dist + ((float)c1 - S.origin[1]) * S.axis[1];
+                dist = dist + ((float)c2 - S.origin[2]) * S.axis[2];
+                return (int)clampRound(dist, maxValue);
+            }
+            const float l0 = lf[0] * A.w[0];
+            const float l1 = lf[1] * A.w[1];
+            const float l2 = lf[2] * A.w[2];
+            float be = 0.0f;
+            int bi = 0;
+#pragma unroll
+            for (int i = 0; i < indexRange; i++)
+            {
+                float d = l0 - S.iw[i][0];
+                float e = d * d;
+                d = l1 - S.iw[i][1];
+                e = e + d * d;
+                d = l2 - S.iw[i][2];
+                e = e + d * d;
+                if (i == 0)
+                    be = e;
+                else
+                {
+                    // be = sseMin(be, e) with the index taken along on the same comparison (the errors are sums of squares: no
+                    // NaN, no -0, so equal values are equal bits; the minimum as v_min_f32, the comparison only for the index)
+                    const bool lt = e < be;
+                    bi = lt ? i : bi;
+                    be = __builtin_fminf(be, e);
+                }
+            }
+            return bi;
+        };
+        // error of the pixel reconstructed with raw index `raw` (BCCommon.h:45-79)
+        auto pixelError = [&](const Selector &S, int raw, u32 a, u32 b, const float (&lf)[3]) -> float {
+            const int weight = (int)((mulU24((u32)raw, (u32)weightRcp) + 256u) >> 9);
+            const int orig[3] = {(int)(short)(a & 0xffffu), (int)(short)(a >> 16), (int)(short)(b & 0xffffu)};
+            float err = 0.0f;
+            int rec[3];
+            float recF[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+            {
+                rec[ch] = reconstructFrom<SIGNED>(S.recBase[ch], S.recDiff[ch], weight);
+                if (!FAST)
+                    recF[ch] = SIGNED ? twosCLHalfToFloat<SIGNED>(rec[ch]) : __half2float(__ushort_as_half((unsigned short)rec[ch]));
+            }
+            if (!FAST && !SIGNED && S.interpFixup)
+            {
+                asm volatile("" ::: "memory"); // one wave-uniform branch around the three rare halvings
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                    recF[ch] = (rec[ch] & 0x7c00) ? recF[ch] : recF[ch] * 0.5f;
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+            {
+                float sq;
+                if (FAST)
+                {
+                    // SqDiffSInt16, ParallelMath.h:996-1010
+                    const int r16 = (int)(short)rec[ch];
+                    const u32 du = (u32)((r16 > orig[ch] ? r16 : orig[ch]) - (r16 > orig[ch] ? orig[ch] : r16)) & 0xffffu;
+                    sq = (float)(int)(du * du);
+                }
+                else
+                {
+                    const float d = recF[ch] - lf[ch];
+                    sq = d * d;
+                }
+                err = err + sq * A.wSq[ch]; // (Flags::Uniform: the weights are 1.0 and the product is exact, no second form needed)
+            }
+            return err;
         };
 
         for (int aPrec = 16; aPrec >= 0; aPrec--)
@@ -468,488 +695,438 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
                     numModesHere++;
                 }
             numModesHere = __builtin_amdgcn_readfirstlane(numModesHere);
-            // Precisions whose modes all delta-code their end points tightly (8 bits and more: a lane's round fits a mode
-            // with probability 2^-8 ... 2^-18 on content without structure) are searched LAZILY: first the chains of both
-            // subsets without any error (indexes only as far as the refiners need them), then the exact set of
-            // (subset-0 round, subset-1 round) pairs some lane could commit, and only the rounds of that set are evaluated
-            // again, with errors (the replay below: code of its own, so that the chains' registers and branches do not know
-            // about it).  The first partition of a precision that needs a replay switches the rest of the precision back to
-            // the eager search (content whose deltas do fit).
+            auto fitsAnyMode = [&](const int (&e)[2][3]) -> bool {
+                bool fits = ownDeltaFits(e, modeW0, aPrec);
+                if (numModesHere > 1)
+                    fits = fits | ownDeltaFits(e, modeW1, aPrec);
+                if (numModesHere > 2)
+                    fits = fits | ownDeltaFits(e, modeW2, aPrec);
+                return fits;
+            };
+            // Precisions whose modes all delta-code their end points tightly are searched LAZILY (file header).  The first
+            // partition of a precision whose replay is long switches the rest of the precision back to the eager search
+            // (content whose deltas do fit).
             bool eagerNow = !(partitioned && aPrec >= CVTT_BC6H_LAZY_MIN);
-            // A precision with ONE mode (7, 9, 10 bits) has no coupling between the lanes of a group in its commit loop: a lane
-            // commits a pair iff the pair beats its best and is legal, whatever its group mates do (the mode loop of
-            // BC67.cpp:2936-2984 has a single iteration).  So each lane needs the errors of the rounds of ITS legal pairs only,
-            // and the replay below evaluates a different round in every lane.  With three modes (8, 11 bits) a lane that is
-            // better but illegal keeps the mode loop of its group going, so every lane needs the errors of every round in the
-            // wave's set: there the replay stays wave-uniform.
-            const bool perLaneReplay = !GW && numModesHere == 1;
+            // A precision with ONE mode (7, 9, 10 bits) has no coupling between the blocks of a group in its commit loop: a block
+            // commits a pair iff the pair beats its best and is legal, whatever its group mates do.  So each block needs the errors
+            // of the rounds of ITS legal pairs only.  With three modes (8, 11 bits) a block that is better but illegal keeps the
+            // mode loop of its group going, so every block of the GROUP needs the errors of every round in the group's set.
+            const bool perBlockReplay = numModesHere == 1;
 
-            for (int pStep = 0; pStep < ((GW && partitioned) ? 4 : numPartitions); pStep++)
+            for (int p = 0; p < numPartitions; p++)
             {
-                const int p = (GW && partitioned) ? pStep * 8 + (lane >> 3) : pStep; // GW: a partition per candidate lane
-                const u32 partitionMask = partitioned ? T->partition2[p] : 0u;
+                const u32 partitionMask = partitioned ? (u32)__builtin_amdgcn_readfirstlane((int)T->partition2[p]) : 0u;
                 const bool lazy = !eagerNow;
-                if (partitioned && aPrec >= 8) { if (lazy) { PROF_COUNT(13, 1) } else { PROF_COUNT(11, 1) } }
-                u32 cand0 = 0;   // lazy: rounds of subset 0 whose own delta fits a mode in THIS lane
-                u32 invBits = 0; // bit subset * 12 + round = the round swapped its end points (anchor index in the upper half)
-                u32 xbits0 = 0, xbits1 = 0; // the spare bits of the packed end points (two per round)
-                u32 roundValid0 = 0xfffu, roundValid1 = 0xfffu; // per group (identical in its 8 lanes)
-                // Rounds of subset 0 whose quantised end points fit the delta coding of a mode of this precision in at
-                // least one lane of the wave.  A block can only be committed with such a round (the legality test of
-                // BC67.cpp:2597-2663 includes subset 0's own delta), the commit loop changes no state without a commit,
-                // and the legality is known before a round's pixels are looked at.  So a round nobody can use needs its
-                // indexes only as far as the next refine pass needs them (no error; nothing at all in the last pass), and
-                // a partition in which no round of subset 0 is usable needs neither subset 1 nor the commit loop.
-                u32 usable0 = 0;
+                __syncthreads(); // the previous partition's history has been read by everybody
+                PROF_COUNT(0, 1)
+                if (partitioned) { if (lazy) { PROF_COUNT(2, 1) } else { PROF_COUNT(5, 1) } }
+                // per group (identical in its 32 lanes): bit m = meta round m of the subset takes part in the commit
+                u32 roundValid0 = 0xfffu & ~abortMask, roundValid1 = 0xfffu & ~abortMask;
+                u32 cand0 = 0;   // lazy: bit r = round (tw, r) of subset 0 fits its own delta in a mode (this lane's chain)
+                // does a round of subset 0 fit the delta coding of a mode of this precision in some lane of the wave?  A block can
+                // only be committed with such a round; a partition without one needs neither subset 1 nor the commit loop.
+                bool usable0 = false;
 
-                PROF_MARK(6)
                 for (int subset = 0; subset < numSubsets; subset++)
                 {
                     const u32 subsetMask = partitioned ? (subset ? partitionMask : (~partitionMask & 0xffffu)) : 0xffffu;
-                    if (subset == 1 && usable0 == 0)
+                    if (subset == 1 && !usable0)
                         break;
-                    const int fixupIndex = GW ? ((subset == 0) ? 0 : (int)T->anchor2[p]) : __builtin_amdgcn_readfirstlane((subset == 0) ? 0 : (int)T->anchor2[p]);
+                    const int fixupIndex = __builtin_amdgcn_readfirstlane((subset == 0) ? 0 : (int)T->anchor2[p]);
                     // the anchor pixel of the subset (its index decides the swap of a round's end points, BC67.cpp:2525-2547)
-                    u32 fa = 0, fb = 0;
-                    float fixLw[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int px = 0; px < 16; px++)
-                        if (px == fixupIndex)
-                        {
-                            fa = pk01[px];
-                            fb = pk2[px];
-                        }
-                    if (!FAST)
-                    {
-                        float fl[3];
-                        pixelLinear(fa, fb, fl);
-                        fixLw[0] = fl[0] * A.w[0];
-                        fixLw[1] = fl[1] * A.w[1];
-                        fixLw[2] = fl[2] * A.w[2];
-                    }
+                    u32 fa, fb;
+                    float fixLf[3];
+                    pixLoad(fixupIndex, fa, fb, fixLf);
                     const int count = __popc(subsetMask);
                     const float wRcp = T->rcpTable[count];
                     const float wCount = (float)count;
 
                     Unfinished ufep;
                     // the refiner's sums of the pre-weighted member pixels (EndpointRefiner.h:78-92) do not depend on the indexes:
-                    // the PCA's first pass forms the same sums in the same order, so a round takes them from here instead of
-                    // adding them up pixel by pixel
+                    // the PCA's first pass forms the same sums in the same order
                     float vsSubset[3];
                     pcaSeeds(subsetMask, ufep, vsSubset);
 
-                    PROF_MARK(0)
-                    for (int tweak = 0; tweak < 4; tweak++)
+                    // meta rounds of this subset that are dropped although the rounds known at their time did not say so (see the
+                    // file header): per group, found after the last pass
+                    u32 forcedDrop = 0;
+                    for (;;)
                     {
                         // EndpointRefiner<3> refiners[2]: fresh (zero in the canonical build) per tweak
                         float tv[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, tt = 0.0f, ts = 0.0f;
                         int refCount = 0; // contributions of the previous round
-                        bool abortRemaining = false;
+                        u32 myQa[3] = {0, 0, 0}, myQb[3] = {0, 0, 0}, myQc[3] = {0, 0, 0}; // the end points of this chain's rounds
+                        u32 myXb = 0, myInv = 0;
+                        u32 rv = 0xfffu & ~abortMask;
+                        bool usableNow = false;
+                        u32 candNow = 0;
 
+#pragma unroll 1
                         for (int refinePass = 0; refinePass < 3; refinePass++)
                         {
-                            const int metaRound = tweak * 3 + refinePass;
-                            if (tweak >= numTweakRounds || refinePass >= numRefineRounds)
-                                abortRemaining = true;
-                            if (abortRemaining)
-                            {
-                                if (subset == 0) roundValid0 &= ~(1u << metaRound); else roundValid1 &= ~(1u << metaRound);
-                                // never written by the reference: the canonical build's zero-initialised automatics
-                                // (fresh for every partition, BC67.cpp:2797-2801), which later rounds compare against
-                                // (the spare bits of such a round stay zero in xbits0 / xbits1)
-                                meta[epqEntry(subset, metaRound)][lane] = 0;
-                                meta[epqEntry(subset, metaRound) + 1][lane] = 0;
-                                if (!partitioned)
-                                    meta[epqEntry(subset, metaRound) + 2][lane] = 0;
-                                continue;
-                            }
+                            const int metaRound = tw * 3 + refinePass;
+                            const bool act = twActive && refinePass < numRefineRounds;
+                            if (refinePass >= numRefineRounds)
+                                break; // (every lane's round is left out: the zero end points below are written once, before the loop)
 
-                            // ---- endpoints in colour space ----
-                            int epCS[2][3];
-                            if (refinePass == 0)
+                            u32 qa = 0, qb = 0, qc = 0;
+                            Selector S;
+                            int fixRaw = 0;
+                            bool invert = false;
+                            bool fits = false;
+                            if (act)
                             {
-                                const float tf0 = T->tweakFactors[indexBits - 2][tweak][0];
-                                const float tf1 = T->tweakFactors[indexBits - 2][tweak][1];
-#pragma unroll
-                                for (int ch = 0; ch < 3; ch++)
+                                // ---- endpoints in colour space ----
+                                int epCS[2][3];
+                                if (refinePass == 0)
                                 {
-                                    // FinishHDRSigned / Unsigned, UnfinishedEndpoints.h:39-75
-                                    const float lo = SIGNED ? -31743.0f : 0.0f;
-                                    const float f0 = sseMax(sseMin(ufep.base[ch] + ufep.offset[ch] * tf0, 31743.0f), lo);
-                                    const float f1 = sseMax(sseMin(ufep.base[ch] + ufep.offset[ch] * tf1, 31743.0f), lo);
-                                    epCS[0][ch] = (int)rintf(f0);
-                                    epCS[1][ch] = (int)rintf(f1);
-                                }
-                            }
-                            else
-                            {
-                                // EndpointRefiner::GetRefinedEndpointsHDR (EndpointRefiner.h:99-175) from the
-                                // previous round's sums (empty when that round was skipped as a duplicate)
-                                const float w = (refCount == 0) ? 1.0f : wCount;
-                                const float wr = (refCount == 0) ? T->rcpTable[1] : wRcp;
-                                float adenom = (tt * w - ts * ts) * wr;
-                                const bool z = (adenom == 0.0f);
-                                if (z) adenom = 1.0f;
 #pragma unroll
-                                for (int ch = 0; ch < 3; ch++)
-                                {
-                                    const float a = (tv[ch] - ts * vs[ch] * wr) / adenom;
-                                    const float b = (vs[ch] - a * ts) * wr;
-                                    float p1 = b, p2 = a + b;
-                                    if (z)
+                                    for (int ch = 0; ch < 3; ch++)
                                     {
-                                        p1 = vs[ch] * wr;
-                                        p2 = p1;
-                                    }
-                                    const float lo = SIGNED ? -31743.0f : 0.0f;
-                                    epCS[0][ch] = (int)rintf(sseMax(sseMin(p1 * A.rcpW[ch], 31743.0f), lo));
-                                    epCS[1][ch] = (int)rintf(sseMax(sseMin(p2 * A.rcpW[ch], 31743.0f), lo));
-                                }
-                            }
-                            // refiners[subset].Init(...)
-#pragma unroll
-                            for (int ch = 0; ch < 3; ch++)
-                                tv[ch] = vs[ch] = 0.0f;
-                            tt = ts = 0.0f;
-                            refCount = 0;
-
-                            // ---- QuantizeEndpoints{Signed,Unsigned}, BC67.cpp:2503-2595 ----
-                            int q[2][3], unq[2][3], fin[2][3];
-#pragma unroll
-                            for (int epi = 0; epi < 2; epi++)
-#pragma unroll
-                                for (int ch = 0; ch < 3; ch++)
-                                {
-                                    if (SIGNED)
-                                    {
-                                        q[epi][ch] = quantizeSigned(epCS[epi][ch], aPrec);
-                                        unq[epi][ch] = unquantizeSigned(q[epi][ch], aPrec, fin[epi][ch]);
-                                    }
-                                    else
-                                    {
-                                        q[epi][ch] = quantizeUnsigned(epCS[epi][ch] & 0xffff, aPrec);
-                                        unq[epi][ch] = unquantizeUnsigned(q[epi][ch], aPrec, fin[epi][ch]);
-                                    }
-                                }
-
-                            PROF_MARK(1)
-                            // ---- index selection, one pixel at a time: IndexSelectorHDR.h:100-144 ----
-                            const u32 sm = GW ? subsetMask : opaqueUniform(subsetMask);
-                            bool interpFixup = true; // may an interpolant of this round have a zero exponent field? (wave-uniform)
-                            float iw[indexRange][3]; // slow: weighted linear colour of every interpolant
-                            float origin[3], axis[3]; // fast: projection axis
-                            if (FAST)
-                            {
-                                // IndexSelector::Init on the colour-space endpoints + SelectIndexLDR
-                                float epDW[3];
-#pragma unroll
-                                for (int ch = 0; ch < 3; ch++)
-                                {
-                                    origin[ch] = (float)fin[0][ch];
-                                    epDW[ch] = ((float)fin[1][ch] - origin[ch]) * A.w[ch];
-                                }
-                                float lenSq = epDW[0] * epDW[0];
-                                lenSq = lenSq + epDW[1] * epDW[1];
-                                lenSq = lenSq + epDW[2] * epDW[2];
-                                lenSq = safeDenom(lenSq);
-                                const float mvdls = maxValue / lenSq;
-#pragma unroll
-                                for (int ch = 0; ch < 3; ch++)
-                                    axis[ch] = epDW[ch] * A.w[ch] * mvdls;
-                            }
-                            else
-                            {
-                                // An interpolant lies between the two finished end points (the interpolation, the
-                                // unscaling and the conversion are monotone), so when no lane's end point has a zero exponent
-                                // field no interpolant has one and the halving of TwosCLHalfToFloat is skipped (unsigned format)
-                                if (!SIGNED)
-                                {
-                                    int lowest = fin[0][0] < fin[1][0] ? fin[0][0] : fin[1][0];
-#pragma unroll
-                                    for (int ch = 1; ch < 3; ch++)
-                                    {
-                                        lowest = fin[0][ch] < lowest ? fin[0][ch] : lowest;
-                                        lowest = fin[1][ch] < lowest ? fin[1][ch] : lowest;
-                                    }
-                                    interpFixup = __ballot(lowest < 0x400) != 0;
-                                }
-                                if (interpFixup)
-                                {
-#pragma unroll
-                                    for (int i = 0; i < indexRange; i++)
-                                    {
-                                        const int weight = mad24(weightRcp, i, 256) >> 9;
-#pragma unroll
-                                        for (int ch = 0; ch < 3; ch++)
-                                            iw[i][ch] = twosCLHalfToFloat<SIGNED>(reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight)) * A.w[ch];
+                                        // FinishHDRSigned / Unsigned, UnfinishedEndpoints.h:39-75
+                                        const float lo = SIGNED ? -31743.0f : 0.0f;
+                                        const float f0 = sseMax(sseMin(ufep.base[ch] + ufep.offset[ch] * tf0, 31743.0f), lo);
+                                        const float f1 = sseMax(sseMin(ufep.base[ch] + ufep.offset[ch] * tf1, 31743.0f), lo);
+                                        epCS[0][ch] = (int)rintf(f0);
+                                        epCS[1][ch] = (int)rintf(f1);
                                     }
                                 }
                                 else
                                 {
+                                    // EndpointRefiner::GetRefinedEndpointsHDR (EndpointRefiner.h:99-175) from the previous round's
+                                    // sums (empty when that round was skipped as a duplicate)
+                                    const float w = (refCount == 0) ? 1.0f : wCount;
+                                    const float wr = (refCount == 0) ? T->rcpTable[1] : wRcp;
+                                    float adenom = (tt * w - ts * ts) * wr;
+                                    const bool z = (adenom == 0.0f);
+                                    if (z) adenom = 1.0f;
 #pragma unroll
-                                    for (int i = 0; i < indexRange; i++)
+                                    for (int ch = 0; ch < 3; ch++)
                                     {
-                                        const int weight = mad24(weightRcp, i, 256) >> 9;
-#pragma unroll
-                                        for (int ch = 0; ch < 3; ch++)
-                                            iw[i][ch] = __half2float(__ushort_as_half((unsigned short)reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight))) * A.w[ch];
-                                    }
-                                }
-                            }
-                            int recBase[3], recDiff[3];
-#pragma unroll
-                            for (int ch = 0; ch < 3; ch++)
-                            {
-                                recBase[ch] = unq[0][ch] * 64 + 32;
-                                recDiff[ch] = unq[1][ch] - unq[0][ch];
-                            }
-                            // raw (un-inverted) index of the pixel packed in (a, b); SelectIndexHDRSlow keeps the FIRST minimum
-                            // lwp: the pixel's weighted linear values (slow indexing only)
-                            auto rawIndexOf = [&](u32 a, u32 b, const float (&lwp)[3]) -> int {
-                                if (FAST)
-                                {
-                                    const int c0 = (int)(short)(a & 0xffffu), c1 = (int)(short)(a >> 16), c2 = (int)(short)(b & 0xffffu);
-                                    float dist = ((float)c0 - origin[0]) * axis[0];
-                                    dist = dist + ((float)c1 - origin[1]) * axis[1];
-                                    dist = dist + ((float)c2 - origin[2]) * axis[2];
-                                    return (int)clampRound(dist, maxValue);
-                                }
-                                const float l0 = lwp[0];
-                                const float l1 = lwp[1];
-                                const float l2 = lwp[2];
-                                float be = 0.0f;
-                                int bi = 0;
-#pragma unroll
-                                for (int i = 0; i < indexRange; i++)
-                                    {
-                                        float d = l0 - iw[i][0];
-                                        float e = d * d;
-                                        d = l1 - iw[i][1];
-                                        e = e + d * d;
-                                        d = l2 - iw[i][2];
-                                        e = e + d * d;
-                                        if (i == 0)
-                                            be = e;
-                                        else
+                                        const float a = (tv[ch] - ts * vs[ch] * wr) / adenom;
+                                        const float b = (vs[ch] - a * ts) * wr;
+                                        float p1 = b, p2 = a + b;
+                                        if (z)
                                         {
-                                            // be = sseMin(be, e) with the index taken along on the same comparison (the errors
-                                            // are sums of squares: no NaN, no -0, so equal values are equal bits)
-                                            // (the minimum as v_min_f32, the comparison only for the index: the select form made
-                                            // every step wait for the previous one's compare -> select, with a hazard nop between)
-                                            const bool lt = e < be;
-                                            bi = lt ? i : bi;
-                                            be = __builtin_fminf(be, e);
+                                            p1 = vs[ch] * wr;
+                                            p2 = p1;
                                         }
+                                        const float lo = SIGNED ? -31743.0f : 0.0f;
+                                        epCS[0][ch] = (int)rintf(sseMax(sseMin(p1 * A.rcpW[ch], 31743.0f), lo));
+                                        epCS[1][ch] = (int)rintf(sseMax(sseMin(p2 * A.rcpW[ch], 31743.0f), lo));
                                     }
-                                return bi;
-                            };
-
-                            const int fixRaw = rawIndexOf(fetchPixel(fa), fetchPixel(fb), fixLw);
-                            PROF_MARK(2)
-                            const bool invert = (indexRange / 2 - 1) < fixRaw;
-                            if (invert)
-                            {
+                                }
+                                // refiners[subset].Init(...)
 #pragma unroll
                                 for (int ch = 0; ch < 3; ch++)
+                                    tv[ch] = vs[ch] = 0.0f;
+                                tt = ts = 0.0f;
+                                refCount = 0;
+
+                                // ---- QuantizeEndpoints{Signed,Unsigned}, BC67.cpp:2503-2595 ----
+                                int q[2][3], unq[2][3], fin[2][3];
+#pragma unroll
+                                for (int epi = 0; epi < 2; epi++)
+#pragma unroll
+                                    for (int ch = 0; ch < 3; ch++)
+                                    {
+                                        if (SIGNED)
+                                        {
+                                            q[epi][ch] = quantizeSigned(epCS[epi][ch], aPrec);
+                                            unq[epi][ch] = unquantizeSigned(q[epi][ch], aPrec, fin[epi][ch]);
+                                        }
+                                        else
+                                        {
+                                            q[epi][ch] = quantizeUnsigned(epCS[epi][ch] & 0xffff, aPrec);
+                                            unq[epi][ch] = unquantizeUnsigned(q[epi][ch], aPrec, fin[epi][ch]);
+                                        }
+                                    }
+                                setupSelector(unq, fin, S);
+                                fixRaw = rawIndexOf(S, fa, fb, fixLf);
+                                invert = (indexRange / 2 - 1) < fixRaw;
+                                if (invert)
                                 {
-                                    const int t = q[0][ch];
-                                    q[0][ch] = q[1][ch];
-                                    q[1][ch] = t;
+#pragma unroll
+                                    for (int ch = 0; ch < 3; ch++)
+                                    {
+                                        const int t = q[0][ch];
+                                        q[0][ch] = q[1][ch];
+                                        q[1][ch] = t;
+                                    }
                                 }
+                                packEPQ(q, qa, qb, qc);
+                                if (subset == 0)
+                                    fits = fitsAnyMode(q);
+                                s_epq[subset][metaRound][0][blk] = qa;
+                                s_epq[subset][metaRound][1][blk] = qb;
+                                if (!partitioned)
+                                    s_epq[1][metaRound][0][blk] = qc;
+                                if (partitioned)
+                                    myXb |= qc << (2 * refinePass);
+                                myInv |= (invert ? 1u : 0u) << refinePass;
                             }
-                            u32 qa, qb, qc;
-                            packEPQ(q, qa, qb, qc);
+#pragma unroll
+                            for (int k = 0; k < 3; k++) // (no dynamic index: the words stay registers)
+                                if (k == refinePass)
+                                {
+                                    myQa[k] = qa;
+                                    myQb[k] = qb;
+                                    myQc[k] = qc;
+                                }
+
                             bool needError = true; // wave-uniform
                             if (subset == 0)
                             {
-                                bool fits = ownDeltaFits(q, modeW0, aPrec);
-                                if (numModesHere > 1)
-                                    fits = fits | ownDeltaFits(q, modeW1, aPrec);
-                                if (numModesHere > 2)
-                                    fits = fits | ownDeltaFits(q, modeW2, aPrec);
                                 needError = __ballot(fits) != 0;
-                                if (needError)
-                                    usable0 |= 1u << metaRound;
+                                usableNow = usableNow || needError;
                                 if (lazy && fits)
-                                    cand0 |= 1u << metaRound;
+                                    candNow |= 1u << refinePass;
                             }
                             if (lazy)
                                 needError = false;
-                            if (invert)
-                                invBits |= 1u << (subset * 12 + metaRound);
-                            // ---- duplicate-round test against every earlier meta round of this subset (group-wide) ----
-                            // Only a group whose eight lanes ALL repeat an earlier round skips the round, so the first of the three
-                            // words is compared alone, and the other two only if some group matches in it everywhere.
-                            const int epq0 = epqEntry(subset, 0), epqNow = epqEntry(subset, metaRound);
-                            const u32 xbPrev = subset == 0 ? xbits0 : xbits1;
-                            bool anySame = false;
-                            for (int prev = 0; prev < metaRound; prev++)
-                                anySame = anySame || (meta[epq0 + prev * epqStride][lane] == qa);
-                            meta[epqNow][lane] = qa;
-                            meta[epqNow + 1][lane] = qb;
-                            if (partitioned)
+#ifdef CVTT_BC6H_DBG_NOSKIP
+                            needError = true;
+                            usableNow = true;
+#endif
+
+                            // ---- duplicate-round test against the meta rounds that are known now: the earlier tweaks' rounds up to
+                            // this pass (DPP from the quad's lower sub-lanes) and this chain's earlier rounds.  Only a group whose
+                            // eight blocks ALL repeat an earlier round skips the round, so the first of the three words is
+                            // compared alone, and the other two only if some group matches in it everywhere.
+                            bool same = false;
+#pragma unroll
+                            for (int r2 = 0; r2 < 3; r2++)
                             {
-                                if (subset == 0) xbits0 |= qc << (2 * metaRound); else xbits1 |= qc << (2 * metaRound);
+                                if (r2 > refinePass)
+                                    continue;
+                                const u32 o0 = quadBcast<0>(myQa[r2]), o1 = quadBcast<1>(myQa[r2]), o2 = quadBcast<2>(myQa[r2]);
+                                same = same | ((tw > 0) & (o0 == qa)) | ((tw > 1) & (o1 == qa)) | ((tw > 2) & (o2 == qa));
+                                if (r2 < refinePass)
+                                    same = same | (myQa[r2] == qa);
                             }
-                            else
-                                meta[epqNow + 2][lane] = qc;
-                            bool groupAllSame = false;
-                            if (metaRound > 0)
+                            bool dropped = false;
                             {
-                                u64 g = __ballot(anySame);
-                                g &= g >> 1;
-                                g &= g >> 2;
+                                u64 g = __ballot(same && act);
                                 g &= g >> 4;
-                                if ((g & 0x0101010101010101ull) != 0)
+                                g &= g >> 8;
+                                g &= g >> 16;
+#ifdef CVTT_BC6H_DBG_NODROP
+                                g = 0;
+#endif
+                                if ((g & 0x0000000f0000000full) != 0)
                                 {
-                                    anySame = false;
-                                    for (int prev = 0; prev < metaRound; prev++)
+                                    same = false;
+#pragma unroll
+                                    for (int r2 = 0; r2 < 3; r2++)
                                     {
-                                        const u32 pc = partitioned ? ((xbPrev >> (2 * prev)) & 3u) : meta[epq0 + prev * epqStride + 2][lane];
-                                        anySame = anySame || (meta[epq0 + prev * epqStride][lane] == qa && meta[epq0 + prev * epqStride + 1][lane] == qb && pc == qc);
+                                        if (r2 > refinePass)
+                                            continue;
+                                        const bool lower = lowerSubLaneHolds(tw, qa, qb, qc, myQa[r2], myQb[r2], myQc[r2]);
+                                        same = same | lower;
+                                        if (r2 < refinePass)
+                                            same = same | ((myQa[r2] == qa) & (myQb[r2] == qb) & (myQc[r2] == qc));
                                     }
-                                    groupAllSame = groupBits(__ballot(anySame), lane) == 0xffu;
+                                    same = same && act;
+                                    // which rounds (tweak t2, this pass) does the lane's group drop?
+                                    const u32 gb = groupBits(__ballot(same), lane);
+#pragma unroll
+                                    for (int t2 = 0; t2 < 4; t2++)
+                                        if (((gb >> t2) & 0x11111111u) == 0x11111111u)
+                                        {
+                                            rv &= ~(1u << (3 * t2 + refinePass));
+                                            if (t2 == tw)
+                                                dropped = true;
+                                        }
                                 }
                             }
-                            PROF_MARK(3)
-                            if (groupAllSame)
+                            // a late duplicate found by an earlier run of these passes
+                            if (forcedDrop != 0)
                             {
-                                if (subset == 0) roundValid0 &= ~(1u << metaRound); else roundValid1 &= ~(1u << metaRound);
-                                // (its indexes are never read: only valid rounds reach the commit)
+#pragma unroll
+                                for (int t2 = 0; t2 < 4; t2++)
+                                    if ((forcedDrop >> (3 * t2 + refinePass)) & 1u)
+                                    {
+                                        rv &= ~(1u << (3 * t2 + refinePass));
+                                        if (t2 == tw)
+                                            dropped = true;
+                                    }
                             }
-                            else if (!needError && refinePass == numRefineRounds - 1)
+
+                            const bool run = act && !dropped;
+                            if (!needError && refinePass == numRefineRounds - 1)
                             {
                                 // nobody can use this round and no refine pass follows it
-                                errAt(metaRound, subset) = FLT_MAX;
+                                if (run)
+                                    errAt(metaRound, subset) = FLT_MAX;
                             }
-                            else
+                            else if (__ballot(run) != 0)
                             {
                                 // ---- error and refiner sums in pixel order (BC67.cpp:2879-2909); the indexes themselves are not kept ----
                                 float subsetError = needError ? 0.0f : FLT_MAX;
-#pragma unroll
-                                for (int px = 0; px < 16; px++)
-                                    if ((sm >> px) & 1u)
+                                if (run)
+                                {
+                                    for (u32 rem = subsetMask; rem != 0; rem &= rem - 1u)
                                     {
-                                        const u32 a = fetchPixel(pk01[px]), b = fetchPixel(pk2[px]);
-                                        float lfp[3] = {0.0f, 0.0f, 0.0f};
-                                        if (!FAST)
-                                        {
-                                            if (partitioned)
-                                            {
-                                                lfp[0] = lf[FAST ? 0 : px][0];
-                                                lfp[1] = lf[FAST ? 0 : px][1];
-                                                lfp[2] = lf[FAST ? 0 : px][2];
-                                            }
-                                            else
-                                                pixelLinear(a, b, lfp);
-                                        }
+                                        const int px = __builtin_ctz(rem);
+                                        u32 a, b;
+                                        float lfp[3];
+                                        pixLoad(px, a, b, lfp);
                                         // (the anchor's scan has been done: its index decided the inversion)
-                                        int raw;
-                                        if (px == fixupIndex)
-                                            raw = fixRaw;
-                                        else
-                                        {
-                                            const float lwp[3] = {lfp[0] * A.w[0], lfp[1] * A.w[1], lfp[2] * A.w[2]};
-                                            raw = rawIndexOf(a, b, lwp);
-                                        }
-                                        const int index = invert ? (indexRange - 1) - raw : raw;
-
-                                        const int weight = (int)((mulU24((u32)raw, (u32)weightRcp) + 256u) >> 9);
-                                        const int orig[3] = {(int)(short)(a & 0xffffu), (int)(short)(a >> 16), (int)(short)(b & 0xffffu)};
+                                        const int raw = (px == fixupIndex) ? fixRaw : rawIndexOf(S, a, b, lfp);
                                         if (needError)
-                                        {
-                                        float err = 0.0f;
-                                        int rec[3];
-                                        float recF[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-                                        for (int ch = 0; ch < 3; ch++)
-                                        {
-                                            rec[ch] = reconstructFrom<SIGNED>(recBase[ch], recDiff[ch], weight);
-                                            if (!FAST)
-                                                recF[ch] = SIGNED ? twosCLHalfToFloat<SIGNED>(rec[ch]) : __half2float(__ushort_as_half((unsigned short)rec[ch]));
-                                        }
-                                        if (!FAST && !SIGNED && interpFixup)
-                                        {
-                                            asm volatile("" ::: "memory"); // one wave-uniform branch around the three rare halvings
-#pragma unroll
-                                            for (int ch = 0; ch < 3; ch++)
-                                                recF[ch] = (rec[ch] & 0x7c00) ? recF[ch] : recF[ch] * 0.5f;
-                                        }
-#pragma unroll
-                                        for (int ch = 0; ch < 3; ch++)
-                                        {
-                                            float sq;
-                                            if (FAST)
-                                            {
-                                                // SqDiffSInt16, ParallelMath.h:996-1010
-                                                const int r16 = (int)(short)rec[ch];
-                                                const u32 du = (u32)((r16 > orig[ch] ? r16 : orig[ch]) - (r16 > orig[ch] ? orig[ch] : r16)) & 0xffffu;
-                                                sq = (float)(int)(du * du);
-                                            }
-                                            else
-                                            {
-                                                const float d = recF[ch] - lfp[ch];
-                                                sq = d * d;
-                                            }
-                                            err = err + sq * A.wSq[ch]; // (Flags::Uniform: the weights are 1.0 and the product is exact, no second form needed)
-                                        }
-                                        subsetError = subsetError + err;
-                                        }
-
+                                            subsetError = subsetError + pixelError(S, raw, a, b, lfp);
                                         if (refinePass != numRefineRounds - 1)
                                         {
+                                            const int index = invert ? (indexRange - 1) - raw : raw;
                                             const float t = (float)index * rcpMaxIndex;
-#pragma unroll
-                                            for (int ch = 0; ch < 3; ch++)
-                                            {
-                                                const float v = (float)orig[ch] * A.w[ch];
-                                                tv[ch] = tv[ch] + t * v;
-                                            }
+                                            tv[0] = tv[0] + t * ((float)(int)(short)(a & 0xffffu) * A.w[0]);
+                                            tv[1] = tv[1] + t * ((float)(int)(short)(a >> 16) * A.w[1]);
+                                            tv[2] = tv[2] + t * ((float)(int)(short)(b & 0xffffu) * A.w[2]);
                                             tt = tt + t * t;
                                             ts = ts + t;
                                             refCount++;
                                         }
                                     }
-                                if (refinePass != numRefineRounds - 1)
-                                {
+                                    if (refinePass != numRefineRounds - 1)
+                                    {
 #pragma unroll
-                                    for (int ch = 0; ch < 3; ch++)
-                                        vs[ch] = vsSubset[ch];
+                                        for (int ch = 0; ch < 3; ch++)
+                                            vs[ch] = vsSubset[ch];
+                                    }
+                                    errAt(metaRound, subset) = subsetError;
                                 }
-                                errAt(metaRound, subset) = subsetError;
                             }
-                            PROF_MARK(4)
+                        }
+                        // the spare bits and the swap flags of this chain's rounds, and -- once per run -- zeros for the rounds the
+                        // options leave out
+                        if (partitioned)
+                            s_xb[subset][blk][tw] = (uint8_t)myXb;
+                        s_inv[subset][blk][tw] = (uint8_t)myInv;
+                        if (abortMask != 0)
+                        {
+#pragma unroll
+                            for (int r = 0; r < 3; r++)
+                                if (!twActive || r >= numRefineRounds)
+                                {
+                                    s_epq[subset][tw * 3 + r][0][blk] = 0;
+                                    s_epq[subset][tw * 3 + r][1][blk] = 0;
+                                    if (!partitioned)
+                                        s_epq[1][tw * 3 + r][0][blk] = 0;
+                                }
+                        }
+
+                        // ---- the rounds that were not known in time: (t' < tw, r' > r) ----
+                        {
+                            bool anyLate = false; // a round of this chain repeats a LATER pass of a lower tweak
+#pragma unroll
+                            for (int r = 0; r < 2; r++)
+                            {
+                                bool s2 = false;
+#pragma unroll
+                                for (int r2 = r + 1; r2 < 3; r2++)
+                                {
+                                    const bool lower = lowerSubLaneHolds(tw, myQa[r], myQb[r], myQc[r], myQa[r2], myQb[r2], myQc[r2]);
+                                    s2 = s2 | lower;
+                                }
+                                anyLate = anyLate || (s2 && twActive && r < numRefineRounds);
+                            }
+                            u32 newDrop = 0; // per group: meta rounds that ran although all eight blocks repeat an earlier round
+#ifdef CVTT_BC6H_DBG_NOLATE
+                            anyLate = false;
+#endif
+#ifdef CVTT_BC6H_TRACE
+                            if (partitioned && aPrec == 6 && p == 11 && subset == 1 && blockIdx.x == (u32)(CVTT_BC6H_TRACE) / 16u)
+                            {
+                                const u64 b0 = __ballot(anyLate);
+                                if (lane == 0) { g_bc6hTrace2[0] += 1; g_bc6hTrace2[1] = b0; g_bc6hTrace2[2] = forcedDrop; }
+                            }
+#endif
+                            if (__ballot(anyLate) != 0)
+                            {
+                                // the complete test of rounds 0 and 1 of every chain: all three words, every earlier meta round
+#pragma unroll
+                                for (int r = 0; r < 2; r++)
+                                {
+                                    bool full = false;
+#pragma unroll
+                                    for (int r2 = 0; r2 < 3; r2++)
+                                    {
+                                        const bool lower = lowerSubLaneHolds(tw, myQa[r], myQb[r], myQc[r], myQa[r2], myQb[r2], myQc[r2]);
+                                        full = full | lower;
+                                        if (r2 < r)
+                                            full = full | ((myQa[r2] == myQa[r]) & (myQb[r2] == myQb[r]) & (myQc[r2] == myQc[r]));
+                                    }
+                                    full = full && twActive && r < numRefineRounds;
+                                    const u32 gb = groupBits(__ballot(full), lane);
+#ifdef CVTT_BC6H_TRACE
+                                    if (partitioned && aPrec == 6 && p == 11 && subset == 1 && blockIdx.x == (u32)(CVTT_BC6H_TRACE) / 16u)
+                                    {
+                                        const u64 b1 = __ballot(full);
+                                        if (lane == 0) { g_bc6hTrace2[3 + r] = b1; g_bc6hTrace2[5 + r] = rv; }
+                                    }
+#endif
+#pragma unroll
+                                    for (int t2 = 1; t2 < 4; t2++)
+                                        if (((gb >> t2) & 0x11111111u) == 0x11111111u && ((rv >> (3 * t2 + r)) & 1u))
+                                            newDrop |= 1u << (3 * t2 + r);
+                                }
+                            }
+                            if (__ballot(newDrop != 0) == 0)
+                            {
+                                if (subset == 0) { roundValid0 = rv; usable0 = usableNow; cand0 = candNow; } else roundValid1 = rv;
+                                break;
+                            }
+                            // the first of them in the reference's order is certain (everything before it is final): the passes run again
+                            // with it dropped.  (A group without a new drop repeats its passes with the same result.)
+                            if (newDrop != 0)
+                                forcedDrop |= 1u << __builtin_ctz(newDrop);
+                            PROF_COUNT(1, 1)
+                            __syncthreads();
                         }
                     }
                 }
-
-                if (lazy && usable0 != 0)
+                __syncthreads(); // the history of this partition is complete: every lane may read every round of its block
+#ifdef CVTT_BC6H_TRACE
+                if (partitioned && aPrec == 6 && blockIndex == (u32)(CVTT_BC6H_TRACE) && tw == 0)
                 {
-                    // ---- which pairs of rounds could some lane commit? (Evaluate*Legality, BC67.cpp:2597-2663, on end points alone) ----
-                    u32 need0 = 0, need1 = 0;
-                    u32 c0 = cand0 & roundValid0;
-                    PROF_COUNT(8, 1)
-                    PROF_COUNT(12, __popcll(__ballot(c0 != 0)))
+                    unsigned *d = &g_bc6hTrace[p * 74];
+                    d[0] = roundValid0;
+                    d[1] = usable0 ? roundValid1 : 0xdeadu;
+                    for (int s2 = 0; s2 < 2; s2++)
+                        for (int m = 0; m < 12; m++)
+                        {
+                            d[2 + (s2 * 12 + m) * 3 + 0] = s_epq[s2][m][0][blk];
+                            d[2 + (s2 * 12 + m) * 3 + 1] = s_epq[s2][m][1][blk];
+                            d[2 + (s2 * 12 + m) * 3 + 2] = __float_as_uint(s_err[s2][m][blk]);
+                        }
+                }
+#endif
+
+                if (lazy && usable0)
+                {
+                    // ---- which pairs of rounds could the block commit? (Evaluate*Legality, BC67.cpp:2597-2663, on end points alone) ----
+                    // lane (block, t) takes the subset-0 rounds of its own chain that fit their own delta and pairs them with all
+                    // twelve rounds of subset 1
+                    u32 need0 = 0, need1 = 0; // bit m: the error of meta round m of subset 0 / 1 is needed (by this block)
+                    u32 c0 = cand0 & (roundValid0 >> (3 * tw)) & 7u;
                     while (__ballot(c0 != 0) != 0)
                     {
-                        PROF_COUNT(9, 1)
-                        const bool act = c0 != 0;
-                        const int m0 = act ? __builtin_ctz(c0) : 0;
+                        const bool actL = c0 != 0;
+                        const int r0 = actL ? __builtin_ctz(c0) : 0;
                         c0 &= c0 - 1u;
+                        const int m0 = 3 * tw + r0;
                         int e0[2][3];
-                        loadEPQ(0, m0, xbits0, e0); // (m0 differs from lane to lane: the entry index is per lane, the bank is the lane's)
+                        loadEPQ(0, m0, e0);
                         const bool own0 = ownDeltaFits(e0, modeW0, aPrec);
                         const bool own1 = numModesHere > 1 && ownDeltaFits(e0, modeW1, aPrec);
                         const bool own2 = numModesHere > 2 && ownDeltaFits(e0, modeW2, aPrec);
-                        // (the lanes with a candidate are few: one or two of 64 on content without structure, and each fits one
-                        // mode as a rule, so every test is followed by a wave-wide "is anybody still in?")
-                        if (__ballot(act && (own0 || own1 || own2)) == 0)
+                        if (__ballot(actL && (own0 || own1 || own2)) == 0)
                             continue;
                         for (int m1 = 0; m1 < 12; m1++)
                         {
                             int x[2][3];
-                            loadEPQ(1, m1, xbits1, x);
-                            const bool in = act && ((roundValid1 >> m1) & 1u);
+                            loadEPQ(1, m1, x);
+                            const bool in = actL && ((roundValid1 >> m1) & 1u);
                             bool ok0 = in && own0, ok1 = in && own1, ok2 = in && own2;
                             const int mask = (1 << aPrec) - 1;
                             auto fitsOne = [&](int v, int base, u32 mw, int ch) -> bool {
@@ -978,172 +1155,77 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
                             }
                         }
                     }
-                    // ---- replay: the rounds of the set again, from their quantised end points, this time with errors ----
-                    // `rm`: the round of subset `rs` (wave-uniform) this lane evaluates -- the same in every lane (three-mode
-                    // precisions) or each lane's own (single-mode precisions); `act`: the lane has one
-                    auto replayRound = [&](int rs, int rm, bool act) {
-                        const u32 rmask = GW ? (rs ? partitionMask : (~partitionMask & 0xffffu)) : opaqueUniform(rs ? partitionMask : (~partitionMask & 0xffffu));
-                        // the end points as the round had them before it swapped them (the scan's first-minimum rule sees the order)
-                        const bool was = ((invBits >> (rs * 12 + rm)) & 1u) != 0;
-                        int rq[2][3];
-                        loadEPQ(rs, rm, rs ? xbits1 : xbits0, rq);
-                        const int (&s0)[3] = rq[0];
-                        const int (&s1)[3] = rq[1];
-                        int unq[2][3], fin[2][3];
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++)
-                        {
-                            const int q0 = was ? s1[ch] : s0[ch], q1 = was ? s0[ch] : s1[ch];
-                            unq[0][ch] = SIGNED ? unquantizeSigned(q0, aPrec, fin[0][ch]) : unquantizeUnsigned(q0, aPrec, fin[0][ch]);
-                            unq[1][ch] = SIGNED ? unquantizeSigned(q1, aPrec, fin[1][ch]) : unquantizeUnsigned(q1, aPrec, fin[1][ch]);
-                        }
-                        float iw[indexRange][3];
-                        float origin[3], axis[3];
-                        if (FAST)
-                        {
-                            float epDW[3];
-#pragma unroll
-                            for (int ch = 0; ch < 3; ch++)
-                            {
-                                origin[ch] = (float)fin[0][ch];
-                                epDW[ch] = ((float)fin[1][ch] - origin[ch]) * A.w[ch];
-                            }
-                            float lenSq = epDW[0] * epDW[0];
-                            lenSq = lenSq + epDW[1] * epDW[1];
-                            lenSq = lenSq + epDW[2] * epDW[2];
-                            lenSq = safeDenom(lenSq);
-                            const float mvdls = maxValue / lenSq;
-#pragma unroll
-                            for (int ch = 0; ch < 3; ch++)
-                                axis[ch] = epDW[ch] * A.w[ch] * mvdls;
-                        }
-                        else
-                        {
-#pragma unroll
-                            for (int i = 0; i < indexRange; i++)
-                            {
-                                const int weight = mad24(weightRcp, i, 256) >> 9;
-#pragma unroll
-                                for (int ch = 0; ch < 3; ch++)
-                                    iw[i][ch] = twosCLHalfToFloat<SIGNED>(reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight)) * A.w[ch];
-                            }
-                        }
-                        float subsetError = 0.0f;
-#pragma unroll 1
-                        for (int px = 0; px < 16; px++)
-                        {
-                            if (((rmask >> px) & 1u) == 0)
-                                continue;
-                            u32 a = 0, b = 0;
-#pragma unroll
-                            for (int k = 0; k < 16; k++)
-                                if (k == px)
-                                {
-                                    a = pk01[k];
-                                    b = pk2[k];
-                                }
-                            float lf[3] = {0.0f, 0.0f, 0.0f};
-                            int raw;
-                            if (FAST)
-                            {
-                                const int c0 = (int)(short)(a & 0xffffu), c1 = (int)(short)(a >> 16), c2 = (int)(short)(b & 0xffffu);
-                                float dist = ((float)c0 - origin[0]) * axis[0];
-                                dist = dist + ((float)c1 - origin[1]) * axis[1];
-                                dist = dist + ((float)c2 - origin[2]) * axis[2];
-                                raw = (int)clampRound(dist, maxValue);
-                            }
-                            else
-                            {
-                                lf[0] = pixelToFloat((int)(short)(a & 0xffffu));
-                                lf[1] = pixelToFloat((int)(short)(a >> 16));
-                                lf[2] = pixelToFloat((int)(short)(b & 0xffffu));
-                                const float l0 = lf[0] * A.w[0], l1 = lf[1] * A.w[1], l2 = lf[2] * A.w[2];
-                                float be = 0.0f;
-                                raw = 0;
-#pragma unroll
-                                for (int i = 0; i < indexRange; i++)
-                                {
-                                    float d = l0 - iw[i][0];
-                                    float e = d * d;
-                                    d = l1 - iw[i][1];
-                                    e = e + d * d;
-                                    d = l2 - iw[i][2];
-                                    e = e + d * d;
-                                    const bool lt = (i == 0) || (e < be);
-                                    raw = lt ? i : raw;
-                                    be = (i == 0) ? e : __builtin_fminf(be, e);
-                                }
-                            }
-                            const int weight = (int)((mulU24((u32)raw, (u32)weightRcp) + 256u) >> 9);
-                            const int orig[3] = {(int)(short)(a & 0xffffu), (int)(short)(a >> 16), (int)(short)(b & 0xffffu)};
-                            float err = 0.0f;
-#pragma unroll
-                            for (int ch = 0; ch < 3; ch++)
-                            {
-                                const int rec = reconstructChannel<SIGNED>(unq[0][ch], unq[1][ch], weight);
-                                float sq;
-                                if (FAST)
-                                {
-                                    const int r16 = (int)(short)rec;
-                                    const u32 du = (u32)((r16 > orig[ch] ? r16 : orig[ch]) - (r16 > orig[ch] ? orig[ch] : r16)) & 0xffffu;
-                                    sq = (float)(int)(du * du);
-                                }
-                                else
-                                {
-                                    const float d = twosCLHalfToFloat<SIGNED>(rec) - lf[ch];
-                                    sq = d * d;
-                                }
-                                err = err + sq * A.wSq[ch]; // (Flags::Uniform: the weights are 1.0 and the product is exact, no second form needed)
-                            }
-                            subsetError = subsetError + err;
-                        }
-                        if (act)
-                            errAt(rm, rs) = subsetError;
-                    };
                     if (__ballot(need0 != 0) == 0)
                         continue; // nobody can commit anything with this partition at this precision
-                    PROF_COUNT(10, 1)
-                    if (perLaneReplay)
+                    PROF_COUNT(3, 1)
+                    // the block's sets (the quad's lanes looked at different rounds of subset 0) ...
+                    need0 |= (u32)__builtin_amdgcn_mov_dpp((int)need0, 0xb1, 0xf, 0xf, true); // quad_perm [1,0,3,2]
+                    need0 |= (u32)__builtin_amdgcn_mov_dpp((int)need0, 0x4e, 0xf, 0xf, true); // quad_perm [2,3,0,1]
+                    need1 |= (u32)__builtin_amdgcn_mov_dpp((int)need1, 0xb1, 0xf, 0xf, true);
+                    need1 |= (u32)__builtin_amdgcn_mov_dpp((int)need1, 0x4e, 0xf, 0xf, true);
+                    if (!perBlockReplay)
                     {
-                        // every lane its own rounds: as many passes as the wave's busiest lane has rounds to evaluate
-                        int passes = 0;
-#pragma unroll 1
-                        for (int rs = 0; rs < 2; rs++)
+                        // ... and with three modes the group's: a block that is better but illegal keeps its group's mode loop going
+#pragma unroll
+                        for (int step = 4; step < 32; step <<= 1)
                         {
-                            u32 todo = rs ? need1 : need0;
-                            while (__ballot(todo != 0) != 0)
+                            need0 |= xorLane(need0, step);
+                            need1 |= xorLane(need1, step);
+                        }
+                    }
+                    // ---- replay: the rounds of the set again, from their quantised end points, this time with errors; each by the
+                    // lane whose chain the round belongs to ----
+                    int slots = 0;
+#pragma unroll 1
+                    for (int rs = 0; rs < 2; rs++)
+                    {
+#pragma unroll 1
+                        for (int r = 0; r < 3; r++)
+                        {
+                            const int rm = 3 * tw + r;
+                            const bool actL = (((rs ? need1 : need0) >> rm) & 1u) != 0;
+                            if (__ballot(actL) == 0)
+                                continue;
+                            slots++;
+                            if (actL)
                             {
-                                const bool act = todo != 0;
-                                const int rm = act ? __builtin_ctz(todo) : 0;
-                                todo &= todo - 1u;
-                                replayRound(rs, rm, act);
-                                passes++;
+                                const u32 rmask = rs ? partitionMask : (~partitionMask & 0xffffu);
+                                // the end points as the round had them before it swapped them (the scan's first-minimum rule sees the order)
+                                const bool was = wasSwapped(rs, rm);
+                                int rq[2][3];
+                                loadEPQ(rs, rm, rq);
+                                int unq[2][3], fin[2][3];
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++)
+                                {
+                                    const int q0 = was ? rq[1][ch] : rq[0][ch], q1 = was ? rq[0][ch] : rq[1][ch];
+                                    unq[0][ch] = SIGNED ? unquantizeSigned(q0, aPrec, fin[0][ch]) : unquantizeUnsigned(q0, aPrec, fin[0][ch]);
+                                    unq[1][ch] = SIGNED ? unquantizeSigned(q1, aPrec, fin[1][ch]) : unquantizeUnsigned(q1, aPrec, fin[1][ch]);
+                                }
+                                Selector S;
+                                setupSelector(unq, fin, S);
+                                float subsetError = 0.0f;
+                                for (u32 rem = rmask; rem != 0; rem &= rem - 1u)
+                                {
+                                    const int px = __builtin_ctz(rem);
+                                    u32 a, b;
+                                    float lfp[3];
+                                    pixLoad(px, a, b, lfp);
+                                    const int raw = rawIndexOf(S, a, b, lfp);
+                                    subsetError = subsetError + pixelError(S, raw, a, b, lfp);
+                                }
+                                errAt(rm, rs) = subsetError;
                             }
                         }
-                        if (passes > CVTT_BC6H_LAZY_SWITCH)
-                            eagerNow = true;
                     }
-                    else
-                    {
-                        u32 replayRounds = 0; // wave-uniform: bit subset * 12 + round
-#pragma unroll
-                        for (int m = 0; m < 12; m++)
-                        {
-                            if (__ballot((need0 >> m) & 1u) != 0) replayRounds |= 1u << m;
-                            if (__ballot((need1 >> m) & 1u) != 0) replayRounds |= 1u << (12 + m);
-                        }
+                    PROF_COUNT(4, slots)
+                    if (slots > CVTT_BC6H_LAZY_SWITCH)
                         eagerNow = true;
-                        for (u32 todo = replayRounds; todo != 0; todo &= todo - 1u)
-                        {
-                            const int bit = __builtin_ctz(todo);
-                            const int rs = bit >= 12 ? 1 : 0;
-                            replayRound(rs, bit - 12 * rs, true);
-                        }
-                    }
+                    __syncthreads();
                 }
 
-                // ---- delta-coding legality + commit, BC67.cpp:2914-2986 ----
-                if (usable0 == 0)
+                // ---- delta-coding legality + commit, BC67.cpp:2914-2986 (the four lanes of a quad do the same) ----
+                if (!usable0)
                     continue;
                 const int numMeta1 = partitioned ? 12 : 1;
                 // cheapest valid subset-1 round: no combination with meta0 can beat the best unless this one does
@@ -1158,12 +1240,9 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
                             minErr1 = e;
                     }
                 }
-                for (int cand = 0; cand < ((GW && partitioned) ? 8 : 1); cand++)
-                {
-                const bool act = !(GW && partitioned) || (lane >> 3) == cand; // GW: the candidates commit in the reference's order
                 for (int meta0 = 0; meta0 < 12; meta0++)
                 {
-                    const bool valid0 = act && ((roundValid0 >> meta0) & 1u) != 0;
+                    const bool valid0 = ((roundValid0 >> meta0) & 1u) != 0;
                     const float err0 = errAt(meta0, 0);
                     const bool canBeat = valid0 && ((partitioned ? err0 + minErr1 : err0) < bestError);
                     if (__ballot(canBeat) == 0)
@@ -1172,14 +1251,14 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
                     int e0[2][3];
                     bool legal0[3] = {true, true, true};
                     {
-                        loadEPQ(0, meta0, xbits0, e0);
+                        loadEPQ(0, meta0, e0);
                         legal0[0] = ownDeltaFits(e0, modeW0, aPrec);
                         if (numModesHere > 1)
                             legal0[1] = ownDeltaFits(e0, modeW1, aPrec);
                         if (numModesHere > 2)
                             legal0[2] = ownDeltaFits(e0, modeW2, aPrec);
                     }
-                    // a lane whose subset-0 delta fits no mode cannot commit with this meta0 whatever meta1 is
+                    // a block whose subset-0 delta fits no mode cannot commit with this meta0 whatever meta1 is
                     if (__ballot(canBeat && (legal0[0] || (numModesHere > 1 && legal0[1]) || (numModesHere > 2 && legal0[2]))) == 0)
                         continue;
                     for (int meta1 = 0; meta1 < numMeta1; meta1++)
@@ -1197,7 +1276,7 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
 
                         int e1[2][3] = {{0, 0, 0}, {0, 0, 0}};
                         if (partitioned)
-                            loadEPQ(1, meta1, xbits1, e1);
+                            loadEPQ(1, meta1, e1);
 
                         for (int mi = 0; mi < numModesHere; mi++)
                         {
@@ -1261,7 +1340,7 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
                                     }
                                     // (the indexes of the two rounds are selected again after the search, from these end
                                     // points in the order the rounds had them)
-                                    bestSwap = ((invBits >> meta0) & 1u) | (partitioned ? ((invBits >> (12 + meta1)) & 1u) << 1 : 0u);
+                                    bestSwap = (wasSwapped(0, meta0) ? 1u : 0u) | ((partitioned && wasSwapped(1, meta1)) ? 2u : 0u);
                                     needsCommit = false;
                                 }
                             }
@@ -1273,37 +1352,16 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
                         }
                     }
                 }
-                if (GW && partitioned)
-                {
-                    // the block's best after this candidate's partition, to all eight lanes of the block
-                    const int src = cand * 8 + (lane & 7);
-                    bestError = __shfl(bestError, src);
-                    bestMode = __shfl(bestMode, src);
-                    bestPartition = __shfl(bestPartition, src);
-                    bestSwap = (u32)__shfl((int)bestSwap, src);
-#pragma unroll
-                    for (int i = 0; i < 6; i++)
-                        bestEP[i] = (u32)__shfl((int)bestEP[i], src);
-                }
-                } // candidates
             }
         }
     };
     searchAll(std::false_type{});
-    if (!FAST)
-    {
-#pragma unroll
-        for (int px = 0; px < 16; px++)
-            pixelLinear(pk01[px], pk2[px], lf[px]);
-    }
     searchAll(std::true_type{});
 
-    PROF_MARK(5)
-    PROF_FLUSH
     // ---- the winner's indexes, selected again from its end points.  A round's indexes are a function of its quantised end
     // points in the order it had them before the anchor swap, of the precision and of the pixels (QuantizeEndpoints* +
-    // SelectIndexHDR*, BC67.cpp:2503-2595, 2879-2893): the same operations on the same values here, once per block, instead of
-    // 48 words of index history per partition and precision in memory. ----
+    // SelectIndexHDR*, BC67.cpp:2503-2595, 2879-2893): the same operations on the same values here, once per block.  Sub-lane t
+    // selects pixels 4t ... 4t+3; the quad then puts the words together. ----
     u32 bestIdxLo = 0, bestIdxHi = 0;
     {
         const bool partitionedB = T->bc6hModeInfo[bestMode][1] != 0;
@@ -1368,11 +1426,15 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
                     axisB[sb][ch] = epDW[ch] * A.w[ch] * mvdls;
             }
         }
-#pragma unroll
-        for (int px = 0; px < 16; px++)
+        u32 myIdx = 0; // four indexes, 4 bits each: pixels 4 tw ... 4 tw + 3
+#pragma unroll 1
+        for (int j = 0; j < 4; j++)
         {
+            const int px = 4 * tw + j;
             const bool s1 = ((pmask >> px) & 1u) != 0;
-            const u32 a = fetchPixel(pk01[px]), b = fetchPixel(pk2[px]);
+            u32 a, b;
+            float lfp[3];
+            pixLoad(px, a, b, lfp);
             const int c[3] = {(int)(short)(a & 0xffffu), (int)(short)(a >> 16), (int)(short)(b & 0xffffu)};
             int raw = 0;
             if (FAST)
@@ -1391,7 +1453,7 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
                     e0[ch] = s1 ? unqB[1][0][ch] : unqB[0][0][ch];
                     e1[ch] = s1 ? unqB[1][1][ch] : unqB[0][1][ch];
                 }
-                const float l0 = lf[FAST ? 0 : px][0] * A.w[0], l1 = lf[FAST ? 0 : px][1] * A.w[1], l2 = lf[FAST ? 0 : px][2] * A.w[2];
+                const float l0 = lfp[0] * A.w[0], l1 = lfp[1] * A.w[1], l2 = lfp[2] * A.w[2];
                 float be = 0.0f;
 #pragma unroll 1
                 for (int i = 0; i < 16; i++)
@@ -1410,14 +1472,15 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
             }
             const bool sw = ((bestSwap >> (s1 ? 1 : 0)) & 1u) != 0;
             const u32 index = (u32)(sw ? (rangeB - 1) - raw : raw);
-            if (px < 8)
-                bestIdxLo |= index << (4 * px);
-            else
-                bestIdxHi |= index << (4 * (px - 8));
+            myIdx |= index << (4 * j);
         }
+        // pixels 0-7 are sub-lanes 0 and 1, 8-15 sub-lanes 2 and 3
+        const u32 i0 = quadBcast<0>(myIdx), i1 = quadBcast<1>(myIdx), i2 = quadBcast<2>(myIdx), i3 = quadBcast<3>(myIdx);
+        bestIdxLo = i0 | (i1 << 16);
+        bestIdxHi = i2 | (i3 << 16);
     }
     // ---- header scatter + indexes (BC67.cpp:2992-3050, BC6H_IO: table from tools/gen_bc6h_layout.py) ----
-    if (valid && (!GW || (threadIdx.x >> 3) == 0))
+    if (valid && tw == 0)
     {
         const bool partitioned = T->bc6hModeInfo[bestMode][1] != 0;
         const int headerBits = partitioned ? 82 : 65;
@@ -1482,11 +1545,11 @@ __global__ __launch_bounds__(64 * CVTT_BC6H_WG_WAVES, (CVTT_BC6H_WAVES + CVTT_BC
 extern "C" hipError_t cvttmi_launch_bc6h(const void *d_blocks, void *d_out, const CvttBc6hArgs *args,
                                          const CvttDeviceTables *d_tables, int isSigned, hipStream_t stream)
 {
-    const uint32_t waves = CVTT_BC6H_GROUPWAVE ? (args->numBlocks + 7u) / 8u : (args->numBlocks + 63u) / 64u;
+    const uint32_t waves = (args->numBlocks + 15u) / 16u;
     if (waves == 0)
         return hipSuccess;
     const bool fast = (args->flags & CVTTMI_FLAG_BC6H_FAST_INDEXING) != 0;
-#define CVTT_LAUNCH(S, Fq) hipLaunchKernelGGL((cvttmi_bc6h_kernel<S, Fq>), dim3((waves + CVTT_BC6H_WG_WAVES - 1) / CVTT_BC6H_WG_WAVES), dim3(64 * CVTT_BC6H_WG_WAVES), 0, stream, (const uint8_t *)d_blocks, (uint8_t *)d_out, *args, d_tables)
+#define CVTT_LAUNCH(S, Fq) hipLaunchKernelGGL((cvttmi_bc6h_kernel<S, Fq>), dim3(waves), dim3(64), 0, stream, (const uint8_t *)d_blocks, (uint8_t *)d_out, *args, d_tables)
     if (isSigned)
     {
         if (fast) CVTT_LAUNCH(true, true); else CVTT_LAUNCH(true, false);
