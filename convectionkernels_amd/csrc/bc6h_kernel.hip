@@ -354,19 +354,26 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
     };
 
     // PCA seeds of a subset and the sums of its pre-weighted pixels (EndpointSelector.h; the reference precomputes them for
-    // every partition, BC67.cpp:2738-2774; per precision here).  The member pixels in ascending order, from LDS.
+    // every partition, BC67.cpp:2738-2774; per precision here).  `subsetMask` is PER LANE: the four sub-lanes of a quad compute the
+    // seeds of four different subsets of their block at once (two partitions x two subsets; the power iteration with its 24
+    // correctly rounded divisions is two thirds of a PCA and would otherwise be done four times over).  Every lane walks its own
+    // member pixels in ascending order (the sums' order of the reference), as many steps as the wave's largest subset has pixels.
     auto pcaSeeds = [&](u32 subsetMask, Unfinished &u, float (&sums)[3]) {
         float cen[3] = {0.0f, 0.0f, 0.0f};
         float count = 0.0f;
-        for (u32 rem = subsetMask; rem != 0; rem &= rem - 1u)
+        for (u32 rem = subsetMask; __ballot(rem != 0) != 0;)
         {
-            const int px = __builtin_ctz(rem);
-            const float4 v = s_px[px][blk];
-            const u32 a = __float_as_uint(v.w), b = s_pk2[px][blk];
-            cen[0] = cen[0] + (float)(int)(short)(a & 0xffffu) * A.w[0];
-            cen[1] = cen[1] + (float)(int)(short)(a >> 16) * A.w[1];
-            cen[2] = cen[2] + (float)(int)(short)(b & 0xffffu) * A.w[2];
-            count = count + 1.0f;
+            if (rem != 0)
+            {
+                const int px = __builtin_ctz(rem);
+                rem &= rem - 1u;
+                const float4 v = s_px[px][blk];
+                const u32 a = __float_as_uint(v.w), b = s_pk2[px][blk];
+                cen[0] = cen[0] + (float)(int)(short)(a & 0xffffu) * A.w[0];
+                cen[1] = cen[1] + (float)(int)(short)(a >> 16) * A.w[1];
+                cen[2] = cen[2] + (float)(int)(short)(b & 0xffffu) * A.w[2];
+                count = count + 1.0f;
+            }
         }
 #pragma unroll
         for (int ch = 0; ch < 3; ch++)
@@ -376,20 +383,24 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
         for (int ch = 0; ch < 3; ch++)
             cen[ch] = cen[ch] / denom;
         float cov[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        for (u32 rem = subsetMask; rem != 0; rem &= rem - 1u)
+        for (u32 rem = subsetMask; __ballot(rem != 0) != 0;)
         {
-            const int px = __builtin_ctz(rem);
-            const float4 v = s_px[px][blk];
-            const u32 a = __float_as_uint(v.w), b = s_pk2[px][blk];
-            const float d0 = (float)(int)(short)(a & 0xffffu) * A.w[0] - cen[0];
-            const float d1 = (float)(int)(short)(a >> 16) * A.w[1] - cen[1];
-            const float d2 = (float)(int)(short)(b & 0xffffu) * A.w[2] - cen[2];
-            cov[0] = cov[0] + d0 * d0;
-            cov[1] = cov[1] + d1 * d0;
-            cov[2] = cov[2] + d1 * d1;
-            cov[3] = cov[3] + d2 * d0;
-            cov[4] = cov[4] + d2 * d1;
-            cov[5] = cov[5] + d2 * d2;
+            if (rem != 0)
+            {
+                const int px = __builtin_ctz(rem);
+                rem &= rem - 1u;
+                const float4 v = s_px[px][blk];
+                const u32 a = __float_as_uint(v.w), b = s_pk2[px][blk];
+                const float d0 = (float)(int)(short)(a & 0xffffu) * A.w[0] - cen[0];
+                const float d1 = (float)(int)(short)(a >> 16) * A.w[1] - cen[1];
+                const float d2 = (float)(int)(short)(b & 0xffffu) * A.w[2] - cen[2];
+                cov[0] = cov[0] + d0 * d0;
+                cov[1] = cov[1] + d1 * d0;
+                cov[2] = cov[2] + d1 * d1;
+                cov[3] = cov[3] + d2 * d0;
+                cov[4] = cov[4] + d2 * d1;
+                cov[5] = cov[5] + d2 * d2;
+            }
         }
         float approx[3] = {1.0f, 1.0f, 1.0f};
         for (int it = 0; it < 8; it++)
@@ -425,17 +436,21 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
         for (int ch = 0; ch < 3; ch++)
             direction[ch] = approx[ch] / approxLen;
         float minDist = FLT_MAX, maxDist = -FLT_MAX;
-        for (u32 rem = subsetMask; rem != 0; rem &= rem - 1u)
+        for (u32 rem = subsetMask; __ballot(rem != 0) != 0;)
         {
-            const int px = __builtin_ctz(rem);
-            const float4 v = s_px[px][blk];
-            const u32 a = __float_as_uint(v.w), b = s_pk2[px][blk];
-            float dist = 0.0f;
-            dist = dist + direction[0] * ((float)(int)(short)(a & 0xffffu) * A.w[0] - cen[0]);
-            dist = dist + direction[1] * ((float)(int)(short)(a >> 16) * A.w[1] - cen[1]);
-            dist = dist + direction[2] * ((float)(int)(short)(b & 0xffffu) * A.w[2] - cen[2]);
-            minDist = sseMin(minDist, dist);
-            maxDist = sseMax(maxDist, dist);
+            if (rem != 0)
+            {
+                const int px = __builtin_ctz(rem);
+                rem &= rem - 1u;
+                const float4 v = s_px[px][blk];
+                const u32 a = __float_as_uint(v.w), b = s_pk2[px][blk];
+                float dist = 0.0f;
+                dist = dist + direction[0] * ((float)(int)(short)(a & 0xffffu) * A.w[0] - cen[0]);
+                dist = dist + direction[1] * ((float)(int)(short)(a >> 16) * A.w[1] - cen[1]);
+                dist = dist + direction[2] * ((float)(int)(short)(b & 0xffffu) * A.w[2] - cen[2]);
+                minDist = sseMin(minDist, dist);
+                maxDist = sseMax(maxDist, dist);
+            }
         }
 #pragma unroll
         for (int ch = 0; ch < 3; ch++)
@@ -445,6 +460,16 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
             u.base[ch] = mn / A.w[ch];
             u.offset[ch] = (mx - mn) / A.w[ch];
         }
+    };
+    // the value sub-lane `src` (wave-uniform) of the quad holds
+    auto quadFrom = [&](float v, int src) -> float {
+        const u32 x = __float_as_uint(v);
+        u32 r;
+        if (src == 0) r = quadBcast<0>(x);
+        else if (src == 1) r = quadBcast<1>(x);
+        else if (src == 2) r = quadBcast<2>(x);
+        else r = quadBcast<3>(x);
+        return __uint_as_float(r);
     };
 
     // the single-subset (4-bit indexes) and the partitioned (3-bit) search are two instantiations of the same body, so
@@ -713,9 +738,19 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
             // mode loop of its group going, so every block of the GROUP needs the errors of every round in the group's set.
             const bool perBlockReplay = numModesHere == 1;
 
+            // the seeds of four subsets at a time: sub-lane t holds those of subset (t & 1) of partition (p & ~1) + (t >> 1)
+            Unfinished quadU;
+            float quadVs[3] = {0.0f, 0.0f, 0.0f};
             for (int p = 0; p < numPartitions; p++)
             {
                 const u32 partitionMask = partitioned ? (u32)__builtin_amdgcn_readfirstlane((int)T->partition2[p]) : 0u;
+                if (!partitioned)
+                    pcaSeeds(0xffffu, quadU, quadVs);
+                else if ((p & 1) == 0)
+                {
+                    const u32 pm = T->partition2[p + (tw >> 1)];
+                    pcaSeeds((tw & 1) ? pm : (~pm & 0xffffu), quadU, quadVs);
+                }
                 const bool lazy = !eagerNow;
                 __syncthreads(); // the previous partition's history has been read by everybody
                 PROF_COUNT(0, 1)
@@ -745,7 +780,16 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                     // the refiner's sums of the pre-weighted member pixels (EndpointRefiner.h:78-92) do not depend on the indexes:
                     // the PCA's first pass forms the same sums in the same order
                     float vsSubset[3];
-                    pcaSeeds(subsetMask, ufep, vsSubset);
+                    {
+                        const int src = partitioned ? (((p & 1) << 1) | subset) : tw;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                        {
+                            ufep.base[ch] = partitioned ? quadFrom(quadU.base[ch], src) : quadU.base[ch];
+                            ufep.offset[ch] = partitioned ? quadFrom(quadU.offset[ch], src) : quadU.offset[ch];
+                            vsSubset[ch] = partitioned ? quadFrom(quadVs[ch], src) : quadVs[ch];
+                        }
+                    }
 
                     // meta rounds of this subset that are dropped although the rounds known at their time did not say so (see the
                     // file header): per group, found after the last pass
@@ -756,6 +800,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                         float tv[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, tt = 0.0f, ts = 0.0f;
                         int refCount = 0; // contributions of the previous round
                         u32 myQa[3] = {0, 0, 0}, myQb[3] = {0, 0, 0}, myQc[3] = {0, 0, 0}; // the end points of this chain's rounds
+                        u32 myFp[3] = {0, 0, 0}; // ... and one word that mixes the three: equal rounds have equal fingerprints
                         u32 myXb = 0, myInv = 0;
                         u32 rv = 0xfffu & ~abortMask;
                         bool usableNow = false;
@@ -865,6 +910,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     myXb |= qc << (2 * refinePass);
                                 myInv |= (invert ? 1u : 0u) << refinePass;
                             }
+                            // (zeros -- a round the options leave out -- have the fingerprint zero)
+                            const u32 fp = qa ^ ((qb << 13) | (qb >> 19)) ^ (qc * 0x9E3779B1u);
 #pragma unroll
                             for (int k = 0; k < 3; k++) // (no dynamic index: the words stay registers)
                                 if (k == refinePass)
@@ -872,6 +919,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     myQa[k] = qa;
                                     myQb[k] = qb;
                                     myQc[k] = qc;
+                                    myFp[k] = fp;
                                 }
 
                             bool needError = true; // wave-uniform
@@ -891,19 +939,21 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 
                             // ---- duplicate-round test against the meta rounds that are known now: the earlier tweaks' rounds up to
                             // this pass (DPP from the quad's lower sub-lanes) and this chain's earlier rounds.  Only a group whose
-                            // eight blocks ALL repeat an earlier round skips the round, so the first of the three words is
-                            // compared alone, and the other two only if some group matches in it everywhere.
+                            // eight blocks ALL repeat an earlier round skips the round, so a fingerprint of the three words is
+                            // compared, and the words themselves only if some group matches in it everywhere.
                             bool same = false;
+#ifndef CVTT_BC6H_X_NODUP // (timing experiment: invalid output)
 #pragma unroll
                             for (int r2 = 0; r2 < 3; r2++)
                             {
                                 if (r2 > refinePass)
                                     continue;
-                                const u32 o0 = quadBcast<0>(myQa[r2]), o1 = quadBcast<1>(myQa[r2]), o2 = quadBcast<2>(myQa[r2]);
-                                same = same | ((tw > 0) & (o0 == qa)) | ((tw > 1) & (o1 == qa)) | ((tw > 2) & (o2 == qa));
+                                const u32 o0 = quadBcast<0>(myFp[r2]), o1 = quadBcast<1>(myFp[r2]), o2 = quadBcast<2>(myFp[r2]);
+                                same = same | ((tw > 0) & (o0 == fp)) | ((tw > 1) & (o1 == fp)) | ((tw > 2) & (o2 == fp));
                                 if (r2 < refinePass)
-                                    same = same | (myQa[r2] == qa);
+                                    same = same | (myFp[r2] == fp);
                             }
+#endif
                             bool dropped = false;
                             {
                                 u64 g = __ballot(same && act);
@@ -1018,6 +1068,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                         // ---- the rounds that were not known in time: (t' < tw, r' > r) ----
                         {
                             bool anyLate = false; // a round of this chain repeats a LATER pass of a lower tweak
+#ifndef CVTT_BC6H_X_NODUP
 #pragma unroll
                             for (int r = 0; r < 2; r++)
                             {
@@ -1025,11 +1076,12 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 #pragma unroll
                                 for (int r2 = r + 1; r2 < 3; r2++)
                                 {
-                                    const bool lower = lowerSubLaneHolds(tw, myQa[r], myQb[r], myQc[r], myQa[r2], myQb[r2], myQc[r2]);
-                                    s2 = s2 | lower;
+                                    const u32 o0 = quadBcast<0>(myFp[r2]), o1 = quadBcast<1>(myFp[r2]), o2 = quadBcast<2>(myFp[r2]);
+                                    s2 = s2 | ((tw > 0) & (o0 == myFp[r])) | ((tw > 1) & (o1 == myFp[r])) | ((tw > 2) & (o2 == myFp[r]));
                                 }
                                 anyLate = anyLate || (s2 && twActive && r < numRefineRounds);
                             }
+#endif
                             u32 newDrop = 0; // per group: meta rounds that ran although all eight blocks repeat an earlier round
 #ifdef CVTT_BC6H_DBG_NOLATE
                             anyLate = false;
@@ -1227,18 +1279,42 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                 // ---- delta-coding legality + commit, BC67.cpp:2914-2986 (the four lanes of a quad do the same) ----
                 if (!usable0)
                     continue;
+#ifdef CVTT_BC6H_X_NOCOMMIT // (timing experiment: invalid output)
+                if (p != 31)
+                    continue;
+#endif
                 const int numMeta1 = partitioned ? 12 : 1;
-                // cheapest valid subset-1 round: no combination with meta0 can beat the best unless this one does
+                // cheapest valid subset-1 round: no combination with meta0 can beat the best unless this one does.  Every sub-lane
+                // looks at the three rounds of its own chain, the quad takes the minimum (sseMin-free: no NaN among errors that count,
+                // and a NaN never passes the `<` of the commit either way).
                 float minErr1 = 0.0f;
                 if (partitioned)
                 {
                     minErr1 = FLT_MAX;
-                    for (int m = 0; m < 12; m++)
+#pragma unroll
+                    for (int r = 0; r < 3; r++)
                     {
-                        const float e = errAt(m, 1);
-                        if (((roundValid1 >> m) & 1u) && e < minErr1)
+                        const float e = errAt(3 * tw + r, 1);
+                        if (((roundValid1 >> (3 * tw + r)) & 1u) && e < minErr1)
                             minErr1 = e;
                     }
+                    float o = __uint_as_float((u32)__builtin_amdgcn_mov_dpp((int)__float_as_uint(minErr1), 0xb1, 0xf, 0xf, true));
+                    minErr1 = o < minErr1 ? o : minErr1;
+                    o = __uint_as_float((u32)__builtin_amdgcn_mov_dpp((int)__float_as_uint(minErr1), 0x4e, 0xf, 0xf, true));
+                    minErr1 = o < minErr1 ? o : minErr1;
+                }
+                // Can ANY round of subset 0 of any block of the wave beat its block's best with that?  Each sub-lane asks for its own
+                // three rounds; when nobody can, the loop below would pass every meta0 without touching anything (its first test).
+                {
+                    bool mine = false;
+#pragma unroll
+                    for (int r = 0; r < 3; r++)
+                    {
+                        const float e0 = errAt(3 * tw + r, 0);
+                        mine = mine | ((((roundValid0 >> (3 * tw + r)) & 1u) != 0) & ((partitioned ? e0 + minErr1 : e0) < bestError));
+                    }
+                    if (__ballot(mine) == 0)
+                        continue;
                 }
                 for (int meta0 = 0; meta0 < 12; meta0++)
                 {
@@ -1355,7 +1431,9 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
             }
         }
     };
+#ifndef CVTT_BC6H_X_NOSINGLE // (timing experiment: invalid output)
     searchAll(std::false_type{});
+#endif
     searchAll(std::true_type{});
 
     // ---- the winner's indexes, selected again from its end points.  A round's indexes are a function of its quantised end
