@@ -234,19 +234,6 @@ __device__ __forceinline__ u32 quadBcast(u32 v)
 {
     return (u32)__builtin_amdgcn_mov_dpp((int)v, Q * 0x55, 0xf, 0xf, true);
 }
-// Does one of the LOWER sub-lanes of the quad hold the three words (wa, wb, wc) in (ma, mb, mc)?  Every DPP move is executed by
-// all lanes, unconditionally, before anything is compared: a cross-lane read inside a short-circuit `&&` runs with the lanes
-// that failed the first comparison switched off -- and a DPP read of a switched-off lane returns zero.
-__device__ __forceinline__ bool lowerSubLaneHolds(int tw, u32 wa, u32 wb, u32 wc, u32 ma, u32 mb, u32 mc)
-{
-    const u32 a0 = quadBcast<0>(ma), b0 = quadBcast<0>(mb), c0 = quadBcast<0>(mc);
-    const u32 a1 = quadBcast<1>(ma), b1 = quadBcast<1>(mb), c1 = quadBcast<1>(mc);
-    const u32 a2 = quadBcast<2>(ma), b2 = quadBcast<2>(mb), c2 = quadBcast<2>(mc);
-    const bool e0 = (a0 == wa) & (b0 == wb) & (c0 == wc);
-    const bool e1 = (a1 == wa) & (b1 == wb) & (c1 == wc);
-    const bool e2 = (a2 == wa) & (b2 == wb) & (c2 == wc);
-    return ((tw > 0) & e0) | ((tw > 1) & e1) | ((tw > 2) & e2);
-}
 // meta round m = 3 * tweak + refine pass: its tweak (m = 0 ... 11)
 __device__ __forceinline__ int tweakOf(int m) { return (m * 11) >> 5; }
 } // namespace
@@ -483,8 +470,6 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
         const float maxValue = (float)(indexRange - 1);
         const int weightRcp = partitioned ? 4681 : 2185; // g_weightReciprocals[8], [16]
         const float rcpMaxIndex = T->rcpMaxIndex[indexBits];
-        const float tf0 = T->tweakFactors[indexBits - 2][tw][0];
-        const float tf1 = T->tweakFactors[indexBits - 2][tw][1];
 
         // ---- the quantised end points of a round as kept in LDS ----
         // two-subset precisions (<= 11 bits): two words per round -- r | g << 11 | b[9:0] << 22 per end point -- plus bit 10 of the
@@ -543,6 +528,21 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
             return ((iw >> (m + 5 * tweakOf(m))) & 1u) != 0; // byte t, bit r: 8 t + r = m + 5 t
         };
         auto errAt = [&](int m, int s) -> float & { return s_err[s][m][blk]; };
+        // Do the three words (wa, wb, wc) of a round of the lane's chain equal those of one of the meta rounds (t' < tw, r2 <= rOther)
+        // or (tw, r2 < rOwn) of subset s -- as the history in LDS has them?  (The exact form of the duplicate test; the rounds'
+        // words were stored by the lanes that own them earlier in this pass, and a wave's LDS operations complete in order.)
+        auto earlierRoundHolds = [&](int s, u32 wa, u32 wb, u32 wc, int rOther, int rOwn) -> bool {
+            bool hit = false;
+            for (int t2 = 0; t2 < 4; t2++)
+                for (int r2 = 0; r2 < 3; r2++)
+                {
+                    const bool wanted = (t2 < tw && r2 <= rOther) || (t2 == tw && r2 < rOwn);
+                    u32 oa, ob, oc;
+                    loadWords(s, 3 * t2 + r2, oa, ob, oc);
+                    hit = hit | (wanted & (oa == wa) & (ob == wb) & (oc == wc));
+                }
+            return hit;
+        };
 
         // ---- one round's index selection set up from its (un-swapped) quantised end points ----
         struct Selector
@@ -637,6 +637,34 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
             const float l2 = lf[2] * A.w[2];
             float be = 0.0f;
             int bi = 0;
+#ifdef CVTT_BC6H_PK_SCAN
+            // two interpolants per packed instruction: the same IEEE operations on the same values (v_pk_add_f32 / v_pk_mul_f32
+            // round each half like the scalar instruction; no contraction), so the errors are bit-identical
+            typedef float pk2 __attribute__((ext_vector_type(2)));
+            const pk2 L0 = {l0, l0}, L1 = {l1, l1}, L2 = {l2, l2};
+#pragma unroll
+            for (int i = 0; i < indexRange; i += 2)
+            {
+                const pk2 I0 = {S.iw[i][0], S.iw[i + 1][0]}, I1 = {S.iw[i][1], S.iw[i + 1][1]}, I2 = {S.iw[i][2], S.iw[i + 1][2]};
+                pk2 d = L0 - I0;
+                pk2 e = d * d;
+                d = L1 - I1;
+                e = e + d * d;
+                d = L2 - I2;
+                e = e + d * d;
+                if (i == 0)
+                    be = e.x;
+                else
+                {
+                    const bool lt = e.x < be;
+                    bi = lt ? i : bi;
+                    be = __builtin_fminf(be, e.x);
+                }
+                const bool lt2 = e.y < be;
+                bi = lt2 ? i + 1 : bi;
+                be = __builtin_fminf(be, e.y);
+            }
+#else
 #pragma unroll
             for (int i = 0; i < indexRange; i++)
             {
@@ -657,6 +685,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                     be = __builtin_fminf(be, e);
                 }
             }
+#endif
             return bi;
         };
         // error of the pixel reconstructed with raw index `raw` (BCCommon.h:45-79)
@@ -768,29 +797,15 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                     if (subset == 1 && !usable0)
                         break;
                     const int fixupIndex = __builtin_amdgcn_readfirstlane((subset == 0) ? 0 : (int)T->anchor2[p]);
-                    // the anchor pixel of the subset (its index decides the swap of a round's end points, BC67.cpp:2525-2547)
-                    u32 fa, fb;
-                    float fixLf[3];
-                    pixLoad(fixupIndex, fa, fb, fixLf);
+                    // (the anchor pixel of the subset -- its index decides the swap of a round's end points, BC67.cpp:2525-2547 -- is
+                    // loaded where a round scans it: five registers less across the passes)
                     const int count = __popc(subsetMask);
                     const float wRcp = T->rcpTable[count];
                     const float wCount = (float)count;
 
-                    Unfinished ufep;
-                    // the refiner's sums of the pre-weighted member pixels (EndpointRefiner.h:78-92) do not depend on the indexes:
-                    // the PCA's first pass forms the same sums in the same order
-                    float vsSubset[3];
-                    {
-                        const int src = partitioned ? (((p & 1) << 1) | subset) : tw;
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++)
-                        {
-                            ufep.base[ch] = partitioned ? quadFrom(quadU.base[ch], src) : quadU.base[ch];
-                            ufep.offset[ch] = partitioned ? quadFrom(quadU.offset[ch], src) : quadU.offset[ch];
-                            vsSubset[ch] = partitioned ? quadFrom(quadVs[ch], src) : quadVs[ch];
-                        }
-                    }
-
+                    // the seeds (and the refiner's sums of the pre-weighted member pixels, EndpointRefiner.h:78-92, which do not depend on
+                    // the indexes: the PCA's first pass forms the same sums in the same order) sit in sub-lane `seedSrc` of the quad
+                    const int seedSrc = partitioned ? (((p & 1) << 1) | subset) : tw;
                     // meta rounds of this subset that are dropped although the rounds known at their time did not say so (see the
                     // file header): per group, found after the last pass
                     u32 forcedDrop = 0;
@@ -799,9 +814,12 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                         // EndpointRefiner<3> refiners[2]: fresh (zero in the canonical build) per tweak
                         float tv[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, tt = 0.0f, ts = 0.0f;
                         int refCount = 0; // contributions of the previous round
-                        u32 myQa[3] = {0, 0, 0}, myQb[3] = {0, 0, 0}, myQc[3] = {0, 0, 0}; // the end points of this chain's rounds
-                        u32 myFp[3] = {0, 0, 0}; // ... and one word that mixes the three: equal rounds have equal fingerprints
+                        // one word that mixes the three words of a round's end points (equal rounds have equal fingerprints); the words
+                        // themselves are read back from the history in LDS in the rare cases that need them
+                        u32 myFp[3] = {0, 0, 0};
                         u32 myXb = 0, myInv = 0;
+                        if (partitioned)
+                            s_xb[subset][blk][tw] = 0; // (rounds that have not run yet read as zeros, like the words of the rounds left out)
                         u32 rv = 0xfffu & ~abortMask;
                         bool usableNow = false;
                         u32 candNow = 0;
@@ -814,6 +832,17 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             if (refinePass >= numRefineRounds)
                                 break; // (every lane's round is left out: the zero end points below are written once, before the loop)
 
+                            // the seeds of this subset from the sub-lane that computed them (DPP: executed by all lanes, before any branch)
+                            float seedBase[3] = {0.0f, 0.0f, 0.0f}, seedOffset[3] = {0.0f, 0.0f, 0.0f};
+                            if (refinePass == 0)
+                            {
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++)
+                                {
+                                    seedBase[ch] = partitioned ? quadFrom(quadU.base[ch], seedSrc) : quadU.base[ch];
+                                    seedOffset[ch] = partitioned ? quadFrom(quadU.offset[ch], seedSrc) : quadU.offset[ch];
+                                }
+                            }
                             u32 qa = 0, qb = 0, qc = 0;
                             Selector S;
                             int fixRaw = 0;
@@ -825,13 +854,15 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 int epCS[2][3];
                                 if (refinePass == 0)
                                 {
+                                    const float tf0 = T->tweakFactors[indexBits - 2][tw][0];
+                                    const float tf1 = T->tweakFactors[indexBits - 2][tw][1];
 #pragma unroll
                                     for (int ch = 0; ch < 3; ch++)
                                     {
                                         // FinishHDRSigned / Unsigned, UnfinishedEndpoints.h:39-75
                                         const float lo = SIGNED ? -31743.0f : 0.0f;
-                                        const float f0 = sseMax(sseMin(ufep.base[ch] + ufep.offset[ch] * tf0, 31743.0f), lo);
-                                        const float f1 = sseMax(sseMin(ufep.base[ch] + ufep.offset[ch] * tf1, 31743.0f), lo);
+                                        const float f0 = sseMax(sseMin(seedBase[ch] + seedOffset[ch] * tf0, 31743.0f), lo);
+                                        const float f1 = sseMax(sseMin(seedBase[ch] + seedOffset[ch] * tf1, 31743.0f), lo);
                                         epCS[0][ch] = (int)rintf(f0);
                                         epCS[1][ch] = (int)rintf(f1);
                                     }
@@ -887,7 +918,12 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                         }
                                     }
                                 setupSelector(unq, fin, S);
-                                fixRaw = rawIndexOf(S, fa, fb, fixLf);
+                                {
+                                    u32 fa, fb;
+                                    float fixLf[3];
+                                    pixLoad(fixupIndex, fa, fb, fixLf);
+                                    fixRaw = rawIndexOf(S, fa, fb, fixLf);
+                                }
                                 invert = (indexRange / 2 - 1) < fixRaw;
                                 if (invert)
                                 {
@@ -907,7 +943,10 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 if (!partitioned)
                                     s_epq[1][metaRound][0][blk] = qc;
                                 if (partitioned)
+                                {
                                     myXb |= qc << (2 * refinePass);
+                                    s_xb[subset][blk][tw] = (uint8_t)myXb;
+                                }
                                 myInv |= (invert ? 1u : 0u) << refinePass;
                             }
                             // (zeros -- a round the options leave out -- have the fingerprint zero)
@@ -916,9 +955,6 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             for (int k = 0; k < 3; k++) // (no dynamic index: the words stay registers)
                                 if (k == refinePass)
                                 {
-                                    myQa[k] = qa;
-                                    myQb[k] = qb;
-                                    myQc[k] = qc;
                                     myFp[k] = fp;
                                 }
 
@@ -965,17 +1001,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 #endif
                                 if ((g & 0x0000000f0000000full) != 0)
                                 {
-                                    same = false;
-#pragma unroll
-                                    for (int r2 = 0; r2 < 3; r2++)
-                                    {
-                                        if (r2 > refinePass)
-                                            continue;
-                                        const bool lower = lowerSubLaneHolds(tw, qa, qb, qc, myQa[r2], myQb[r2], myQc[r2]);
-                                        same = same | lower;
-                                        if (r2 < refinePass)
-                                            same = same | ((myQa[r2] == qa) & (myQb[r2] == qb) & (myQc[r2] == qc));
-                                    }
+                                    __syncthreads(); // (the other sub-lanes' words of this pass are in LDS)
+                                    same = earlierRoundHolds(subset, qa, qb, qc, refinePass, refinePass);
                                     same = same && act;
                                     // which rounds (tweak t2, this pass) does the lane's group drop?
                                     const u32 gb = groupBits(__ballot(same), lane);
@@ -1037,20 +1064,25 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                             refCount++;
                                         }
                                     }
-                                    if (refinePass != numRefineRounds - 1)
-                                    {
-#pragma unroll
-                                        for (int ch = 0; ch < 3; ch++)
-                                            vs[ch] = vsSubset[ch];
-                                    }
                                     errAt(metaRound, subset) = subsetError;
+                                }
+                                if (refinePass != numRefineRounds - 1)
+                                {
+                                    // (DPP outside the `if (run)`: every lane executes it)
+#pragma unroll
+                                    for (int ch = 0; ch < 3; ch++)
+                                    {
+                                        const float v = partitioned ? quadFrom(quadVs[ch], seedSrc) : quadVs[ch];
+                                        if (run)
+                                            vs[ch] = v;
+                                    }
                                 }
                             }
                         }
                         // the spare bits and the swap flags of this chain's rounds, and -- once per run -- zeros for the rounds the
                         // options leave out
-                        if (partitioned)
-                            s_xb[subset][blk][tw] = (uint8_t)myXb;
+                        if (partitioned && !twActive)
+                            s_xb[subset][blk][tw] = 0;
                         s_inv[subset][blk][tw] = (uint8_t)myInv;
                         if (abortMask != 0)
                         {
@@ -1096,18 +1128,13 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             if (__ballot(anyLate) != 0)
                             {
                                 // the complete test of rounds 0 and 1 of every chain: all three words, every earlier meta round
-#pragma unroll
+                                __syncthreads();
+#pragma unroll 1
                                 for (int r = 0; r < 2; r++)
                                 {
-                                    bool full = false;
-#pragma unroll
-                                    for (int r2 = 0; r2 < 3; r2++)
-                                    {
-                                        const bool lower = lowerSubLaneHolds(tw, myQa[r], myQb[r], myQc[r], myQa[r2], myQb[r2], myQc[r2]);
-                                        full = full | lower;
-                                        if (r2 < r)
-                                            full = full | ((myQa[r2] == myQa[r]) & (myQb[r2] == myQb[r]) & (myQc[r2] == myQc[r]));
-                                    }
+                                    u32 wa, wb, wc;
+                                    loadWords(subset, 3 * tw + r, wa, wb, wc);
+                                    bool full = earlierRoundHolds(subset, wa, wb, wc, 2, r);
                                     full = full && twActive && r < numRefineRounds;
                                     const u32 gb = groupBits(__ballot(full), lane);
 #ifdef CVTT_BC6H_TRACE
