@@ -1343,6 +1343,129 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                     if (__ballot(mine) == 0)
                         continue;
                 }
+                if (numModesHere == 1)
+                {
+                    // ---- ONE mode at this precision (6, 7, 9, 10 bits; every single-subset precision): no block looks at its group
+                    // mates in the commit loop -- a pair is committed iff it beats the block's best and is legal -- so what the loop
+                    // leaves behind is the legal pair with the smallest combined error below the best, the first such pair in
+                    // (meta0, meta1) order (every commit needs a strictly smaller error).  Sub-lane t looks for it among the pairs
+                    // of ITS chain's subset-0 rounds (meta0 = 3t ... 3t+2: consecutive in that order), the quad takes the smallest,
+                    // the lower sub-lane on equal errors. ----
+                    const u32 mw = modeW0;
+                    const bool transformed = (mw & 16u) != 0;
+                    const int mask = (1 << aPrec) - 1;
+                    auto fitsOne = [&](int v, int base, int ch) -> bool {
+                        const int lost = (int)((mw >> (8 + 8 * ch)) & 31u);
+                        const int d16 = (int)(short)(unsigned short)(v - base);
+                        const int delta = (int)(short)(unsigned short)((u32)d16 << lost) >> lost;
+                        return ((delta + base) & mask & 0xffff) == (v & mask & 0xffff);
+                    };
+                    float localBest = bestError;
+                    int localPair = -1; // meta0 * 16 + meta1
+#pragma unroll 1
+                    for (int r = 0; r < 3; r++)
+                    {
+                        const int m0 = 3 * tw + r;
+                        const float err0 = errAt(m0, 0);
+                        bool cand = (((roundValid0 >> m0) & 1u) != 0) & ((partitioned ? err0 + minErr1 : err0) < localBest);
+                        if (__ballot(cand) == 0)
+                            continue;
+                        int e0[2][3];
+                        loadEPQ(0, m0, e0);
+                        cand = cand & ownDeltaFits(e0, mw, aPrec);
+                        if (!partitioned)
+                        {
+                            if (cand)
+                            {
+                                localBest = err0;
+                                localPair = m0 * 16;
+                            }
+                            continue;
+                        }
+                        if (__ballot(cand) == 0)
+                            continue;
+#pragma unroll 1
+                        for (int m1 = 0; m1 < 12; m1++)
+                        {
+                            const float c = err0 + errAt(m1, 1);
+                            bool ok = cand & (((roundValid1 >> m1) & 1u) != 0) & (c < localBest);
+                            if (__ballot(ok) == 0)
+                                continue;
+                            if (transformed)
+                            {
+                                int x[2][3];
+                                loadEPQ(1, m1, x);
+#pragma unroll
+                                for (int epi = 0; epi < 2; epi++)
+#pragma unroll
+                                    for (int ch = 0; ch < 3; ch++)
+                                        ok = ok & fitsOne(x[epi][ch], e0[0][ch], ch);
+                            }
+                            if (ok)
+                            {
+                                localBest = c;
+                                localPair = m0 * 16 + m1;
+                            }
+                        }
+                    }
+                    // the quad's winner (all four lanes end up with the same)
+                    float wb = __uint_as_float(quadBcast<0>(__float_as_uint(localBest)));
+                    int wp = (int)quadBcast<0>((u32)localPair);
+#define CVTT_QUAD_STEP(Q) { const float ob = __uint_as_float(quadBcast<Q>(__float_as_uint(localBest))); const int op = (int)quadBcast<Q>((u32)localPair); \
+                            const bool lt = ob < wb; wb = lt ? ob : wb; wp = lt ? op : wp; }
+                    CVTT_QUAD_STEP(1) CVTT_QUAD_STEP(2) CVTT_QUAD_STEP(3)
+#undef CVTT_QUAD_STEP
+                    const bool improved = (wp >= 0) & (wb < bestError);
+                    if (__ballot(improved) != 0)
+                    {
+                        if (improved)
+                        {
+                            const int m0 = wp >> 4, m1 = wp & 15;
+                            int e0[2][3], e1[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                            loadEPQ(0, m0, e0);
+                            if (partitioned)
+                                loadEPQ(1, m1, e1);
+                            int enc[2][2][3];
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++)
+                            {
+                                enc[0][0][ch] = e0[0][ch];
+                                enc[0][1][ch] = e0[1][ch];
+                                enc[1][0][ch] = partitioned ? e1[0][ch] : 0;
+                                enc[1][1][ch] = partitioned ? e1[1][ch] : 0;
+                                if (transformed)
+                                {
+                                    // the deltas the mode stores (they fit: the pair is legal)
+                                    const int lost = (int)((mw >> (8 + 8 * ch)) & 31u);
+#pragma unroll
+                                    for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+                                        for (int epi = 0; epi < 2; epi++)
+                                        {
+                                            if ((sb == 0 && epi == 0) || (sb == 1 && !partitioned))
+                                                continue;
+                                            const int d16 = (int)(short)(unsigned short)(enc[sb][epi][ch] - enc[0][0][ch]);
+                                            enc[sb][epi][ch] = (int)(short)(unsigned short)((u32)d16 << lost) >> lost;
+                                        }
+                                }
+                            }
+                            bestError = wb;
+                            bestMode = (int)(mw & 15u);
+                            bestPartition = p;
+                            bestEP[0] = ((u32)enc[0][0][0] & 0xffffu) | ((u32)enc[0][0][1] << 16);
+                            bestEP[1] = ((u32)enc[0][0][2] & 0xffffu) | ((u32)enc[0][1][0] << 16);
+                            bestEP[2] = ((u32)enc[0][1][1] & 0xffffu) | ((u32)enc[0][1][2] << 16);
+                            if (partitioned)
+                            {
+                                bestEP[3] = ((u32)enc[1][0][0] & 0xffffu) | ((u32)enc[1][0][1] << 16);
+                                bestEP[4] = ((u32)enc[1][0][2] & 0xffffu) | ((u32)enc[1][1][0] << 16);
+                                bestEP[5] = ((u32)enc[1][1][1] & 0xffffu) | ((u32)enc[1][1][2] << 16);
+                            }
+                            bestSwap = (wasSwapped(0, m0) ? 1u : 0u) | ((partitioned && wasSwapped(1, m1)) ? 2u : 0u);
+                        }
+                    }
+                    continue;
+                }
                 for (int meta0 = 0; meta0 < 12; meta0++)
                 {
                     const bool valid0 = ((roundValid0 >> meta0) & 1u) != 0;
