@@ -216,8 +216,9 @@ __device__ __forceinline__ int reconstructFrom(int base, int diff, int weight)
     }
     else
     {
-        const u32 p = (u32)(DYN ? madI24(weight, diff, base) : mad24(weight, diff, base)) >> 6; // e < 2^16, weight <= 64: 0 <= 64 e0 + w (e1 - e0) + 32 < 2^22 + 32
-        return (int)(mulU24(p & 0xffffu, 31u) >> 6);   // UnscaleHDRValueUnsigned
+        // e < 2^16, weight <= 64: 0 <= 64 e0 + w (e1 - e0) + 32 < 2^22 + 32, so ">> 6 & 0xffff" is one v_bfe_u32 (and the mask never bites)
+        const u32 p = __builtin_amdgcn_ubfe((u32)(DYN ? madI24(weight, diff, base) : mad24(weight, diff, base)), 6u, 16u);
+        return (int)(mulU24(p, 31u) >> 6);   // UnscaleHDRValueUnsigned
     }
 }
 template <bool SIGNED>
@@ -243,7 +244,10 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                                                          const CvttBc6hArgs A, const CvttDeviceTables *__restrict__ T)
 {
     // ---- everything a wave knows about its 16 blocks and the partition it is searching: 10 KB of LDS ----
-    __shared__ float4 s_px[16][16];        // [pixel][block]: the three linear values (TwosCLHalfToFloat) and, in .w, red | green << 16 (2CL)
+    // [pixel][block]: .w = red | green << 16 (2CL integers); .xyz = unsigned format: the three PRE-WEIGHTED values ((float)value *
+    // channel weight: what the PCA and the refiner add up -- the linear value is one v_cvt_f32_f16 away); signed format: the three
+    // LINEAR values (TwosCLHalfToFloat of a negative 2CL value is ten instructions, the pre-weighted value three)
+    __shared__ float4 s_px[16][16];
     __shared__ u32 s_pk2[16][16];          // [pixel][block]: blue (2CL)
     __shared__ u32 s_epq[2][12][2][16];    // [subset][meta round][word][block]: the quantised end points of a round (layout: packEPQ)
     __shared__ float s_err[2][12][16];     // [subset][meta round][block]
@@ -256,9 +260,13 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
     const u32 blockIndex = blockIdx.x * 16u + (u32)blk;
     const bool valid = blockIndex < A.numBlocks;
 
+    // Does any pixel value of the wave have a zero exponent field (the patterns TwosCLHalfToFloat halves)?  Almost never, and then
+    // the three fix-ups per pixel are skipped (unsigned format; wave-uniform)
+    bool pixelFixup = true;
     // ---- load + clamp to the "2CL" domain (BC67.cpp:2691-2715); sub-lane t takes pixels t, t + 4, t + 8, t + 12 ----
     {
         const uint2 *src = reinterpret_cast<const uint2 *>(blocks + (size_t)(valid ? blockIndex : 0u) * 128u);
+        bool zeroExp = false;
 #pragma unroll
         for (int j = 0; j < 4; j++)
         {
@@ -280,21 +288,64 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                     x = x < 0 ? 0 : x;
                 x = x > 31743 ? 31743 : x;
                 v[ch] = x;
-                l[ch] = twosCLHalfToFloat<SIGNED>(x);
+                l[ch] = SIGNED ? twosCLHalfToFloat<SIGNED>(x) : (float)x * A.w[ch];
+                zeroExp = zeroExp | ((x & 0x7c00) == 0);
             }
             s_px[px][blk] = make_float4(l[0], l[1], l[2], __uint_as_float(((u32)v[0] & 0xffffu) | ((u32)v[1] << 16)));
             s_pk2[px][blk] = (u32)v[2] & 0xffffu;
         }
+        pixelFixup = __ballot(zeroExp) != 0;
     }
     __syncthreads();
-    // pixel px of the lane's block: a = red | green << 16, b = blue (2CL integers), lf = the three linear values
-    auto pixLoad = [&](int px, u32 &a, u32 &b, float (&lf)[3]) {
+    // pixel px of the lane's block: a = red | green << 16, b = blue (2CL integers), lf = the three linear values (BC67.cpp:2711),
+    // pw = the three pre-weighted values (BCCommon PreWeightPixelsHDR)
+    auto pixLoad = [&](int px, u32 &a, u32 &b, float (&lf)[3], float (&pw)[3]) {
         const float4 v = s_px[px][blk];
-        lf[0] = v.x;
-        lf[1] = v.y;
-        lf[2] = v.z;
         a = __float_as_uint(v.w);
         b = s_pk2[px][blk];
+        if (SIGNED)
+        {
+            lf[0] = v.x;
+            lf[1] = v.y;
+            lf[2] = v.z;
+            pw[0] = (float)(int)(short)(a & 0xffffu) * A.w[0];
+            pw[1] = (float)(int)(short)(a >> 16) * A.w[1];
+            pw[2] = (float)(int)(short)(b & 0xffffu) * A.w[2];
+        }
+        else
+        {
+            pw[0] = v.x;
+            pw[1] = v.y;
+            pw[2] = v.z;
+            const u32 c[3] = {a & 0xffffu, a >> 16, b & 0xffffu};
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+                lf[ch] = __half2float(__ushort_as_half((unsigned short)c[ch]));
+            if (pixelFixup)
+            {
+                asm volatile("" ::: "memory"); // keep this ONE branch: as selects it costs what it is meant to save
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                    lf[ch] = (c[ch] & 0x7c00u) ? lf[ch] : lf[ch] * 0.5f;
+            }
+        }
+    };
+    // ... the pre-weighted values alone (PCA)
+    auto pixPW = [&](int px, float (&pw)[3]) {
+        const float4 v = s_px[px][blk];
+        if (SIGNED)
+        {
+            const u32 a = __float_as_uint(v.w), b = s_pk2[px][blk];
+            pw[0] = (float)(int)(short)(a & 0xffffu) * A.w[0];
+            pw[1] = (float)(int)(short)(a >> 16) * A.w[1];
+            pw[2] = (float)(int)(short)(b & 0xffffu) * A.w[2];
+        }
+        else
+        {
+            pw[0] = v.x;
+            pw[1] = v.y;
+            pw[2] = v.z;
+        }
     };
 
     const int numTweakRounds = A.seedPoints < 1 ? 1 : (A.seedPoints > 4 ? 4 : A.seedPoints);
@@ -354,11 +405,11 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
             {
                 const int px = __builtin_ctz(rem);
                 rem &= rem - 1u;
-                const float4 v = s_px[px][blk];
-                const u32 a = __float_as_uint(v.w), b = s_pk2[px][blk];
-                cen[0] = cen[0] + (float)(int)(short)(a & 0xffffu) * A.w[0];
-                cen[1] = cen[1] + (float)(int)(short)(a >> 16) * A.w[1];
-                cen[2] = cen[2] + (float)(int)(short)(b & 0xffffu) * A.w[2];
+                float pw[3];
+                pixPW(px, pw);
+                cen[0] = cen[0] + pw[0];
+                cen[1] = cen[1] + pw[1];
+                cen[2] = cen[2] + pw[2];
                 count = count + 1.0f;
             }
         }
@@ -376,11 +427,11 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
             {
                 const int px = __builtin_ctz(rem);
                 rem &= rem - 1u;
-                const float4 v = s_px[px][blk];
-                const u32 a = __float_as_uint(v.w), b = s_pk2[px][blk];
-                const float d0 = (float)(int)(short)(a & 0xffffu) * A.w[0] - cen[0];
-                const float d1 = (float)(int)(short)(a >> 16) * A.w[1] - cen[1];
-                const float d2 = (float)(int)(short)(b & 0xffffu) * A.w[2] - cen[2];
+                float pw[3];
+                pixPW(px, pw);
+                const float d0 = pw[0] - cen[0];
+                const float d1 = pw[1] - cen[1];
+                const float d2 = pw[2] - cen[2];
                 cov[0] = cov[0] + d0 * d0;
                 cov[1] = cov[1] + d1 * d0;
                 cov[2] = cov[2] + d1 * d1;
@@ -429,12 +480,12 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
             {
                 const int px = __builtin_ctz(rem);
                 rem &= rem - 1u;
-                const float4 v = s_px[px][blk];
-                const u32 a = __float_as_uint(v.w), b = s_pk2[px][blk];
+                float pw[3];
+                pixPW(px, pw);
                 float dist = 0.0f;
-                dist = dist + direction[0] * ((float)(int)(short)(a & 0xffffu) * A.w[0] - cen[0]);
-                dist = dist + direction[1] * ((float)(int)(short)(a >> 16) * A.w[1] - cen[1]);
-                dist = dist + direction[2] * ((float)(int)(short)(b & 0xffffu) * A.w[2] - cen[2]);
+                dist = dist + direction[0] * (pw[0] - cen[0]);
+                dist = dist + direction[1] * (pw[1] - cen[1]);
+                dist = dist + direction[2] * (pw[2] - cen[2]);
                 minDist = sseMin(minDist, dist);
                 maxDist = sseMax(maxDist, dist);
             }
@@ -920,8 +971,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 setupSelector(unq, fin, S);
                                 {
                                     u32 fa, fb;
-                                    float fixLf[3];
-                                    pixLoad(fixupIndex, fa, fb, fixLf);
+                                    float fixLf[3], fixPw[3];
+                                    pixLoad(fixupIndex, fa, fb, fixLf, fixPw);
                                     fixRaw = rawIndexOf(S, fa, fb, fixLf);
                                 }
                                 invert = (indexRange / 2 - 1) < fixRaw;
@@ -950,7 +1001,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 myInv |= (invert ? 1u : 0u) << refinePass;
                             }
                             // (zeros -- a round the options leave out -- have the fingerprint zero)
-                            const u32 fp = qa ^ ((qb << 13) | (qb >> 19)) ^ (qc * 0x9E3779B1u);
+                            const u32 fp = qa ^ ((qb << 13) | (qb >> 19)) ^ ((qc << 7) | (qc >> 25)) ^ (qc << 21);
 #pragma unroll
                             for (int k = 0; k < 3; k++) // (no dynamic index: the words stay registers)
                                 if (k == refinePass)
@@ -1046,8 +1097,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     {
                                         const int px = __builtin_ctz(rem);
                                         u32 a, b;
-                                        float lfp[3];
-                                        pixLoad(px, a, b, lfp);
+                                        float lfp[3], pwp[3];
+                                        pixLoad(px, a, b, lfp, pwp);
                                         // (the anchor's scan has been done: its index decided the inversion)
                                         const int raw = (px == fixupIndex) ? fixRaw : rawIndexOf(S, a, b, lfp);
                                         if (needError)
@@ -1056,9 +1107,9 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                         {
                                             const int index = invert ? (indexRange - 1) - raw : raw;
                                             const float t = (float)index * rcpMaxIndex;
-                                            tv[0] = tv[0] + t * ((float)(int)(short)(a & 0xffffu) * A.w[0]);
-                                            tv[1] = tv[1] + t * ((float)(int)(short)(a >> 16) * A.w[1]);
-                                            tv[2] = tv[2] + t * ((float)(int)(short)(b & 0xffffu) * A.w[2]);
+                                            tv[0] = tv[0] + t * pwp[0];
+                                            tv[1] = tv[1] + t * pwp[1];
+                                            tv[2] = tv[2] + t * pwp[2];
                                             tt = tt + t * t;
                                             ts = ts + t;
                                             refCount++;
@@ -1288,8 +1339,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 {
                                     const int px = __builtin_ctz(rem);
                                     u32 a, b;
-                                    float lfp[3];
-                                    pixLoad(px, a, b, lfp);
+                                    float lfp[3], pwp[3];
+                                    pixLoad(px, a, b, lfp, pwp);
                                     const int raw = rawIndexOf(S, a, b, lfp);
                                     subsetError = subsetError + pixelError(S, raw, a, b, lfp);
                                 }
@@ -1661,8 +1712,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
             const int px = 4 * tw + j;
             const bool s1 = ((pmask >> px) & 1u) != 0;
             u32 a, b;
-            float lfp[3];
-            pixLoad(px, a, b, lfp);
+            float lfp[3], pwp[3];
+            pixLoad(px, a, b, lfp, pwp);
             const int c[3] = {(int)(short)(a & 0xffffu), (int)(short)(a >> 16), (int)(short)(b & 0xffffu)};
             int raw = 0;
             if (FAST)
