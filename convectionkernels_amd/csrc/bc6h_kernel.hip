@@ -52,11 +52,11 @@
 // Developer-only counters (-DCVTT_BC6H_PROFILE): [0] partition searches (per wave), [1] subset passes run again after a late
 // duplicate, [2] lazy partitions, [3] lazy partitions with a replay, [4] replayed round slots, [5] eager partitions
 #ifdef CVTT_BC6H_PROFILE
-__device__ unsigned long long g_bc6hProf[16];
+__device__ unsigned long long g_bc6hProf[32];
 #define PROF_COUNT(slot, n) { if (threadIdx.x == 0) atomicAdd(&g_bc6hProf[slot], (unsigned long long)(n)); }
 extern "C" int cvttmi_bc6h_prof_read(unsigned long long *out)
 {
-    unsigned long long zero[16] = {0};
+    unsigned long long zero[32] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bc6hProf), sizeof(zero)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_bc6hProf), zero, sizeof(zero)) != hipSuccess) return -1;
     return 0;
@@ -254,9 +254,14 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
     __shared__ uint8_t s_xb[2][16][4];     // [subset][block][tweak]: bits 2r, 2r+1 = the two spare bits of round (tweak, r) (two-subset form)
     __shared__ uint8_t s_inv[2][16][4];    // [subset][block][tweak]: bit r = round (tweak, r) exchanged its end points (anchor index in the upper half)
 
-    const int lane = threadIdx.x;
-    const int blk = lane >> 2;
-    const int tw = lane & 3;
+    // (not const: REFRESH_LANE() hands the optimiser the same values as "new" ones at the top of every partition, so that the lane
+    // masks (tw > 0, tw == 1, ...) and LDS addresses it derives from them are computed where they are used instead of being
+    // hoisted in front of the whole search and kept -- i.e. spilled -- across it; the lane number comes from v_mbcnt, a
+    // workgroup being one wave)
+    int lane = threadIdx.x;
+    int blk = lane >> 2;
+    int tw = lane & 3;
+#define REFRESH_LANE() do { lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); asm volatile("" : "+v"(lane)); blk = lane >> 2; tw = lane & 3; } while (0)
     const u32 blockIndex = blockIdx.x * 16u + (u32)blk;
     const bool valid = blockIndex < A.numBlocks;
 
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 
     const int numTweakRounds = A.seedPoints < 1 ? 1 : (A.seedPoints > 4 ? 4 : A.seedPoints);
     const int numRefineRounds = A.refineRounds < 1 ? 1 : (A.refineRounds > 3 ? 3 : A.refineRounds);
-    const bool twActive = tw < numTweakRounds;
+    bool twActive = tw < numTweakRounds;
     // the meta rounds the option values leave out (BC67.cpp:2819-2827): never valid, their end points stay the zeros of the
     // canonical build's fresh automatics -- which later rounds are still compared with
     u32 abortMask = 0;
@@ -362,9 +367,22 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 
     // running best (BC67.cpp:2721-2733), the same in the four lanes of a quad
     float bestError = FLT_MAX;
-    int bestMode = 0, bestPartition = 0;
-    u32 bestEP[6] = {0, 0, 0, 0, 0, 0}; // [subset][3 dwords: (e0r|e0g<<16),(e0b|e1r<<16),(e1g|e1b<<16)]
-    u32 bestSwap = 0; // bit s: the winning round of subset s exchanged its end points
+    // The rest of the block's best -- seven words: the encoded end points [subset][3 dwords: (e0r|e0g<<16),(e0b|e1r<<16),(e1g|e1b<<16)]
+    // and mode | partition << 4 | swap << 9 (swap bit s: the winning round of subset s exchanged its end points) -- is computed by
+    // all four lanes of the quad at a commit and KEPT two words per sub-lane (words 2t, 2t+1 in sub-lane t): it is written a few
+    // times per block and read once, and as nine registers per lane it was what the allocator spilled (56 B of scratch).
+    u32 bestShare0 = 0, bestShare1 = 0;
+    auto keepBest = [&](const int (&enc)[2][2][3], int mode, int partition, u32 swap, bool two) {
+        const u32 w0 = ((u32)enc[0][0][0] & 0xffffu) | ((u32)enc[0][0][1] << 16);
+        const u32 w1 = ((u32)enc[0][0][2] & 0xffffu) | ((u32)enc[0][1][0] << 16);
+        const u32 w2 = ((u32)enc[0][1][1] & 0xffffu) | ((u32)enc[0][1][2] << 16);
+        const u32 w3 = two ? (((u32)enc[1][0][0] & 0xffffu) | ((u32)enc[1][0][1] << 16)) : 0u;
+        const u32 w4 = two ? (((u32)enc[1][0][2] & 0xffffu) | ((u32)enc[1][1][0] << 16)) : 0u;
+        const u32 w5 = two ? (((u32)enc[1][1][1] & 0xffffu) | ((u32)enc[1][1][2] << 16)) : 0u;
+        const u32 w6 = (u32)mode | ((u32)partition << 4) | (swap << 9);
+        bestShare0 = tw == 0 ? w0 : tw == 1 ? w2 : tw == 2 ? w4 : w6;
+        bestShare1 = tw == 0 ? w1 : tw == 1 ? w3 : tw == 2 ? w5 : 0u;
+    };
 
     // A mode of the current precision as one wave-uniform word (a scalar register): mode | transformed << 4 | the bits a
     // delta loses per channel (16 - bPrec) << 8, 16, 24.
@@ -520,7 +538,9 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
         constexpr int indexRange = 1 << indexBits;
         const float maxValue = (float)(indexRange - 1);
         const int weightRcp = partitioned ? 4681 : 2185; // g_weightReciprocals[8], [16]
-        const float rcpMaxIndex = T->rcpMaxIndex[indexBits];
+        // (= CvttDeviceTables::rcpMaxIndex[indexBits]: the correctly rounded quotient, folded at compile time -- a literal instead of a
+        // register held from here to the end of the search)
+        constexpr float rcpMaxIndex = 1.0f / (float)(indexRange - 1);
 
         // ---- the quantised end points of a round as kept in LDS ----
         // two-subset precisions (<= 11 bits): two words per round -- r | g << 11 | b[9:0] << 22 per end point -- plus bit 10 of the
@@ -824,9 +844,9 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
             for (int p = 0; p < numPartitions; p++)
             {
                 const u32 partitionMask = partitioned ? (u32)__builtin_amdgcn_readfirstlane((int)T->partition2[p]) : 0u;
-                if (!partitioned)
-                    pcaSeeds(0xffffu, quadU, quadVs);
-                else if ((p & 1) == 0)
+                // (the single-subset search computes its seeds inside the pass loop: with its sixteen-entry interpolant table it has no
+                // registers to hold them across the passes)
+                if (partitioned && (p & 1) == 0)
                 {
                     const u32 pm = T->partition2[p + (tw >> 1)];
                     pcaSeeds((tw & 1) ? pm : (~pm & 0xffffu), quadU, quadVs);
@@ -887,6 +907,8 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             float seedBase[3] = {0.0f, 0.0f, 0.0f}, seedOffset[3] = {0.0f, 0.0f, 0.0f};
                             if (refinePass == 0)
                             {
+                                if (!partitioned)
+                                    pcaSeeds(0xffffu, quadU, quadVs); // (every lane its own copy: four units per block)
 #pragma unroll
                                 for (int ch = 0; ch < 3; ch++)
                                 {
@@ -1211,6 +1233,13 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                             if (newDrop != 0)
                                 forcedDrop |= 1u << __builtin_ctz(newDrop);
                             PROF_COUNT(1, 1)
+#ifdef CVTT_BC6H_PROFILE
+                            if ((lane & 31) == 0 && newDrop != 0)
+                            {
+                                atomicAdd(&g_bc6hProf[8 + __builtin_ctz(newDrop)], 1ull); // which round is forced
+                                atomicAdd(&g_bc6hProf[20 + (__popc(newDrop) > 7 ? 7 : __popc(newDrop))], 1ull); // how many new drops the run found
+                            }
+#endif
                             __syncthreads();
                         }
                     }
@@ -1501,18 +1530,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 }
                             }
                             bestError = wb;
-                            bestMode = (int)(mw & 15u);
-                            bestPartition = p;
-                            bestEP[0] = ((u32)enc[0][0][0] & 0xffffu) | ((u32)enc[0][0][1] << 16);
-                            bestEP[1] = ((u32)enc[0][0][2] & 0xffffu) | ((u32)enc[0][1][0] << 16);
-                            bestEP[2] = ((u32)enc[0][1][1] & 0xffffu) | ((u32)enc[0][1][2] << 16);
-                            if (partitioned)
-                            {
-                                bestEP[3] = ((u32)enc[1][0][0] & 0xffffu) | ((u32)enc[1][0][1] << 16);
-                                bestEP[4] = ((u32)enc[1][0][2] & 0xffffu) | ((u32)enc[1][1][0] << 16);
-                                bestEP[5] = ((u32)enc[1][1][1] & 0xffffu) | ((u32)enc[1][1][2] << 16);
-                            }
-                            bestSwap = (wasSwapped(0, m0) ? 1u : 0u) | ((partitioned && wasSwapped(1, m1)) ? 2u : 0u);
+                            keepBest(enc, (int)(mw & 15u), p, (wasSwapped(0, m0) ? 1u : 0u) | ((partitioned && wasSwapped(1, m1)) ? 2u : 0u), partitioned);
                         }
                     }
                     continue;
@@ -1604,20 +1622,9 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                 if (commit)
                                 {
                                     bestError = combined;
-                                    bestMode = mode;
-                                    bestPartition = p;
-                                    bestEP[0] = ((u32)enc[0][0][0] & 0xffffu) | ((u32)enc[0][0][1] << 16);
-                                    bestEP[1] = ((u32)enc[0][0][2] & 0xffffu) | ((u32)enc[0][1][0] << 16);
-                                    bestEP[2] = ((u32)enc[0][1][1] & 0xffffu) | ((u32)enc[0][1][2] << 16);
-                                    if (partitioned)
-                                    {
-                                        bestEP[3] = ((u32)enc[1][0][0] & 0xffffu) | ((u32)enc[1][0][1] << 16);
-                                        bestEP[4] = ((u32)enc[1][0][2] & 0xffffu) | ((u32)enc[1][1][0] << 16);
-                                        bestEP[5] = ((u32)enc[1][1][1] & 0xffffu) | ((u32)enc[1][1][2] << 16);
-                                    }
                                     // (the indexes of the two rounds are selected again after the search, from these end
                                     // points in the order the rounds had them)
-                                    bestSwap = (wasSwapped(0, meta0) ? 1u : 0u) | ((partitioned && wasSwapped(1, meta1)) ? 2u : 0u);
+                                    keepBest(enc, mode, p, (wasSwapped(0, meta0) ? 1u : 0u) | ((partitioned && wasSwapped(1, meta1)) ? 2u : 0u), partitioned);
                                     needsCommit = false;
                                 }
                             }
@@ -1642,6 +1649,13 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
     // SelectIndexHDR*, BC67.cpp:2503-2595, 2879-2893): the same operations on the same values here, once per block.  Sub-lane t
     // selects pixels 4t ... 4t+3; the quad then puts the words together. ----
     u32 bestIdxLo = 0, bestIdxHi = 0;
+    REFRESH_LANE();
+    // the block's best back from the four sub-lanes
+    const u32 bestEP[6] = {quadBcast<0>(bestShare0), quadBcast<0>(bestShare1), quadBcast<1>(bestShare0),
+                           quadBcast<1>(bestShare1), quadBcast<2>(bestShare0), quadBcast<2>(bestShare1)};
+    const u32 bestW6 = quadBcast<3>(bestShare0);
+    const int bestMode = (int)(bestW6 & 15u), bestPartition = (int)((bestW6 >> 4) & 31u);
+    const u32 bestSwap = bestW6 >> 9;
     {
         const bool partitionedB = T->bc6hModeInfo[bestMode][1] != 0;
         const int aPrecB = (int)T->bc6hModeInfo[bestMode][3];
@@ -1759,7 +1773,9 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
         bestIdxHi = i2 | (i3 << 16);
     }
     // ---- header scatter + indexes (BC67.cpp:2992-3050, BC6H_IO: table from tools/gen_bc6h_layout.py) ----
-    if (valid && tw == 0)
+    // (the block index again, from the refreshed lane number: held since the load it was spilled)
+    const u32 blockIndexOut = blockIdx.x * 16u + (u32)blk;
+    if (blockIndexOut < A.numBlocks && tw == 0)
     {
         const bool partitioned = T->bc6hModeInfo[bestMode][1] != 0;
         const int headerBits = partitioned ? 82 : 65;
@@ -1817,7 +1833,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
         o.y = (u32)(lo >> 32);
         o.z = (u32)hi;
         o.w = (u32)(hi >> 32);
-        *reinterpret_cast<uint4 *>(out + (size_t)blockIndex * 16u) = o;
+        *reinterpret_cast<uint4 *>(out + (size_t)blockIndexOut * 16u) = o;
     }
 }
 
@@ -1840,3 +1856,4 @@ extern "C" hipError_t cvttmi_launch_bc6h(const void *d_blocks, void *d_out, cons
 #undef CVTT_LAUNCH
     return hipGetLastError();
 }
+#undef REFRESH_LANE
