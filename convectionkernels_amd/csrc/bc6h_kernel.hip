@@ -888,6 +888,7 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                         // one word that mixes the three words of a round's end points (equal rounds have equal fingerprints); the words
                         // themselves are read back from the history in LDS in the rare cases that need them
                         u32 myFp[3] = {0, 0, 0};
+                        u32 lateBits = 0; // bit r: the fingerprint of round (tw, r) equals that of a LATER pass of a lower sub-lane
                         u32 myXb = 0, myInv = 0;
                         if (partitioned)
                             s_xb[subset][blk][tw] = 0; // (rounds that have not run yet read as zeros, like the words of the rounds left out)
@@ -1059,6 +1060,18 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                                     continue;
                                 const u32 o0 = quadBcast<0>(myFp[r2]), o1 = quadBcast<1>(myFp[r2]), o2 = quadBcast<2>(myFp[r2]);
                                 same = same | ((tw > 0) & (o0 == fp)) | ((tw > 1) & (o1 == fp)) | ((tw > 2) & (o2 == fp));
+                                if (r2 == refinePass)
+                                {
+                                    // ... and while the lower sub-lanes' fingerprints of THIS pass are here: do they repeat an EARLIER
+                                    // round of this chain?  That round ran without knowing (the late duplicates, after the passes)
+#pragma unroll
+                                    for (int r0 = 0; r0 < 2; r0++)
+                                        if (r0 < refinePass)
+                                        {
+                                            const bool l = ((tw > 0) & (o0 == myFp[r0])) | ((tw > 1) & (o1 == myFp[r0])) | ((tw > 2) & (o2 == myFp[r0]));
+                                            lateBits |= l ? (1u << r0) : 0u;
+                                        }
+                                }
                                 if (r2 < refinePass)
                                     same = same | (myFp[r2] == fp);
                             }
@@ -1172,21 +1185,14 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 
                         // ---- the rounds that were not known in time: (t' < tw, r' > r) ----
                         {
-                            bool anyLate = false; // a round of this chain repeats a LATER pass of a lower tweak
-#ifndef CVTT_BC6H_X_NODUP
-#pragma unroll
-                            for (int r = 0; r < 2; r++)
+                            // (fingerprints: gathered during the passes; the passes the options leave out have zero words, fingerprint 0)
+                            if (numRefineRounds < 3 && tw > 0)
                             {
-                                bool s2 = false;
 #pragma unroll
-                                for (int r2 = r + 1; r2 < 3; r2++)
-                                {
-                                    const u32 o0 = quadBcast<0>(myFp[r2]), o1 = quadBcast<1>(myFp[r2]), o2 = quadBcast<2>(myFp[r2]);
-                                    s2 = s2 | ((tw > 0) & (o0 == myFp[r])) | ((tw > 1) & (o1 == myFp[r])) | ((tw > 2) & (o2 == myFp[r]));
-                                }
-                                anyLate = anyLate || (s2 && twActive && r < numRefineRounds);
+                                for (int r = 0; r < 2; r++)
+                                    lateBits |= (myFp[r] == 0u) ? (1u << r) : 0u;
                             }
-#endif
+                            bool anyLate = twActive && (lateBits & ((1u << numRefineRounds) - 1u) & 3u) != 0;
                             u32 newDrop = 0; // per group: meta rounds that ran although all eight blocks repeat an earlier round
 #ifdef CVTT_BC6H_DBG_NOLATE
                             anyLate = false;
@@ -1535,6 +1541,10 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
                     }
                     continue;
                 }
+#ifdef CVTT_BC6H_X_NOCOMMIT3 // (timing experiment: invalid output)
+                if (p != 31)
+                    continue;
+#endif
                 for (int meta0 = 0; meta0 < 12; meta0++)
                 {
                     const bool valid0 = ((roundValid0 >> meta0) & 1u) != 0;
