@@ -11,7 +11,11 @@ import content
 
 which, lib, wave = sys.argv[1], sys.argv[2], sys.argv[3]
 big = content.config_blocks_hdr(3, 2048, 2048)
-blocks = np.ascontiguousarray(big[177296:177312] if wave == "A" else big[222064:222080])
+if wave in ("A", "B"):
+    blocks = np.ascontiguousarray(big[177296:177312] if wave == "A" else big[222064:222080])
+else:  # "name:edge:first": 16 blocks of config-3 noise of that edge from block `first`
+    _, edge, first = wave.split(":")
+    blocks = np.ascontiguousarray(content.config_blocks_hdr(3, int(edge), int(edge))[int(first):int(first) + 16])
 if which == "cpu":
     from oracle import pyref
     os.environ["ORC_BC6H_TRACE_ON"] = "1"
