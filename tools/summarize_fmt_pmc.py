@@ -36,9 +36,11 @@ for d in sorted(glob.glob(os.path.join(out_dir, "pmc_*"))):
             xcd = c["GRBM_GUI_ACTIVE"] / 8.0
             simd = xcd * 1024
             e["derived"] = {"valu_insts_per_wave": c["SQ_INSTS_VALU"] / (e["grid"] / 64),
-                            "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4 / simd,
+                            # (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU on gfx950 -- profiles/r06/valu_fma_probe_pmc.json -- so the
+                            # "valu_busy_frac" / "cycles_per_valu_inst" of rounds 2-5 said nothing: dropped)
                             "avg_waves_per_simd": c["SQ_WAVE_CYCLES"] * 4 / simd,
-                            "cycles_per_valu_inst": c["SQ_ACTIVE_INST_VALU"] * 4 / c["SQ_INSTS_VALU"]}
+                            "simd_cycles_per_valu_inst": simd / c["SQ_INSTS_VALU"],
+                            "valu_issue_frac_of_2cycle_peak": c["SQ_INSTS_VALU"] * 2 / simd}
         except Exception as ex:  # noqa
             e["derived_error"] = str(ex)
     # second pass: LDS / memory instruction counters of the same kernel

@@ -65,9 +65,12 @@ try:
     d["derived"] = {
         "clock_ghz": xcd_cycles / (d["mean_last20"]["dur_us"] * 1e3),
         "valu_insts_per_wave": c["SQ_INSTS_VALU"] / (int(d["grid"]) / 64),
-        "valu_busy_frac(ACTIVE_INST_VALU*4/simd_cycles)": c["SQ_ACTIVE_INST_VALU"] * 4 / simd_cycles,
+        # (Rounds 2-5 also derived "valu_busy_frac" = SQ_ACTIVE_INST_VALU * 4 / simd_cycles and got 1.1-1.36: on gfx950
+        # SQ_ACTIVE_INST_VALU counts the same events as SQ_INSTS_VALU -- equal to the last digit on the single-instruction
+        # launches of tools/valu_fma_probe.hip, profiles/r06/valu_fma_probe_pmc.json -- so that number was 4 x instructions per
+        # SIMD cycle, not a busy fraction.  The issue fraction below is the one figure these two counters give.)
         "avg_waves_per_simd(WAVE_CYCLES*4/simd_cycles)": c["SQ_WAVE_CYCLES"] * 4 / simd_cycles,
-        "cycles_per_valu_inst": c["SQ_ACTIVE_INST_VALU"] * 4 / c["SQ_INSTS_VALU"],
+        "simd_cycles_per_valu_inst": simd_cycles / c["SQ_INSTS_VALU"],
         # MI355X_MICROARCH.md: a wave64 VALU instruction occupies a SIMD for 2 cycles -> issue peak = simd_cycles / 2
         "valu_issue_frac_of_2cycle_peak": c["SQ_INSTS_VALU"] * 2 / simd_cycles,
     }
