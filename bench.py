@@ -38,9 +38,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # algorithmic (compulsory) bytes per block, SURVEY.md 8(d): PixelBlock in + packed block out
 ALGO_BYTES = {"bc7": 80, "bc1": 72, "bc6hu": 144, "etc2rgba": 80}
 # VALU issue peak: MI355X_MICROARCH.md ("Wave scheduling"): a wave64 VALU instruction occupies its SIMD for 2 cycles, i.e.
-# 256 CUs x 4 SIMDs x clock / 2 wave-instructions per second.  (tools/valu_peak.hip, profiles/r02/valu_peak.json, measures
-# how close real instruction mixes come: 2.3 cycles for pairs of waves whose instructions can overlap -- plain f32
-# add/sub/mul/fma, moves, integer add/logic -- and 4.2-4.4 for everything else: packed, 24-bit multiply, dot, SDWA, DPP.)
+# 256 CUs x 4 SIMDs x clock / 2 wave-instructions per second.  Measured (tools/valu_fma_probe.hip, profiles/r06/
+# valu_peak_reconciled.md): 2.2-2.3 cycles for f32 add / sub / mul / fma whose sources sit in different VGPR banks; min / max,
+# 24-bit multiplies, conversions, v_perm, dot products, packed f32 and any three-source instruction with two sources in one
+# bank take 4.3 -- so no kernel with such instructions can reach frac = 1, and the line does not pretend to know how close it could get.
 VALU_CYCLES_PER_INST = 2.0
 SHADER_CLOCK_HZ = 2.4e9
 
@@ -617,15 +618,6 @@ def roofline_block(fmt, nblk, k_ms, kernel, insts_per_block=None, hbm_bytes_per_
          "peak_source": "MI355X_MICROARCH.md: one wave64 VALU instruction per SIMD per 2 cycles, 1024 SIMDs at %.1f GHz" % (SHADER_CLOCK_HZ / 1e9)}
     if hbm.get("traffic_over_algorithmic") is not None:
         r["traffic_over_algorithmic"] = hbm["traffic_over_algorithmic"]
-    if mix and mix.get("issue_floor_cycles_per_inst"):
-        # The 2-cycle peak holds for plain f32 add / sub / mul, moves, integer add and logic only; everything else occupies the
-        # SIMD for 4.3 cycles (8.3: rcp / sqrt) -- measured, profiles/r02/valu_peak.json.  `valu_mix` prices THIS kernel's
-        # instruction classes (SQ_INSTS_VALU_* of the same profile; tools/valu_mix.py says how, and that it is an estimate):
-        # frac_of_mix_floor = the cycles per instruction its mix needs at full overlap / the cycles it takes.
-        actual = (VALU_PEAK * VALU_CYCLES_PER_INST) / rate  # SIMD cycles per wave instruction, as measured here
-        r["valu_mix"] = dict(mix)
-        r["valu_mix"]["actual_cycles_per_inst"] = actual
-        r["valu_mix"]["frac_of_mix_floor"] = mix["issue_floor_cycles_per_inst"] / actual
     return r
 
 
