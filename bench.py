@@ -424,7 +424,7 @@ def run_sharded(args):
             if pmc and not pmc.get("stale"):
                 result["roofline"] = roofline_block("bc7", nloc, k_ms, "cvttmi_bc7_kernel", insts_per_block=pmc["valu_insts_per_wave"] / 16.0,
                                                     hbm_bytes_per_block=pmc["hbm_bytes_per_launch"] / float(pmc["blocks"]),
-                                                    waves_per_simd=pmc.get("avg_waves_per_simd"), source=pmc["source"], mix=pmc.get("valu_mix"))
+                                                    waves_per_simd=pmc.get("avg_waves_per_simd"), source=pmc["source"])
             else:
                 result["roofline"] = roofline_block("bc7", nloc, k_ms, "cvttmi_bc7_kernel")
             result["roofline"]["note"] = "rank 0's shard (%d blocks) per launch; per-block counters of the 4096^2 profile of the same kernel" % nloc
@@ -585,13 +585,13 @@ def format_counters(src_sha):
                         "hbm_bytes_per_block": (sum(hbm) / blocks[fmt]) if len(hbm) == len(kernels) else None,
                         "avg_waves_per_simd": sum(k["derived"]["avg_waves_per_simd"] * k["dur_us"] for k in kernels if "derived" in k) / dur,
                         "kernels": [k["kernel"] for k in kernels], "profiled_blocks": blocks[fmt],
-                        "valu_mix": max(kernels, key=lambda k: k["dur_us"]).get("valu_mix")}
+                        }
         return out
     except Exception:  # noqa
         return None
 
 
-def roofline_block(fmt, nblk, k_ms, kernel, insts_per_block=None, hbm_bytes_per_block=None, waves_per_simd=None, source=None, mix=None):
+def roofline_block(fmt, nblk, k_ms, kernel, insts_per_block=None, hbm_bytes_per_block=None, waves_per_simd=None, source=None):
     """The roofline of one kernel launch.  The search kernels are VALU-issue bound (72-144 algorithmic bytes per block against
     thousands of instructions), so when the PMC profile of this very library is at hand `bound` is "valu": achieved =
     wave-level VALU instructions per second (SQ_INSTS_VALU of the profile, per block, x the blocks of this launch / the kernel
@@ -640,7 +640,6 @@ def profiled_counters(lib_sha):
                 "hbm_bytes_per_launch": d["hbm_traffic_bytes_per_launch"]["bytes_corrected"],
                 "valu_insts_per_wave": sq["derived"]["valu_insts_per_wave"],
                 "avg_waves_per_simd": sq["derived"].get("avg_waves_per_simd(WAVE_CYCLES*4/simd_cycles)"),
-                "valu_mix": d.get("valu_mix"),
                 "blocks": int(sq["grid"]) // 4}
     except Exception:  # noqa
         return None
@@ -726,7 +725,7 @@ def run_single(args):
         waves = (nblk + 15) // 16
         result["roofline"] = roofline_block("bc7", nblk, k_ms, "cvttmi_bc7_kernel", insts_per_block=pmc["valu_insts_per_wave"] * waves / float(nblk),
                                             hbm_bytes_per_block=pmc["hbm_bytes_per_launch"] / float(nblk),
-                                            waves_per_simd=pmc.get("avg_waves_per_simd"), source=pmc["source"], mix=pmc.get("valu_mix"))
+                                            waves_per_simd=pmc.get("avg_waves_per_simd"), source=pmc["source"])
         result["roofline"]["note"] = ("kernel_ms brackets the launches of one encode on its stream (search + hand-over launch + commit); "
                                       "%d algorithmic bytes per block, so the HBM fraction (`hbm`) is small by construction" % ALGO_BYTES["bc7"])
         result["valu_issue"] = {"insts_per_wave": pmc["valu_insts_per_wave"], "achieved": result["roofline"]["achieved"], "unit": "wave-instructions/s",
@@ -817,7 +816,7 @@ def per_config_legs(torch, api, synth, ctx, dev, h, rcp, rcp_gold, same_lut, arg
         c = next((fmtc[k] for k in ([prof] if isinstance(prof, str) else (prof or [])) if fmtc and isinstance(fmtc.get(k), dict)), None)
         if c:
             roof = roofline_block(fmt, n, ms_min, "+".join(c["kernels"]), insts_per_block=c["valu_wave_insts_per_block"],
-                                  hbm_bytes_per_block=c["hbm_bytes_per_block"], waves_per_simd=c["avg_waves_per_simd"], source=fmtc["source"], mix=c.get("valu_mix"))
+                                  hbm_bytes_per_block=c["hbm_bytes_per_block"], waves_per_simd=c["avg_waves_per_simd"], source=fmtc["source"])
             if c["profiled_blocks"] != n:
                 roof["counters_note"] = "per-block counters of the same kernel on %d blocks of the same kind of content" % c["profiled_blocks"]
         else:

@@ -86,9 +86,12 @@ for d in sorted(glob.glob(os.path.join(out_dir, "pmc_*"))):
         for (kname, _), c5 in d5.items():  # the last dispatch of each kernel stays
             if kname in last and c5.get("SQ_INSTS_VALU"):
                 try:
-                    last[kname]["valu_mix"] = valu_mix.floor(c5, STATIC.get(kname.replace("void ", "")))
+                    # (the counter classes only: the "issue floor" that rounds 4-5 derived from them rested on round 2's
+                    # pairing model, which profiles/r06/valu_peak_reconciled.md retires)
+                    m = valu_mix.floor(c5, STATIC.get(kname.replace("void ", "")))
+                    last[kname]["valu_classes"] = {"fraction_of_valu_instructions": m["fraction_of_valu_instructions"]} if m else None
                 except Exception as ex:  # noqa
-                    last[kname]["valu_mix_error"] = str(ex)
+                    last[kname]["valu_classes_error"] = str(ex)
     summary[fmt] = list(last.values())
     st = glob.glob(os.path.join(out_dir, "trace_" + fmt, "*kernel_stats.csv"))
     if st:

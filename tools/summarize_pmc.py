@@ -95,10 +95,12 @@ try:
     import valu_mix
     name = summary["pmc_sq"][0]["kernel"]
     me = [e for e in summary["pmc_mix"] if e["kernel"] == name][0]
-    summary["valu_mix"] = valu_mix.floor(me["mean_last20"]["counters"], valu_mix.static_split().get(name.replace("void ", "")))
-    summary["valu_mix"]["kernel"] = name
+    # (the counter classes only: the "issue floor" of rounds 4-5 rested on round 2's pairing model, retired by
+    # profiles/r06/valu_peak_reconciled.md)
+    m = valu_mix.floor(me["mean_last20"]["counters"], valu_mix.static_split().get(name.replace("void ", "")))
+    summary["valu_classes"] = {"fraction_of_valu_instructions": m["fraction_of_valu_instructions"], "kernel": name}
 except Exception as e:  # noqa
-    summary["valu_mix_error"] = str(e)
+    summary["valu_classes_error"] = str(e)
 # which kernel objects these counters belong to: bench.py quotes them only while the loaded library still holds the same ones
 try:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
