@@ -50,7 +50,8 @@
 #include <type_traits>
 
 // Developer-only counters (-DCVTT_BC6H_PROFILE): [0] partition searches (per wave), [1] subset passes run again after a late
-// duplicate, [2] lazy partitions, [3] lazy partitions with a replay, [4] replayed round slots, [5] eager partitions
+// duplicate, [2] lazy partitions, [3] lazy partitions with a replay, [4] replayed round slots, [5] eager partitions,
+// [6] several-mode commits worked out without the pair loop, [7] with it
 #ifdef CVTT_BC6H_PROFILE
 __device__ unsigned long long g_bc6hProf[32];
 #define PROF_COUNT(slot, n) { if (threadIdx.x == 0) atomicAdd(&g_bc6hProf[slot], (unsigned long long)(n)); }
@@ -1544,6 +1545,190 @@ __global__ __launch_bounds__(64, CVTT_BC6H_WAVES) void cvttmi_bc6h_kernel(const 
 #ifdef CVTT_BC6H_X_NOCOMMIT3 // (timing experiment: invalid output)
                 if (p != 31)
                     continue;
+#endif
+#ifndef CVTT_BC6H_X_SEQ3
+                if (partitioned)
+                {
+                    // ---- SEVERAL modes at this precision (8 and 11 bits).  What the mode loop below leaves behind, worked out
+                    // without walking the pairs one at a time.  For a pair Y of rounds let S(Y) = the blocks of the group whose
+                    // combined error beats their best just before Y, L_i(Y) = the modes block i's deltas fit at Y, f_i = min L_i.
+                    // The loop commits i in S at EVERY legal mode up to the mode E(Y) where it stops, and it stops at the first mode at
+                    // which somebody commits and nobody of S is left without a commit: E(Y) = max over S of f_i, the last mode when
+                    // somebody of S fits none.  So (1) a block's best error moves exactly as with one mode -- down to the combined
+                    // error of every pair that beats it and is legal in SOME mode -- and its final pair X is the first pair with the
+                    // smallest such error; (2) its mode is the highest one of L(X) that is <= E(X).  (1) is the quad search of the
+                    // one-mode path with a mode mask.  (2) needs the group mates at X only when L(X) holds more than one mode: a mate
+                    // with error(X) >= its best before the search is not in S, one with error(X) < its best AFTER the search is, and
+                    // for one in between S depends on the pairs before X -- when such a mate could raise the mode, the wave takes the
+                    // pair-by-pair loop below instead (nothing has been written by then). ----
+                    const int mask = (1 << aPrec) - 1;
+                    auto fitsOne = [&](u32 mw, int v, int base, int ch) -> bool {
+                        const int lost = (int)((mw >> (8 + 8 * ch)) & 31u);
+                        const int d16 = (int)(short)(unsigned short)(v - base);
+                        const int delta = (int)(short)(unsigned short)((u32)d16 << lost) >> lost;
+                        return ((delta + base) & mask & 0xffff) == (v & mask & 0xffff);
+                    };
+                    auto ownMask = [&](const int (&e)[2][3]) -> u32 {
+                        u32 m = ownDeltaFits(e, modeW0, aPrec) ? 1u : 0u;
+                        if (numModesHere > 1)
+                            m |= ownDeltaFits(e, modeW1, aPrec) ? 2u : 0u;
+                        if (numModesHere > 2)
+                            m |= ownDeltaFits(e, modeW2, aPrec) ? 4u : 0u;
+                        return m;
+                    };
+                    // the modes of `own` that subset 1's end points fit too (deltas against subset 0's first end point)
+                    auto pairMask = [&](u32 own, const int (&e0)[2][3], const int (&x)[2][3]) -> u32 {
+                        u32 m = own;
+#pragma unroll
+                        for (int mi = 0; mi < 3; mi++)
+                        {
+                            if (mi >= numModesHere)
+                                break;
+                            const u32 mw = (mi == 0) ? modeW0 : (mi == 1) ? modeW1 : modeW2;
+                            if ((mw & 16u) == 0)
+                                continue;
+                            bool ok = true;
+#pragma unroll
+                            for (int epi = 0; epi < 2; epi++)
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++)
+                                    ok = ok & fitsOne(mw, x[epi][ch], e0[0][ch], ch);
+                            m &= ok ? ~0u : ~(1u << mi);
+                        }
+                        return m;
+                    };
+                    float localBest = bestError;
+                    int localPair = -1; // meta0 * 16 + meta1
+                    u32 localModes = 0;
+#pragma unroll 1
+                    for (int r = 0; r < 3; r++)
+                    {
+                        const int m0 = 3 * tw + r;
+                        const float err0 = errAt(m0, 0);
+                        bool cand = (((roundValid0 >> m0) & 1u) != 0) & (err0 + minErr1 < localBest);
+                        if (__ballot(cand) == 0)
+                            continue;
+                        int e0[2][3];
+                        loadEPQ(0, m0, e0);
+                        const u32 own = ownMask(e0);
+                        cand = cand & (own != 0);
+                        if (__ballot(cand) == 0)
+                            continue;
+#pragma unroll 1
+                        for (int m1 = 0; m1 < 12; m1++)
+                        {
+                            const float c = err0 + errAt(m1, 1);
+                            bool ok = cand & (((roundValid1 >> m1) & 1u) != 0) & (c < localBest);
+                            if (__ballot(ok) == 0)
+                                continue;
+                            int x[2][3];
+                            loadEPQ(1, m1, x);
+                            const u32 L = pairMask(own, e0, x);
+                            if (ok & (L != 0))
+                            {
+                                localBest = c;
+                                localPair = m0 * 16 + m1;
+                                localModes = L;
+                            }
+                        }
+                    }
+                    float wb = __uint_as_float(quadBcast<0>(__float_as_uint(localBest)));
+                    int wp = (int)quadBcast<0>((u32)localPair);
+                    u32 wL = quadBcast<0>(localModes);
+#define CVTT_QUAD_STEP(Q) { const float ob = __uint_as_float(quadBcast<Q>(__float_as_uint(localBest))); const int op = (int)quadBcast<Q>((u32)localPair); \
+                            const u32 ol = quadBcast<Q>(localModes); const bool lt = ob < wb; wb = lt ? ob : wb; wp = lt ? op : wp; wL = lt ? ol : wL; }
+                    CVTT_QUAD_STEP(1) CVTT_QUAD_STEP(2) CVTT_QUAD_STEP(3)
+#undef CVTT_QUAD_STEP
+                    const bool improved = (wp >= 0) & (wb < bestError);
+                    if (__ballot(improved) == 0)
+                        continue;
+                    const float bestAfter = improved ? wb : bestError;
+                    int modeIdx = improved ? (int)__builtin_ctz(wL | 8u) : 0;
+                    bool walkPairs = false;
+                    u64 toResolve = __ballot(improved & ((wL & (wL - 1u)) != 0) & (tw == 0));
+                    while (toResolve != 0)
+                    {
+                        const int src = (int)__builtin_ctzll(toResolve);
+                        toResolve &= toResolve - 1;
+                        const int X = __builtin_amdgcn_readlane(wp, src);
+                        const u32 Lq = (u32)__builtin_amdgcn_readlane((int)wL, src);
+                        const int k1 = (int)__builtin_ctz(Lq);
+                        const int m0 = X >> 4, m1 = X & 15;
+                        const bool mate = (((lane ^ src) & 32) == 0) & ((lane >> 2) != (src >> 2));
+                        const float ci = errAt(m0, 0) + errAt(m1, 1);
+                        const bool maybeIn = mate & (((roundValid0 >> m0) & 1u) != 0) & (((roundValid1 >> m1) & 1u) != 0) & (ci < bestError);
+                        if (__ballot(maybeIn) == 0)
+                            continue;
+                        int y0[2][3], y1[2][3];
+                        loadEPQ(0, m0, y0);
+                        loadEPQ(1, m1, y1);
+                        const u32 Li = pairMask(ownMask(y0), y0, y1);
+                        const int fi = Li != 0 ? (int)__builtin_ctz(Li) : numModesHere - 1;
+                        // would this mate, if it is in S, carry the loop to a legal mode of the block above k1?
+                        const bool raises = maybeIn & ((Lq & ((2u << fi) - 1u) & ~((2u << k1) - 1u)) != 0);
+                        // in S for certain: the error beats even the best AFTER the search, or this is the pair the mate commits
+                        // itself; a mate whose own pair comes before X has its final best at X (decided by the first test), and
+                        // so has one that does not improve.  Open: a mate whose own pair comes after X, error in between.
+                        const bool inS = (ci < bestAfter) | (improved & (wp == X));
+                        const bool sure = raises & inS;
+                        if (__ballot(raises & !inS & improved & (wp > X)) != 0)
+                        {
+                            walkPairs = true;
+                            break;
+                        }
+                        const u64 sureBits = __ballot(sure);
+                        if (sureBits == 0)
+                            continue;
+                        int E = k1;
+                        if (__ballot(sure & (fi >= 1)) != 0)
+                            E = E > 1 ? E : 1;
+                        if (__ballot(sure & (fi >= 2)) != 0)
+                            E = 2;
+                        const int top = 31 - (int)__builtin_clz(Lq & ((2u << E) - 1u));
+                        if ((lane >> 2) == (src >> 2))
+                            modeIdx = top;
+                    }
+                    if (!walkPairs)
+                    {
+                        if (improved)
+                        {
+                            const u32 mw = (modeIdx == 0) ? modeW0 : (modeIdx == 1) ? modeW1 : modeW2;
+                            const bool transformed = (mw & 16u) != 0;
+                            const int m0 = wp >> 4, m1 = wp & 15;
+                            int e0[2][3], e1[2][3];
+                            loadEPQ(0, m0, e0);
+                            loadEPQ(1, m1, e1);
+                            int enc[2][2][3];
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++)
+                            {
+                                enc[0][0][ch] = e0[0][ch];
+                                enc[0][1][ch] = e0[1][ch];
+                                enc[1][0][ch] = e1[0][ch];
+                                enc[1][1][ch] = e1[1][ch];
+                                if (transformed)
+                                {
+                                    const int lost = (int)((mw >> (8 + 8 * ch)) & 31u);
+#pragma unroll
+                                    for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+                                        for (int epi = 0; epi < 2; epi++)
+                                        {
+                                            if (sb == 0 && epi == 0)
+                                                continue;
+                                            const int d16 = (int)(short)(unsigned short)(enc[sb][epi][ch] - enc[0][0][ch]);
+                                            enc[sb][epi][ch] = (int)(short)(unsigned short)((u32)d16 << lost) >> lost;
+                                        }
+                                }
+                            }
+                            bestError = wb;
+                            keepBest(enc, (int)(mw & 15u), p, (wasSwapped(0, m0) ? 1u : 0u) | (wasSwapped(1, m1) ? 2u : 0u), true);
+                        }
+                        PROF_COUNT(6, 1)
+                        continue;
+                    }
+                    PROF_COUNT(7, 1)
+                }
 #endif
                 for (int meta0 = 0; meta0 < 12; meta0++)
                 {

@@ -16,5 +16,6 @@ for name, b in [("noise (config 3, 1024^2)", synth.tile_blocks(synth.image_f16bi
     v = list(buf)
     print("%-26s %7d blocks: partition searches (per wave) %d, subset passes run again %d (%.4f per search), lazy %d (with replay %d, %d round slots), eager %d"
           % (name, len(b), v[0], v[1], v[1] / max(1, v[0]), v[2], v[3], v[4], v[5]))
+    print("    several-mode commits worked out without the pair loop %d, with it %d" % (v[6], v[7]))
     print("    forced round (tweak, pass) histogram:", {"(%d,%d)" % (m // 3, m % 3): v[8 + m] for m in range(12) if v[8 + m]})
     print("    new drops found per run again:", {k: v[20 + k] for k in range(8) if v[20 + k]})
