@@ -107,6 +107,35 @@ def test_one_context_on_two_streams_and_two_threads(gpu_ctx):
     assert (res["a"] == e1).all() and (res["b"] == e2).all() and (res["c"] == e1).all()
 
 
+def test_two_contexts_on_two_streams_overlap_and_agree(gpu_ctx):
+    """the pipelined caller of bench.py's `two_streams` leg: two contexts, each on its own stream, encode different images at the
+    same time (nothing is shared between contexts: each has its hand-over list, counters and BC6H work space); every output equals
+    the one-context result.  Mixed formats, so that kernels of different shapes are resident together."""
+    import torch
+    from convectionkernels_amd import api, synth
+    n = 1 << 18
+    b1, b2 = _blocks(n, seed=12), _blocks(n, seed=13)
+    t1, t2 = torch.from_numpy(b1).cuda(), torch.from_numpy(b2).cuda()
+    h = torch.from_numpy(synth.tile_blocks(synth.image_f16bits(3, 256, 256))).cuda()
+    want = {"bc7a": gpu_ctx.encode_bc7(t1).cpu().numpy(), "bc7b": gpu_ctx.encode_bc7(t2).cpu().numpy(),
+            "etc": gpu_ctx.encode_etc2_rgba(t2[:32768]).cpu().numpy(), "hdr": gpu_ctx.encode_bc6h(h).cpu().numpy(),
+            "bc1": gpu_ctx.encode_bc1(t1).cpu().numpy()}
+    other = api.Context(0)
+    other.set_rcp_table(gpu_ctx.get_rcp_table())
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    got = []
+    for i in range(4):
+        got.append(("bc7a", gpu_ctx.encode_bc7(t1, stream=sa.cuda_stream)))
+        got.append(("bc7b", other.encode_bc7(t2, stream=sb.cuda_stream)))
+        got.append(("hdr", gpu_ctx.encode_bc6h(h, stream=sa.cuda_stream)))
+        got.append(("etc", other.encode_etc2_rgba(t2[:32768], stream=sb.cuda_stream)))
+        got.append(("bc1", other.encode_bc1(t1, stream=sb.cuda_stream)))
+    torch.cuda.synchronize()
+    for k, o in got:
+        assert (o.cpu().numpy() == want[k]).all(), k
+
+
 def test_wrong_buffers_are_refused(gpu_ctx):
     import torch
     from convectionkernels_amd import api
