@@ -26,10 +26,16 @@
 //     among those is a drop, decided where the reference decides it.  What is not known yet are the rounds (t' < t, r' > r).  They
 //     are compared after the last pass; a group-wide match that only they produce (the first such round in the reference's
 //     order is certain: everything before it is final) is recorded as a forced drop and the subset's three passes run again --
-//     which content does about never (0 of 1.5 M partition searches of the noise image, 2e-4 of them on smooth ramps:
-//     profiles/r06/bc6h_rerun_stats.txt).  The state this converges to is the reference's: by induction over the meta-round
+//     which noise does about never (8e-4 per partition search) and content whose chains converge to the same end points often
+//     (smooth ramps 0.15, a narrow value range 0.92 per search: tools/bc6h_rerun_stats.py, profiles/r06/ab_bc6h.txt).  The
+//     state this converges to is the reference's: by induction over the meta-round
 //     order every round's end points follow from its chain's earlier rounds and their validity, every validity from the end
 //     points of the earlier rounds.
+//   * THE COMMIT.  With one mode at a precision no block looks at its group mates: the loop leaves the first legal pair of rounds
+//     with the smallest combined error, found by the quad (sub-lane t: the pairs of its chain's subset-0 rounds).  With three
+//     modes (8, 11 bits) the loop commits a block at every legal mode up to E = max over S of (first legal mode), S = the mates
+//     that beat their best at that pair; the pair is found the same way and the mode from the mates at that pair, and the wave
+//     walks the pairs like the reference only when a mate's membership of S depends on the pairs before (see the commit code).
 //   * slow indexing: the weighted linear colours of the 8 / 16 interpolants of a round sit in registers and every pixel scans
 //     them in order (strict '<', IndexSelectorHDR.h:125-139); the anchor pixel goes first because its index decides the
 //     endpoint inversion; indexes are not kept (the winner's are selected again, once, after the search).
